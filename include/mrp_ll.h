@@ -1,0 +1,144 @@
+/*
+ * mrp_ll.h — C ABI of the MI355X low-level search engine (libmrp_ll.so).
+ *
+ * Drop-in boundary for ONE path of Sartor02/libMultiRobotPlanning: the per-agent low-level search that the
+ * conflict-tree searches call once per agent and once per conflict-tree child.  The reference has no FFI at this
+ * point — the boundary is a compile-time template concept — so each entry point below names the reference
+ * interface it replaces:
+ *
+ *   LowLevelSearch_t::search(const State& start, PlanResult& out)
+ *       CBS  : AStar<State,Action,Cost,LowLevelEnvironment>            cbs.hpp:248, called at cbs.hpp:99-101,155-157
+ *       ECBS : AStarEpsilon<State,Action,Cost,LowLevelEnvironment>(w)  ecbs.hpp:421-422, called at ecbs.hpp:126-129,265-268
+ *       search bodies: a_star.hpp:63-161, a_star_epsilon.hpp:86-285
+ *   LowLevelEnvironment(env, agentIdx, constraints[, solution])        cbs.hpp:209-217, ecbs.hpp:365-375
+ *       -> Environment::setLowLevelContext                              example/ecbs.cpp:264-274, example/cbs.cpp:266-276
+ *   Environment::{admissibleHeuristic,isSolution,getNeighbors,stateValid,transitionValid,
+ *                 focalStateHeuristic,focalTransitionHeuristic}         example/ecbs.cpp:276-312,352-399,497-510
+ *   PlanResult{states,actions,cost,fmin}                                planresult.hpp:18-27
+ *   Environment::onExpandLowLevelNode (the metric's numerator)          example/ecbs.cpp:476-479
+ *
+ * Because a device cannot call back into C++ templates, everything the search reads is passed explicitly in
+ * mrp_ll_job: the static map, the agent's start/goal, its vertex/edge constraint sets and (ECBS) the other agents'
+ * current paths that the focal heuristics consult.  Jobs of one batch are independent; results are bit-identical to
+ * the reference's integers (cost, fmin, path, expansion count) for the grid MAPF Environment of example/ecbs.cpp and
+ * example/cbs.cpp.  All buffers are caller-owned; no pointer outlives the call that received it (for
+ * mrp_ll_submit: the matching mrp_ll_wait).
+ *
+ * A context is NOT thread-safe; use one per host thread.  There is no CPU fallback: every entry point fails with
+ * MRP_LL_E_DEVICE when no HIP device is usable.
+ */
+#ifndef MRP_LL_H
+#define MRP_LL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes of the API calls ------------------------------------------------------------------------- */
+#define MRP_LL_SUCCESS 0
+#define MRP_LL_E_INVALID (-1)  /* bad argument (NULL pointer, unknown map id, dimension out of range, ...)   */
+#define MRP_LL_E_DEVICE (-2)   /* HIP error / no device; see mrp_ll_last_error()                            */
+#define MRP_LL_E_NOMEM (-3)
+#define MRP_LL_E_BUSY (-4)     /* no free ticket for mrp_ll_submit                                          */
+
+/* ---- search algorithm of a job ----------------------------------------------------------------------------- */
+#define MRP_LL_ASTAR 0     /* a_star.hpp AStar::search          (CBS low level)  */
+#define MRP_LL_ASTAR_EPS 1 /* a_star_epsilon.hpp AStarEpsilon   (ECBS low level) */
+
+/* ---- per-job status (mrp_ll_result.status) ----------------------------------------------------------------- */
+#define MRP_LL_OK 0             /* search() returned true                                                    */
+#define MRP_LL_NO_SOLUTION 1    /* search() returned false: open list exhausted (a_star.hpp:160)              */
+#define MRP_LL_CAP_EXPANSIONS 2 /* job.max_expansions exceeded (the reference has no cap and would keep going) */
+#define MRP_LL_CAP_NODES 3      /* per-search node arena exhausted (mrp_ll_options.arena_nodes)               */
+#define MRP_LL_CAP_HORIZON 4    /* a state beyond mrp_ll_options.max_horizon would have been generated         */
+#define MRP_LL_BAD_JOB 5        /* job rejected on the host (unknown map, start/goal outside the grid, ...)    */
+#define MRP_LL_PATH_TRUNCATED 6 /* solved, but result.states_cap was too small; cost/fmin/expanded are valid    */
+
+/* Action codes == enum class Action of example/ecbs.cpp:49-55 */
+#define MRP_LL_ACT_UP 0
+#define MRP_LL_ACT_DOWN 1
+#define MRP_LL_ACT_LEFT 2
+#define MRP_LL_ACT_RIGHT 3
+#define MRP_LL_ACT_WAIT 4
+
+typedef struct mrp_ll_ctx mrp_ll_ctx;
+
+typedef struct mrp_ll_options {
+  int32_t device;          /* HIP device ordinal                                                             */
+  int32_t n_tickets;       /* batches that may be in flight at once (0 = default 4)                           */
+  int32_t slots;           /* resident searches per in-flight batch (0 = default 1024)                        */
+  int32_t arena_nodes;     /* HBM node capacity per search before MRP_LL_CAP_NODES (0 = default 131072)       */
+  int32_t max_horizon;     /* largest state time + 1 (0 = default 512, max 1024)                              */
+  int32_t max_cells;       /* largest dimx*dimy accepted by mrp_ll_upload_map (0 = default 4096, max 65025)   */
+  int32_t lds_nodes;       /* node capacity of the LDS-resident fast tier (0 = default, <0 = disable LDS tier) */
+  int32_t reserved;
+} mrp_ll_options;
+
+/* One low-level search == one LowLevelEnvironment + one LowLevelSearch_t::search call of the reference. */
+typedef struct mrp_ll_job {
+  int32_t map_id;  /* from mrp_ll_upload_map                                                                  */
+  int32_t algo;    /* MRP_LL_ASTAR | MRP_LL_ASTAR_EPS                                                         */
+  float w;         /* suboptimality bound, binary32 exactly as AStarEpsilon::m_w (a_star_epsilon.hpp:386)      */
+  int32_t agent_idx; /* index of this agent inside `path_*` (its own entry is ignored, ecbs.cpp:287)          */
+  int32_t start_x, start_y; /* start State is (time 0, x, y)  (ecbs.cpp:571)                                  */
+  int32_t goal_x, goal_y;   /* m_goals[agentIdx]              (ecbs.cpp:573)                                  */
+  int32_t n_vertex_constraints;
+  const int32_t* vertex_constraints; /* [n][3] = time, x, y           (ecbs.cpp:108-112)                      */
+  int32_t n_edge_constraints;
+  const int32_t* edge_constraints;   /* [n][5] = time, x1, y1, x2, y2 (ecbs.cpp:140-147)                      */
+  /* ECBS focal context: the CT node's `solution` vector (ecbs.hpp:381-389). Ignored for MRP_LL_ASTAR. */
+  int32_t n_agents;                  /* solution.size(); 0 = no context                                       */
+  const int32_t* path_len;           /* [n_agents] states per path; 0 = empty path, skipped (ecbs.cpp:287)    */
+  const int32_t* const* path_xy;     /* [n_agents] -> [path_len][2] = x, y at time 0,1,2,...                  */
+  int64_t max_expansions;            /* < 0: unlimited                                                        */
+} mrp_ll_job;
+
+typedef struct mrp_ll_result {
+  int32_t status;   /* MRP_LL_OK ... */
+  int32_t cost;     /* PlanResult::cost  (valid when status == MRP_LL_OK / MRP_LL_PATH_TRUNCATED)             */
+  int32_t fmin;     /* PlanResult::fmin  (a_star_epsilon.hpp:210, a_star.hpp:104)                              */
+  int32_t n_states; /* PlanResult::states.size(); actions.size() == n_states - 1                              */
+  int64_t expanded; /* calls of onExpandNode during this search (counts the goal pop)                         */
+  int32_t* states_txy; /* caller buffer [states_cap][3] = time, x, y ; may be NULL                            */
+  int32_t* actions;    /* caller buffer [states_cap]    = MRP_LL_ACT_* ; may be NULL                          */
+  int32_t states_cap;
+  int32_t tier;     /* 0 = finished in the LDS tier, 1 = migrated to the HBM arena (diagnostic)               */
+} mrp_ll_result;
+
+typedef struct mrp_ll_stats {
+  int64_t launches;          /* kernel launches so far                                                        */
+  int64_t jobs;              /* searches run                                                                  */
+  int64_t expansions;        /* low-level expansions summed over all searches                                 */
+  int64_t nodes_created;     /* heap pushes summed over all searches                                          */
+  int64_t migrated;          /* searches that left the LDS tier                                               */
+  double kernel_ms;          /* sum of hipEvent-measured kernel durations (on the launching stream)           */
+  double h2d_ms, d2h_ms;     /* hipEvent-measured copy durations                                              */
+} mrp_ll_stats;
+
+int mrp_ll_create(const mrp_ll_options* opt, mrp_ll_ctx** out);
+void mrp_ll_destroy(mrp_ll_ctx* ctx);
+const char* mrp_ll_last_error(const mrp_ll_ctx* ctx);
+
+/* Static map (Environment ctor, ecbs.cpp:249-259): obstacles as [n][2] = x, y.  Uploaded once, used by any job. */
+int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t n_obstacles, const int32_t* obstacles_xy,
+                      int32_t* map_id);
+
+/* Blocking: run n_jobs independent searches, fill results[i] for jobs[i]. */
+int mrp_ll_search_batch(mrp_ll_ctx* ctx, int32_t n_jobs, const mrp_ll_job* jobs, mrp_ll_result* results);
+
+/* Asynchronous form of the same call: submit returns a ticket; results are valid after mrp_ll_wait(ticket). */
+int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t n_jobs, const mrp_ll_job* jobs, mrp_ll_result* results, int32_t* ticket);
+int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket);
+
+int mrp_ll_get_stats(const mrp_ll_ctx* ctx, mrp_ll_stats* out);
+int mrp_ll_reset_stats(mrp_ll_ctx* ctx);
+
+/* Library version / build info ("gfx950 ..."). */
+const char* mrp_ll_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRP_LL_H */

@@ -1,0 +1,13 @@
+"""MI355X-native low-level search engine for CBS / ECBS (the one hot path of Sartor02/libMultiRobotPlanning).
+
+Layout:
+  csrc/ll_kernel.hip      hand-written gfx950 kernels: A* / focal A*-epsilon over (time, cell) states
+  csrc/mrp_ll_host.cpp    C-ABI (include/mrp_ll.h): context, map upload, batch packing, launch, results
+  csrc/hl/                host-side C++ conflict-tree drivers (CBS, ECBS) that call the C-ABI (include/mrp_hl.h)
+  ll.py / hl.py           ctypes plumbing used by tests and bench.py
+
+The product path never imports ``oracle`` and has no CPU fallback.
+"""
+from . import _build  # noqa: F401
+
+__all__ = ["ll", "hl", "_build"]

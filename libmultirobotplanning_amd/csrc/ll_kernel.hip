@@ -1,0 +1,557 @@
+// Low-level space-time searches of CBS / ECBS as hand-written HIP for gfx950 (MI355X, CDNA4).
+//
+// One 64-lane wavefront (== one workgroup) runs ONE low-level search at a time and pulls searches from the batch's
+// job queue until it is empty.  Inside a search the reference's sequential semantics are replayed verbatim — the
+// results of A*-epsilon depend on the tie order of boost::heap::d_ary_heap — so the open list, the
+// focal list and the ordered walk are exact array-heap emulations executed wave-uniformly (scalar control flow), while
+// the 64 lanes are used for everything whose order cannot be observed:
+//   * the five successor probes of an expansion (bounds, obstacle, vertex constraint, closed/open membership — all
+//     one bit test in a per-search (time, cell) bitmap; edge constraints by key compare) run on lanes 0..4;
+//   * the O(N) focal heuristics (ecbs.cpp:282-312) are two coalesced row loads of the other agents' positions and a
+//     ballot + popcount per discovered successor;
+//   * bitmap rows are initialised lazily, 64 words per instruction.
+// Search state lives in LDS (fast tier); a search that outgrows it migrates to a per-workgroup HBM arena and
+// continues with the same code instantiated for global pointers.
+//
+// Reference semantics implemented here (file:line in /root/reference):
+//   AStarEpsilon::search   include/libMultiRobotPlanning/a_star_epsilon.hpp:86-285
+//   AStar::search          include/libMultiRobotPlanning/a_star.hpp:63-161
+//   Environment (grid)     example/ecbs.cpp:264-312,352-399,497-510  (example/cbs.cpp identical minus focal parts)
+//   heap rules             boost::heap::d_ary_heap<arity<2>, mutable_<true>> as restated in oracle/heap_restated.hpp
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ll_device.h"
+
+namespace mrp {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+
+#define DEVI __device__ __forceinline__
+
+DEVI uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+DEVI int32_t rfli(int32_t v) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)v); }
+DEVI uint64_t rfl64(uint64_t v) {
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// ---- entry packing ---------------------------------------------------------------------------------------------
+DEVI uint64_t packEntry(uint32_t fh, uint32_t f, uint32_t g, uint32_t id) {
+  return ((uint64_t)(kFhMax - fh) << (kIdBits + kGBits + kFBits)) | ((uint64_t)(kFMax - f) << (kIdBits + kGBits)) |
+         ((uint64_t)g << kIdBits) | id;
+}
+DEVI int32_t entryF(uint64_t e) { return (int32_t)(kFMax - (uint32_t)((e >> (kIdBits + kGBits)) & kFMax)); }
+DEVI uint32_t entryId(uint64_t e) { return (uint32_t)e & kIdMask; }
+DEVI uint32_t openKey(uint64_t e) { return (uint32_t)(e >> kIdBits) & kOpenKeyMask; }
+DEVI uint64_t focalKey(uint64_t e) { return e >> kIdBits; }
+
+// ---- memory tiers ----------------------------------------------------------------------------------------------
+// AS = 3: LDS, AS = 1: global (HBM arena).  Heap arrays are stored with a one-element bias so that the two children
+// (2i+1, 2i+2) of any node form one 16-byte aligned pair -> a single ds_read_b128 / global_load_dwordx4.
+template <int AS>
+struct Mem {
+  typedef __attribute__((address_space(AS))) uint64_t* P64;
+  typedef __attribute__((address_space(AS))) uint32_t* P32;
+  typedef __attribute__((address_space(AS))) u32x4* PNode;
+  typedef __attribute__((address_space(AS))) u64x2* PPair;
+  PNode nodes;   // x | y<<8 | t<<16 | act<<27 ; parent id ; focalH ; position in the open array
+  P64 open;      // biased: element i at open[i] (pointer already includes the +1 bias)
+  P64 focal;
+  P64 aux;       // std::priority_queue of the ordered walk: (openKey << 32) | open index
+  P32 bits;      // (time, cell) bitmap: 1 = obstacle | vertex constraint | already discovered
+  uint32_t capNodes, capRows, rowWords;
+};
+
+struct Ctx {  // wave-uniform job context
+  uint32_t dimx, dimy, wpr, gx, gy, sx, sy;
+  int32_t lastGoal;
+  float w;
+  uint32_t nVc, nEc;
+  const uint32_t* vc;
+  const uint32_t* ec;
+  const uint32_t* obst;     // global obstacle bitmap
+  const uint16_t* paths;
+  uint32_t nAgentsPad, tPad;
+  int64_t maxExp;
+};
+
+struct SState {  // wave-uniform search state (kept in SGPRs by construction)
+  uint32_t nNodes, nOpen, nFocal, rowsReady;
+  int32_t bestF;
+  int64_t expansions;
+};
+
+enum : int { RUN_MIGRATE_NODES = -1, RUN_MIGRATE_ROWS = -2 };
+constexpr int32_t ST_CAP_FOCAL = 7;
+
+template <int AS>
+DEVI uint64_t ld64(typename Mem<AS>::P64 p, uint32_t i) { return rfl64(p[i]); }
+
+template <int AS>
+DEVI void ldPair(typename Mem<AS>::P64 p, uint32_t i, uint64_t& a, uint64_t& b) {  // i odd -> 16-byte aligned
+  u64x2 v = *(typename Mem<AS>::PPair)(p + i);
+  a = rfl64(v.x);
+  b = rfl64(v.y);
+}
+
+// ---- heap primitives (wave-uniform; OPEN=true maintains the handle -> position map inside the node record) -----
+template <int AS, bool OPEN>
+DEVI void heapStore(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx, uint64_t e) {
+  heap[idx] = e;
+  if (OPEN) ((typename Mem<AS>::P32)m.nodes)[entryId(e) * 4 + 3] = idx;
+}
+template <bool OPEN>
+DEVI bool keyLess(uint64_t a, uint64_t b) {  // the reference's "operator<": a is WORSE than b
+  return OPEN ? (openKey(a) < openKey(b)) : (focalKey(a) < focalKey(b));
+}
+
+// boost siftup: while cmp(parent, child) swap
+template <int AS, bool OPEN>
+DEVI void siftUp(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx, uint64_t e) {
+  while (idx != 0) {
+    uint32_t parent = (idx - 1) >> 1;
+    uint64_t pe = ld64<AS>(heap, parent);
+    if (!keyLess<OPEN>(pe, e)) break;
+    heapStore<AS, OPEN>(m, heap, idx, pe);
+    idx = parent;
+  }
+  heapStore<AS, OPEN>(m, heap, idx, e);
+}
+
+// boost siftdown of element e starting from hole idx in a heap of n elements: choose the first maximal child,
+// move down while !cmp(child, e)
+template <int AS, bool OPEN>
+DEVI void siftDown(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t n, uint32_t idx, uint64_t e) {
+  for (;;) {
+    uint32_t c = 2 * idx + 1;
+    if (c >= n) break;
+    uint64_t e1, e2;
+    ldPair<AS>(heap, c, e1, e2);
+    uint32_t pick = c;
+    uint64_t pe = e1;
+    if (c + 1 < n && keyLess<OPEN>(e1, e2)) {
+      pick = c + 1;
+      pe = e2;
+    }
+    if (keyLess<OPEN>(pe, e)) break;
+    heapStore<AS, OPEN>(m, heap, idx, pe);
+    idx = pick;
+  }
+  heapStore<AS, OPEN>(m, heap, idx, e);
+}
+
+// boost pop: swap(front, back), drop back, siftdown(0)
+template <int AS, bool OPEN>
+DEVI void heapPop(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t& n) {
+  n -= 1;
+  if (n == 0) return;
+  uint64_t last = ld64<AS>(heap, n);
+  siftDown<AS, OPEN>(m, heap, n, 0, last);
+}
+
+// boost erase(handle): swap the element up to the root unconditionally, then pop
+template <int AS>
+DEVI void openErase(Mem<AS>& m, uint32_t& n, uint32_t idx) {
+  while (idx != 0) {
+    uint32_t parent = (idx - 1) >> 1;
+    uint64_t pe = ld64<AS>(m.open, parent);
+    heapStore<AS, true>(m, m.open, idx, pe);
+    idx = parent;
+  }
+  heapPop<AS, true>(m, m.open, n);
+}
+
+// ---- ordered walk (open.ordered_begin(), a_star_epsilon.hpp:141-152) ----------------------------------------
+// libstdc++ std::priority_queue<…> restated: __push_heap / __adjust_heap of bits/stl_heap.h.
+template <int AS>
+DEVI void auxPush(Mem<AS>& m, uint32_t& npq, uint64_t v) {
+  uint32_t hole = npq++;
+  while (hole > 0) {
+    uint32_t parent = (hole - 1) >> 1;
+    uint64_t pe = ld64<AS>(m.aux, parent);
+    if (!((uint32_t)(pe >> 32) < (uint32_t)(v >> 32))) break;
+    m.aux[hole] = pe;
+    hole = parent;
+  }
+  m.aux[hole] = v;
+}
+template <int AS>
+DEVI uint32_t auxPop(Mem<AS>& m, uint32_t& npq) {
+  uint64_t result = ld64<AS>(m.aux, 0);
+  uint64_t value = ld64<AS>(m.aux, npq - 1);
+  npq -= 1;
+  int32_t len = (int32_t)npq;
+  if (len > 0) {
+    int32_t hole = 0, child = 0;
+    while (child < (len - 1) / 2) {
+      child = 2 * (child + 1);
+      uint64_t l, r;  // l = aux[child-1] (odd index), r = aux[child]
+      ldPair<AS>(m.aux, (uint32_t)child - 1, l, r);
+      uint64_t pe = r;
+      if ((uint32_t)(r >> 32) < (uint32_t)(l >> 32)) {
+        child--;
+        pe = l;
+      }
+      m.aux[hole] = pe;
+      hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+      child = 2 * (child + 1);
+      m.aux[hole] = ld64<AS>(m.aux, (uint32_t)child - 1);
+      hole = child - 1;
+    }
+    while (hole > 0) {
+      int32_t parent = (hole - 1) / 2;
+      uint64_t pe = ld64<AS>(m.aux, (uint32_t)parent);
+      if (!((uint32_t)(pe >> 32) < (uint32_t)(value >> 32))) break;
+      m.aux[hole] = pe;
+      hole = parent;
+    }
+    m.aux[hole] = value;
+  }
+  return (uint32_t)result;  // low 32 bits = index into the open array
+}
+
+template <int AS>
+DEVI void orderedWalk(Mem<AS>& m, SState& s, const Ctx& c, int32_t oldBest) {
+  // int * float products in binary32, no contraction (a_star_epsilon.hpp:145,149)
+  const float lo = __fmul_rn((float)oldBest, c.w);
+  const float hi = __fmul_rn((float)s.bestF, c.w);
+  uint32_t npq = 0, cur = 0;
+  for (;;) {
+    uint32_t first = 2 * cur + 1;
+    if (first < s.nOpen) {
+      uint64_t e1, e2;
+      ldPair<AS>(m.open, first, e1, e2);
+      auxPush<AS>(m, npq, ((uint64_t)openKey(e1) << 32) | first);
+      if (first + 1 < s.nOpen) auxPush<AS>(m, npq, ((uint64_t)openKey(e2) << 32) | (first + 1));
+    }
+    uint64_t e = ld64<AS>(m.open, cur);
+    float fv = (float)entryF(e);
+    if (fv > lo && fv <= hi) {
+      siftUp<AS, false>(m, m.focal, s.nFocal, e);
+      s.nFocal += 1;
+    }
+    if (fv > hi) break;
+    if (npq == 0) break;
+    cur = auxPop<AS>(m, npq);
+  }
+}
+
+// ---- lazy bitmap rows: row t = obstacles | vertex constraints at time t | states already discovered --------
+template <int AS>
+DEVI void ensureRows(Mem<AS>& m, SState& s, const Ctx& c, uint32_t t1, const uint32_t* obstGlobal,
+                     typename Mem<AS>::P32 obstLocal, bool useLocal) {
+  if (t1 < s.rowsReady) return;
+  const uint32_t lane = threadIdx.x;
+  uint32_t r0 = s.rowsReady;
+  uint32_t r1 = t1 + 4;
+  if (r1 > m.capRows) r1 = m.capRows;
+  for (uint32_t r = r0; r < r1; ++r)
+    for (uint32_t wd = lane; wd < c.wpr; wd += 64)
+      m.bits[r * m.rowWords + wd] = useLocal ? obstLocal[wd] : obstGlobal[wd];
+  __syncthreads();
+  for (uint32_t j = lane; j < c.nVc; j += 64) {
+    uint32_t v = c.vc[j];
+    uint32_t tt = v >> 16, cell = v & 0xFFFFu;
+    if (tt >= r0 && tt < r1) {
+      uint32_t* p = (uint32_t*)(m.bits + tt * m.rowWords + (cell >> 5));
+      atomicOr(p, 1u << (cell & 31));
+    }
+  }
+  __syncthreads();
+  s.rowsReady = r1;
+}
+
+// ---- one search in one tier ------------------------------------------------------------------------------------
+template <int AS, bool EPS>
+DEVI void initSearch(Mem<AS>& m, SState& s, const Ctx& c) {
+  uint32_t h0 = (c.sx > c.gx ? c.sx - c.gx : c.gx - c.sx) + (c.sy > c.gy ? c.sy - c.gy : c.gy - c.sy);
+  s.nNodes = 1;
+  s.nOpen = 1;
+  s.nFocal = EPS ? 1 : 0;
+  s.rowsReady = 0;
+  s.bestF = (int32_t)h0;
+  s.expansions = 0;
+  u32x4 n0;
+  n0.x = c.sx | (c.sy << 8) | (0u << 16) | (7u << 27);
+  n0.y = kNoParent;
+  n0.z = 0;
+  n0.w = 0;
+  m.nodes[0] = n0;
+  uint64_t e0 = packEntry(0, h0, 0, 0);
+  m.open[0] = e0;
+  if (EPS) m.focal[0] = e0;
+}
+
+// Returns a status (>= 0) when the search ended, or RUN_MIGRATE_* when this tier is too small to continue.
+template <int AS, bool EPS>
+DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 obstLocal,
+                   typename Mem<AS>::P32 ecLocal, bool useLocal, DevResult& res, uint16_t* outPath) {
+  const uint32_t lane = threadIdx.x;
+  for (;;) {
+    if (s.nOpen == 0) return ST_NO_SOLUTION;
+    uint64_t topE = ld64<AS>(m.open, 0);
+    uint64_t curE = topE;
+    if (EPS) {
+      int32_t oldBest = s.bestF;
+      s.bestF = entryF(topE);
+      if (s.bestF > oldBest) orderedWalk<AS>(m, s, c, oldBest);
+      curE = ld64<AS>(m.focal, 0);
+    }
+    const uint32_t curId = entryId(curE);
+    u32x4 nd = m.nodes[curId];
+    const uint32_t xyt = rfl(nd.x);
+    const uint32_t x = xyt & 0xFF, y = (xyt >> 8) & 0xFF, t = (xyt >> 16) & 0x7FF;
+    const uint32_t curFh = rfl(nd.z);
+    const uint32_t curPos = rfl(nd.w);
+    const bool isGoal = (x == c.gx) && (y == c.gy) && ((int32_t)t > c.lastGoal);
+    if (!isGoal) {
+      if (s.nNodes + 5 > m.capNodes) return RUN_MIGRATE_NODES;
+      if (t + 1 >= m.capRows) return RUN_MIGRATE_ROWS;
+    }
+    // other agents' positions at t and t+1 (issued early; consumed after the heap pops)
+    uint32_t a0 = kEmptyCell, b0 = kEmptyCell, a1 = kEmptyCell, b1 = kEmptyCell;
+    const uint16_t* rowA = nullptr;
+    const uint16_t* rowB = nullptr;
+    if (EPS && c.nAgentsPad && !isGoal) {
+      uint32_t ra = t < c.tPad ? t : c.tPad - 1;
+      uint32_t rb = (t + 1) < c.tPad ? (t + 1) : c.tPad - 1;
+      rowA = c.paths + (size_t)ra * c.nAgentsPad;
+      rowB = c.paths + (size_t)rb * c.nAgentsPad;
+      if (lane < c.nAgentsPad) {  // rows are n_agents_pad (multiple of 16) entries long
+        a0 = rowA[lane];
+        b0 = rowB[lane];
+      }
+      if (64 + lane < c.nAgentsPad) {
+        a1 = rowA[64 + lane];
+        b1 = rowB[64 + lane];
+      }
+    }
+
+    s.expansions += 1;  // onExpandNode (a_star_epsilon.hpp:193 / a_star.hpp:87) — counts the goal pop too
+    if (c.maxExp >= 0 && s.expansions > c.maxExp) return ST_CAP_EXP;
+
+    if (isGoal) {
+      res.cost = (int32_t)t;
+      res.fmin = EPS ? entryF(topE) : entryF(curE);
+      res.n_states = (int32_t)t + 1;
+      uint32_t nid = curId;
+      for (int32_t k = (int32_t)t; k >= 0; --k) {  // follow cameFrom (a_star_epsilon.hpp:198-208)
+        u32x4 pn = m.nodes[nid];
+        if (lane == 0) outPath[k] = (uint16_t)(pn.x & 0xFFFF);
+        nid = rfl(pn.y);
+      }
+      return ST_OK;
+    }
+
+    if (EPS) {
+      heapPop<AS, false>(m, m.focal, s.nFocal);
+      openErase<AS>(m, s.nOpen, curPos);
+    } else {
+      heapPop<AS, true>(m, m.open, s.nOpen);
+    }
+
+    const uint32_t t1 = t + 1;
+    ensureRows<AS>(m, s, c, t1, c.obst, obstLocal, useLocal);
+
+    // successors in the reference's order Wait, Left, Right, Up, Down (ecbs.cpp:365-398) on lanes 0..4
+    const int32_t dx = (lane == 2) - (lane == 1);
+    const int32_t dy = (lane == 3) - (lane == 4);
+    const uint32_t nx = x + (uint32_t)dx, ny = y + (uint32_t)dy;
+    const bool inb = (lane < 5) && (nx < c.dimx) && (ny < c.dimy);
+    const uint32_t ncell = inb ? ny * c.dimx + nx : 0;
+    const uint32_t curCell = y * c.dimx + x;
+    uint32_t word = m.bits[t1 * m.rowWords + (ncell >> 5)];
+    bool ok = inb && !((word >> (ncell & 31)) & 1u);
+    if (c.nEc) {  // transitionValid (ecbs.cpp:505-510)
+      const uint32_t key = (t << 19) | (curCell << 3) | lane;
+      for (uint32_t j = 0; j < c.nEc; ++j) {
+        uint32_t e = (j < 64) ? ecLocal[j] : c.ec[j];
+        ok = ok && (e != key);
+      }
+    }
+    uint64_t mask = __ballot(ok) & 0x1Full;
+
+    while (mask) {
+      const uint32_t k = (uint32_t)__builtin_ctzll(mask);
+      mask &= mask - 1;
+      const uint32_t cx = __builtin_amdgcn_readlane(nx, k);
+      const uint32_t cy = __builtin_amdgcn_readlane(ny, k);
+      const uint32_t cc = __builtin_amdgcn_readlane(ncell, k);
+      uint32_t fh = curFh;
+      if (EPS && c.nAgentsPad) {
+        // focalStateHeuristic (ecbs.cpp:282-295) + focalTransitionHeuristic (ecbs.cpp:298-312)
+        uint32_t cnt = __popcll(__ballot(b0 == cc)) + __popcll(__ballot(a0 == cc && b0 == curCell));
+        if (c.nAgentsPad > 64) {
+          cnt += __popcll(__ballot(b1 == cc)) + __popcll(__ballot(a1 == cc && b1 == curCell));
+          for (uint32_t base = 128; base < c.nAgentsPad; base += 64) {
+            uint32_t av = kEmptyCell, bv = kEmptyCell;
+            if (base + lane < c.nAgentsPad) {
+              av = rowA[base + lane];
+              bv = rowB[base + lane];
+            }
+            cnt += __popcll(__ballot(bv == cc)) + __popcll(__ballot(av == cc && bv == curCell));
+          }
+        }
+        fh += cnt;
+        if (fh > kFhMax) return ST_CAP_FOCAL;
+      }
+      const uint32_t h = (cx > c.gx ? cx - c.gx : c.gx - cx) + (cy > c.gy ? cy - c.gy : c.gy - cy);
+      const uint32_t f = t1 + h;
+      const uint32_t nid = s.nNodes;
+      s.nNodes += 1;
+      u32x4 nn;
+      nn.x = cx | (cy << 8) | (t1 << 16) | (k << 27);
+      nn.y = curId;
+      nn.z = fh;
+      nn.w = 0;
+      m.nodes[nid] = nn;
+      {  // mark (t1, cell) discovered: stands for stateToHeap / closedSet membership (a_star_epsilon.hpp:224-227)
+        uint32_t wi = t1 * m.rowWords + (cc >> 5);
+        uint32_t wv = rfl(m.bits[wi]);
+        m.bits[wi] = wv | (1u << (cc & 31));
+      }
+      const uint64_t e = packEntry(fh, f, t1, nid);
+      siftUp<AS, true>(m, m.open, s.nOpen, e);
+      s.nOpen += 1;
+      if (EPS) {
+        if ((float)(int32_t)f <= __fmul_rn((float)s.bestF, c.w)) {  // a_star_epsilon.hpp:240
+          siftUp<AS, false>(m, m.focal, s.nFocal, e);
+          s.nFocal += 1;
+        }
+      }
+    }
+  }
+}
+
+// ---- LDS layout ------------------------------------------------------------------------------------------------
+constexpr uint32_t kEcLocal = 64;
+__host__ __device__ inline uint32_t ldsBytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords) {
+  // nodes 16 B, three biased heaps 8 B (+16 B bias pad each), bitmap rows, obstacle row, edge constraints
+  return capNodes * 16 + 3 * (capNodes * 8 + 16) + rows * rowWords * 4 + rowWords * 4 + kEcLocal * 4;
+}
+
+template <bool EPS>
+DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t* arenaSlot, DevResult& res,
+                 uint16_t* outPath) {
+  const uint32_t lane = threadIdx.x;
+  Ctx c;
+  c.dimx = J.dimx; c.dimy = J.dimy; c.wpr = J.words_per_row;
+  c.gx = J.gx; c.gy = J.gy; c.sx = J.sx; c.sy = J.sy;
+  c.lastGoal = J.last_goal_constraint;
+  c.w = J.w;
+  c.nVc = J.n_vc; c.nEc = J.n_ec;
+  c.vc = P.cons + J.vc_off;
+  c.ec = P.cons + J.ec_off;
+  c.obst = P.maps + J.map_word_off;
+  c.paths = P.paths + J.path_off;
+  c.nAgentsPad = J.n_agents_pad; c.tPad = J.t_pad;
+  c.maxExp = J.max_expansions;
+
+  SState s;
+  int rc;
+  res.tier = 0;
+
+  // HBM tier view of this workgroup's arena slot
+  Mem<1> g;
+  {
+    uint8_t* p = arenaSlot;
+    g.nodes = (Mem<1>::PNode)p;                  p += (size_t)P.arena_nodes * 16;
+    g.open = (Mem<1>::P64)(p + 8);               p += (size_t)P.arena_nodes * 8 + 16;
+    g.focal = (Mem<1>::P64)(p + 8);              p += (size_t)P.arena_nodes * 8 + 16;
+    g.aux = (Mem<1>::P64)(p + 8);                p += (size_t)P.arena_nodes * 8 + 16;
+    g.bits = (Mem<1>::P32)p;
+    g.capNodes = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
+  }
+
+  const bool ldsOk = P.lds_nodes != 0 && c.wpr <= P.lds_row_words;
+  if (ldsOk) {
+    Mem<3> m;
+    uint8_t* p = smem;
+    m.nodes = (Mem<3>::PNode)p;                  p += P.lds_nodes * 16;
+    m.open = (Mem<3>::P64)(p + 8);               p += P.lds_nodes * 8 + 16;
+    m.focal = (Mem<3>::P64)(p + 8);              p += P.lds_nodes * 8 + 16;
+    m.aux = (Mem<3>::P64)(p + 8);                p += P.lds_nodes * 8 + 16;
+    m.bits = (Mem<3>::P32)p;                     p += P.lds_rows * P.lds_row_words * 4;
+    Mem<3>::P32 obstLocal = (Mem<3>::P32)p;      p += P.lds_row_words * 4;
+    Mem<3>::P32 ecLocal = (Mem<3>::P32)p;
+    m.capNodes = P.lds_nodes; m.capRows = P.lds_rows; m.rowWords = P.lds_row_words;
+
+    __syncthreads();  // previous job's LDS reads are done
+    for (uint32_t wd = lane; wd < c.wpr; wd += 64) obstLocal[wd] = c.obst[wd];
+    if (lane < kEcLocal && lane < c.nEc) ecLocal[lane] = c.ec[lane];
+    __syncthreads();
+
+    initSearch<3, EPS>(m, s, c);
+    rc = runSearch<3, EPS>(m, s, c, obstLocal, ecLocal, true, res, outPath);
+    if (rc == RUN_MIGRATE_NODES || rc == RUN_MIGRATE_ROWS) {
+      // migrate the whole search state to the HBM arena and continue with the same code on global pointers
+      res.tier = 1;
+      __syncthreads();
+      for (uint32_t i = lane; i < s.nNodes; i += 64) g.nodes[i] = m.nodes[i];
+      for (uint32_t i = lane; i < s.nOpen; i += 64) g.open[i] = m.open[i];
+      for (uint32_t i = lane; i < s.nFocal; i += 64) g.focal[i] = m.focal[i];
+      for (uint32_t r = 0; r < s.rowsReady; ++r)
+        for (uint32_t wd = lane; wd < c.wpr; wd += 64) g.bits[r * g.rowWords + wd] = m.bits[r * m.rowWords + wd];
+      __syncthreads();
+      rc = runSearch<1, EPS>(g, s, c, (Mem<1>::P32)c.obst, (Mem<1>::P32)c.ec, false, res, outPath);
+    }
+  } else {
+    res.tier = 1;
+    initSearch<1, EPS>(g, s, c);
+    __syncthreads();
+    rc = runSearch<1, EPS>(g, s, c, (Mem<1>::P32)c.obst, (Mem<1>::P32)c.ec, false, res, outPath);
+  }
+  if (rc == RUN_MIGRATE_NODES) rc = ST_CAP_NODES;
+  if (rc == RUN_MIGRATE_ROWS) rc = ST_CAP_HORIZON;
+  res.status = rc;
+  res.expanded = s.expansions;
+  res.nodes_created = s.nNodes;
+}
+
+// One workgroup == one wavefront; persistent over the batch's job queue (exit: queue exhausted).
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchParams P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t lane = threadIdx.x;
+  uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
+  for (;;) {
+    uint32_t j = 0;
+    if (lane == 0) j = atomicAdd(P.queue_head, 1u);
+    j = rfl(j);
+    if (j >= P.n_jobs) break;
+    const DevJob& J = P.jobs[j];
+    DevResult res;
+    res.status = ST_BAD; res.cost = 0; res.fmin = 0; res.n_states = 0; res.expanded = 0; res.nodes_created = 0;
+    res.tier = 0;
+    uint16_t* outPath = P.out_paths + (size_t)j * P.out_stride;
+    const uint32_t algo = rfl(J.algo);
+    if (algo == 1)
+      runJob<true>(P, J, smem, arenaSlot, res, outPath);
+    else
+      runJob<false>(P, J, smem, arenaSlot, res, outPath);
+    if (lane == 0) P.results[j] = res;
+  }
+}
+
+}  // namespace mrp
+
+// ---- host-callable launcher (used by mrp_ll_host.cpp) -----------------------------------------------------------
+extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords) {
+  return mrp::ldsBytes(capNodes, rows, rowWords);
+}
+
+extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, hipStream_t stream) {
+  static bool attrSet = false;
+  if (!attrSet) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mrp::mrp_ll_search_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attrSet = true;
+  }
+  hipLaunchKernelGGL(mrp::mrp_ll_search_kernel, dim3(grid), dim3(64), ldsBytes, stream, *P);
+  return hipGetLastError();
+}

@@ -1,0 +1,202 @@
+"""ctypes binding of include/mrp_ll.h — the C-ABI of the HIP low-level search engine.
+
+This is plumbing for tests and benchmarks; it mirrors the reference's low-level call
+``LowLevelSearch_t(llenv[, w]).search(start, out)`` (cbs.hpp:99-101,155-157; ecbs.hpp:126-129,265-268) as
+``LowLevelEngine.search_batch([LLJob...]) -> [LLResult...]``.  There is no CPU fallback: if the HIP library is
+missing or no GPU is visible, construction raises.
+"""
+import ctypes
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG, "lib", "libmrp_ll.so")
+
+ASTAR, ASTAR_EPS = 0, 1
+OK, NO_SOLUTION, CAP_EXPANSIONS, CAP_NODES, CAP_HORIZON, BAD_JOB, PATH_TRUNCATED, CAP_FOCAL = range(8)
+ACTION_NAMES = ["Up", "Down", "Left", "Right", "Wait"]  # example/ecbs.cpp:49-55
+
+I32P = ctypes.POINTER(ctypes.c_int32)
+
+
+class mrp_ll_options(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("n_tickets", ctypes.c_int32), ("slots", ctypes.c_int32),
+                ("arena_nodes", ctypes.c_int32), ("max_horizon", ctypes.c_int32), ("max_cells", ctypes.c_int32),
+                ("lds_nodes", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class mrp_ll_job(ctypes.Structure):
+    _fields_ = [("map_id", ctypes.c_int32), ("algo", ctypes.c_int32), ("w", ctypes.c_float),
+                ("agent_idx", ctypes.c_int32), ("start_x", ctypes.c_int32), ("start_y", ctypes.c_int32),
+                ("goal_x", ctypes.c_int32), ("goal_y", ctypes.c_int32),
+                ("n_vertex_constraints", ctypes.c_int32), ("vertex_constraints", I32P),
+                ("n_edge_constraints", ctypes.c_int32), ("edge_constraints", I32P),
+                ("n_agents", ctypes.c_int32), ("path_len", I32P), ("path_xy", ctypes.POINTER(I32P)),
+                ("max_expansions", ctypes.c_int64)]
+
+
+class mrp_ll_result(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("cost", ctypes.c_int32), ("fmin", ctypes.c_int32),
+                ("n_states", ctypes.c_int32), ("expanded", ctypes.c_int64), ("states_txy", I32P),
+                ("actions", I32P), ("states_cap", ctypes.c_int32), ("tier", ctypes.c_int32)]
+
+
+class mrp_ll_stats(ctypes.Structure):
+    _fields_ = [("launches", ctypes.c_int64), ("jobs", ctypes.c_int64), ("expansions", ctypes.c_int64),
+                ("nodes_created", ctypes.c_int64), ("migrated", ctypes.c_int64), ("kernel_ms", ctypes.c_double),
+                ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double)]
+
+
+EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
+           "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version"]
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """Load libmrp_ll.so (raises OSError with a build hint if it is missing — no fallback)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise OSError(f"{p} not found: build it with `python -m libmultirobotplanning_amd._build` "
+                      "(hipcc --offload-arch=gfx950); the engine has no CPU fallback")
+    lib = ctypes.CDLL(p)
+    lib.mrp_ll_create.restype = ctypes.c_int
+    lib.mrp_ll_create.argtypes = [ctypes.POINTER(mrp_ll_options), ctypes.POINTER(ctypes.c_void_p)]
+    lib.mrp_ll_destroy.restype = None
+    lib.mrp_ll_destroy.argtypes = [ctypes.c_void_p]
+    lib.mrp_ll_last_error.restype = ctypes.c_char_p
+    lib.mrp_ll_last_error.argtypes = [ctypes.c_void_p]
+    lib.mrp_ll_upload_map.restype = ctypes.c_int
+    lib.mrp_ll_upload_map.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, I32P, I32P]
+    lib.mrp_ll_search_batch.restype = ctypes.c_int
+    lib.mrp_ll_search_batch.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(mrp_ll_job),
+                                        ctypes.POINTER(mrp_ll_result)]
+    lib.mrp_ll_submit.restype = ctypes.c_int
+    lib.mrp_ll_submit.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(mrp_ll_job),
+                                  ctypes.POINTER(mrp_ll_result), I32P]
+    lib.mrp_ll_wait.restype = ctypes.c_int
+    lib.mrp_ll_wait.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.mrp_ll_get_stats.restype = ctypes.c_int
+    lib.mrp_ll_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(mrp_ll_stats)]
+    lib.mrp_ll_reset_stats.restype = ctypes.c_int
+    lib.mrp_ll_reset_stats.argtypes = [ctypes.c_void_p]
+    lib.mrp_ll_version.restype = ctypes.c_char_p
+    lib.mrp_ll_version.argtypes = []
+    if path is None:
+        _lib = lib
+    return lib
+
+
+@dataclass
+class LLJob:
+    """One low-level search: LowLevelEnvironment(env, agent, constraints[, solution]) + search(start, out)."""
+    map_id: int
+    algo: int
+    start: Sequence[int]
+    goal: Sequence[int]
+    agent_idx: int = 0
+    w: float = 1.0
+    vertex_constraints: Sequence[Sequence[int]] = ()   # (time, x, y)
+    edge_constraints: Sequence[Sequence[int]] = ()     # (time, x1, y1, x2, y2)
+    ctx_paths: Sequence[Sequence[Sequence[int]]] = ()  # per agent [[x, y], ...]; [] = empty path
+    max_expansions: int = -1
+
+
+@dataclass
+class LLResult:
+    status: int
+    success: bool
+    cost: int
+    fmin: int
+    expanded: int
+    states: List[List[int]] = field(default_factory=list)   # [t, x, y]
+    actions: List[int] = field(default_factory=list)
+    tier: int = 0
+
+
+class LowLevelEngine:
+    def __init__(self, device: int = 0, n_tickets: int = 0, slots: int = 0, arena_nodes: int = 0,
+                 max_horizon: int = 0, max_cells: int = 0, lds_nodes: int = 0):
+        self._lib = load_library()
+        opt = mrp_ll_options(device, n_tickets, slots, arena_nodes, max_horizon, max_cells, lds_nodes, 0)
+        h = ctypes.c_void_p()
+        rc = self._lib.mrp_ll_create(ctypes.byref(opt), ctypes.byref(h))
+        if rc != 0 or not h:
+            raise RuntimeError(f"mrp_ll_create failed (rc={rc}): a HIP device is required, there is no CPU fallback")
+        self._h = h
+        self.max_horizon = max_horizon or 512
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mrp_ll_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed rc={rc}: {self._lib.mrp_ll_last_error(self._h).decode()}")
+
+    def upload_map(self, dimx, dimy, obstacles) -> int:
+        ob = np.ascontiguousarray(np.asarray(obstacles, dtype=np.int32).reshape(-1, 2))
+        mid = ctypes.c_int32(-1)
+        self._check(self._lib.mrp_ll_upload_map(self._h, dimx, dimy, len(ob), ob.ctypes.data_as(I32P),
+                                                ctypes.byref(mid)), "mrp_ll_upload_map")
+        return mid.value
+
+    def search_batch(self, jobs: Sequence[LLJob], states_cap: Optional[int] = None) -> List[LLResult]:
+        n = len(jobs)
+        cap = states_cap or self.max_horizon
+        cjobs = (mrp_ll_job * max(n, 1))()
+        cres = (mrp_ll_result * max(n, 1))()
+        keep = []
+        states = np.zeros((max(n, 1), cap, 3), dtype=np.int32)
+        actions = np.zeros((max(n, 1), cap), dtype=np.int32)
+        for i, j in enumerate(jobs):
+            cj = cjobs[i]
+            cj.map_id, cj.algo, cj.w, cj.agent_idx = j.map_id, j.algo, j.w, j.agent_idx
+            cj.start_x, cj.start_y, cj.goal_x, cj.goal_y = j.start[0], j.start[1], j.goal[0], j.goal[1]
+            vc = np.ascontiguousarray(np.asarray(j.vertex_constraints, dtype=np.int32).reshape(-1, 3))
+            ec = np.ascontiguousarray(np.asarray(j.edge_constraints, dtype=np.int32).reshape(-1, 5))
+            cj.n_vertex_constraints, cj.vertex_constraints = len(vc), vc.ctypes.data_as(I32P)
+            cj.n_edge_constraints, cj.edge_constraints = len(ec), ec.ctypes.data_as(I32P)
+            na = len(j.ctx_paths)
+            plen = np.asarray([len(p) for p in j.ctx_paths], dtype=np.int32)
+            parr = [np.ascontiguousarray(np.asarray(p, dtype=np.int32).reshape(-1, 2)) for p in j.ctx_paths]
+            pptr = (I32P * max(na, 1))(*[a.ctypes.data_as(I32P) for a in parr])
+            cj.n_agents = na
+            cj.path_len = plen.ctypes.data_as(I32P)
+            cj.path_xy = ctypes.cast(pptr, ctypes.POINTER(I32P))
+            cj.max_expansions = j.max_expansions
+            keep.append((vc, ec, plen, parr, pptr))
+            cres[i].states_txy = states[i].ctypes.data_as(I32P)
+            cres[i].actions = actions[i].ctypes.data_as(I32P)
+            cres[i].states_cap = cap
+        self._check(self._lib.mrp_ll_search_batch(self._h, n, cjobs, cres), "mrp_ll_search_batch")
+        out = []
+        for i in range(n):
+            r = cres[i]
+            ns = r.n_states if r.status in (OK, PATH_TRUNCATED) else 0
+            m = min(ns, cap)
+            out.append(LLResult(status=r.status, success=r.status in (OK, PATH_TRUNCATED), cost=r.cost, fmin=r.fmin,
+                                expanded=r.expanded, states=states[i, :m].tolist(),
+                                actions=actions[i, :max(m - 1, 0)].tolist(), tier=r.tier))
+        return out
+
+    def stats(self) -> dict:
+        st = mrp_ll_stats()
+        self._check(self._lib.mrp_ll_get_stats(self._h, ctypes.byref(st)), "mrp_ll_get_stats")
+        return {k: getattr(st, k) for k, _ in mrp_ll_stats._fields_}
+
+    def reset_stats(self):
+        self._check(self._lib.mrp_ll_reset_stats(self._h), "mrp_ll_reset_stats")

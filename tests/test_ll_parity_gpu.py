@@ -1,0 +1,148 @@
+"""GPU parity of the HIP low-level searches (through the C-ABI, include/mrp_ll.h) against the oracle.
+
+Every case runs the same low-level call — same map, agent, start/goal, constraint sets and (ECBS) CT-node paths — on
+the MI355X and in the oracle's restatement of a_star.hpp / a_star_epsilon.hpp, and demands bit-exact equality of
+success, cost, fmin, the onExpandNode count and the full path.  Calls are harvested from real CBS / ECBS runs of the
+oracle on shipped benchmark inputs (tests/golden/bench_instances.json), so constraint sets and focal contexts are the
+ones the conflict tree really produces.
+"""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from libmultirobotplanning_amd import ll
+    eng = ll.LowLevelEngine(device=0)
+    yield eng
+    eng.close()
+
+
+def _harvest(oracle_mod, bench_instances, names, algo, w, cap_total):
+    cases = []
+    for name in names:
+        inst = bench_instances[name]
+        summary, calls = oracle_mod.mapf_record(algo, inst, w=w, cap_total=cap_total)
+        for c in calls:
+            cases.append((name, inst, c))
+    return cases
+
+
+def _run_and_compare(engine, cases, algo_ll, w):
+    from libmultirobotplanning_amd import ll
+    map_ids = {}
+    jobs = []
+    for name, inst, c in cases:
+        if name not in map_ids:
+            map_ids[name] = engine.upload_map(inst["dimx"], inst["dimy"], inst["obstacles"])
+        a = c["agent"]
+        jobs.append(ll.LLJob(map_id=map_ids[name], algo=algo_ll, start=inst["starts"][a], goal=inst["goals"][a],
+                             agent_idx=a, w=w, vertex_constraints=c["vertex_constraints"],
+                             edge_constraints=c["edge_constraints"], ctx_paths=c["ctx_paths"]))
+    res = engine.search_batch(jobs)
+    assert len(res) == len(cases)
+    for (name, inst, c), r in zip(cases, res):
+        ctx = (name, c["agent"], len(c["vertex_constraints"]), len(c["edge_constraints"]))
+        assert r.success == c["success"], ctx
+        assert r.expanded == c["expanded"], ctx
+        if c["success"]:
+            assert r.status == ll.OK
+            assert (r.cost, r.fmin) == (c["cost"], c["fmin"]), ctx
+            assert [s[1:] for s in r.states] == c["states"], ctx
+            assert [s[0] for s in r.states] == list(range(len(c["states"]))), ctx
+        else:
+            assert r.status == ll.NO_SOLUTION, ctx
+    return res
+
+
+def test_ecbs_low_level_calls_32x32(engine, oracle_mod, bench_instances):
+    names = ["map_32by32_obst204_agents10_ex%d" % k for k in range(12)]
+    names += ["map_32by32_obst204_agents20_ex0", "map_32by32_obst204_agents30_ex1", "map_32by32_obst204_agents50_ex0"]
+    cases = _harvest(oracle_mod, bench_instances, names, oracle_mod.ECBS, 1.3, 3_000_000)
+    assert len(cases) > 200
+    from libmultirobotplanning_amd import ll
+    _run_and_compare(engine, cases, ll.ASTAR_EPS, 1.3)
+
+
+def test_ecbs_low_level_calls_100_agents(engine, oracle_mod, bench_instances):
+    cases = _harvest(oracle_mod, bench_instances, ["map_32by32_obst204_agents100_ex0"], oracle_mod.ECBS, 1.3, 3_000_000)
+    from libmultirobotplanning_amd import ll
+    res = _run_and_compare(engine, cases, ll.ASTAR_EPS, 1.3)
+    assert any(r.tier == 1 for r in res) or max(r.expanded for r in res) < 300  # big searches leave the LDS tier
+
+
+def test_ecbs_w1_low_level_calls(engine, oracle_mod, bench_instances, ref_tests):
+    from libmultirobotplanning_amd import ll
+    cases = _harvest(oracle_mod, bench_instances, ["map_8by8_obst12_agents4_ex%d" % k for k in range(5)],
+                     oracle_mod.ECBS, 1.0, 300_000)
+    cases += _harvest(oracle_mod, ref_tests["mapf"], ["mapf_simple1", "mapf_circle", "mapf_atGoal", "mapf_swap4"],
+                      oracle_mod.ECBS, 1.0, 300_000)
+    _run_and_compare(engine, cases, ll.ASTAR_EPS, 1.0)
+
+
+def test_cbs_low_level_calls_8x8(engine, oracle_mod, bench_instances, ref_tests):
+    from libmultirobotplanning_amd import ll
+    names = ["map_8by8_obst12_agents%d_ex%d" % (n, k) for n in (2, 4, 5, 6) for k in range(4)]
+    cases = _harvest(oracle_mod, bench_instances, names, oracle_mod.CBS, 1.0, 300_000)
+    cases += _harvest(oracle_mod, ref_tests["mapf"], ["mapf_simple1", "mapf_circle", "mapf_atGoal", "mapf_swap2"],
+                      oracle_mod.CBS, 1.0, 300_000)
+    assert len(cases) > 100
+    _run_and_compare(engine, cases, ll.ASTAR, 1.0)
+
+
+def test_tiers_agree(oracle_mod, bench_instances):
+    """Same jobs through (a) a tiny LDS tier that forces migration, (b) the HBM tier only: identical results."""
+    from libmultirobotplanning_amd import ll
+    cases = _harvest(oracle_mod, bench_instances, ["map_32by32_obst204_agents10_ex%d" % k for k in range(4)],
+                     oracle_mod.ECBS, 1.3, 3_000_000)
+    for lds_nodes in (32, -1):
+        eng = ll.LowLevelEngine(device=0, lds_nodes=lds_nodes, n_tickets=1, slots=256)
+        try:
+            res = _run_and_compare(eng, cases, ll.ASTAR_EPS, 1.3)
+            assert any(r.tier == 1 for r in res)
+        finally:
+            eng.close()
+
+
+def test_edge_cases(engine, oracle_mod):
+    from libmultirobotplanning_amd import ll
+    open_map = dict(dimx=4, dimy=3, obstacles=[])
+    boxed = dict(dimx=3, dimy=3, obstacles=[[0, 1], [1, 0], [1, 2], [2, 1]])  # centre cell walled in
+    mid_open = engine.upload_map(4, 3, [])
+    mid_boxed = engine.upload_map(3, 3, boxed["obstacles"])
+    specs = [
+        # (map, map_id, algo, start, goal, vc, ec, ctx, w, cap)
+        (open_map, mid_open, ll.ASTAR, [0, 0], [0, 0], [], [], [], 1.0, -1),                 # start == goal
+        (open_map, mid_open, ll.ASTAR_EPS, [0, 0], [0, 0], [[3, 0, 0]], [], [], 1.3, -1),    # goal constrained later
+        (open_map, mid_open, ll.ASTAR, [0, 0], [3, 2], [[1, 1, 0], [1, 0, 1]], [], [], 1.0, -1),  # both moves blocked at t=1
+        (open_map, mid_open, ll.ASTAR_EPS, [0, 0], [3, 0], [], [[0, 0, 0, 1, 0], [1, 0, 0, 1, 0]], [], 1.3, -1),
+        (boxed, mid_boxed, ll.ASTAR, [1, 1], [0, 0], [[1, 1, 1]], [], [], 1.0, -1),          # open list exhausted
+        (boxed, mid_boxed, ll.ASTAR_EPS, [1, 1], [0, 0], [[1, 1, 1]], [], [], 1.3, -1),
+        (boxed, mid_boxed, ll.ASTAR, [1, 1], [0, 0], [], [], [], 1.0, 50),                    # unreachable: cap hit
+        (open_map, mid_open, ll.ASTAR_EPS, [0, 0], [3, 2], [], [], [[], [[1, 0], [0, 0], [0, 1]], [[3, 2]]], 1.3, -1),
+    ]
+    jobs = [ll.LLJob(map_id=mid, algo=algo, start=s, goal=g, agent_idx=0, w=w, vertex_constraints=vc,
+                     edge_constraints=ec, ctx_paths=ctx, max_expansions=cap)
+            for (_, mid, algo, s, g, vc, ec, ctx, w, cap) in specs]
+    res = engine.search_batch(jobs)
+    for (mp, mid, algo, s, g, vc, ec, ctx, w, cap), r in zip(specs, res):
+        o = oracle_mod.ll_search(algo, mp, 0, s, g, vc, ec, ctx, w=w, cap_expansions=cap)
+        if o["rc"] == -1:
+            assert r.status == ll.CAP_EXPANSIONS
+            continue
+        assert r.success == o["success"], (s, g, vc)
+        assert r.expanded == o["expanded"]
+        if o["success"]:
+            assert (r.cost, r.fmin, r.states, r.actions) == (o["cost"], o["fmin"], o["states"], o["actions"])
+        else:
+            assert r.status == ll.NO_SOLUTION
+    assert engine.search_batch([]) == []
+    # rejected on the host, loudly
+    bad = engine.search_batch([ll.LLJob(map_id=999, algo=ll.ASTAR, start=[0, 0], goal=[1, 1])])
+    assert bad[0].status == ll.BAD_JOB
+
+
+def test_stats_report_kernel_time(engine):
+    st = engine.stats()
+    assert st["launches"] > 0 and st["kernel_ms"] > 0 and st["expansions"] > 0
