@@ -34,6 +34,19 @@ def _stale(out, paths):
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in paths)
 
 
+def build_trace(verbose=False):
+    """Diagnostic variant of libmrp_ll.so (-DMRP_LL_TRACE): the kernel writes progress words to a host-mapped buffer
+    that mrp_ll_wait dumps if a launch does not finish within 10 s (run with MRP_LL_DEBUG=1 MRP_LL_LIB=<this file>)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    spec = TARGETS["libmrp_ll.so"]
+    out = os.path.join(LIBDIR, "libmrp_ll_trace.so")
+    cmd = [HIPCC] + COMMON + ["-DMRP_LL_TRACE", "-o", out] + [os.path.join(CSRC, s) for s in spec["srcs"]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return out
+
+
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     built = []
@@ -56,3 +69,5 @@ if __name__ == "__main__":
     import sys
     for p in build(force="--force" in sys.argv, verbose=True):
         print("built", p)
+    if "--trace" in sys.argv:
+        print("built", build_trace(verbose=True))

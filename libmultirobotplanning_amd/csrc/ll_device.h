@@ -68,6 +68,7 @@ struct LaunchParams {
   uint32_t lds_nodes;         // node capacity of the LDS tier (0 = LDS tier disabled)
   uint32_t lds_rows;          // bitmap rows held in LDS
   uint32_t lds_row_words;     // words per row the LDS layout was sized for
+  volatile uint32_t* debug;   // host-mapped trace words (MRP_LL_DEBUG only; nullptr otherwise)
 };
 
 }  // namespace mrp

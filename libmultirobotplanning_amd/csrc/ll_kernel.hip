@@ -29,6 +29,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
 #define DEVI __device__ __forceinline__
+#ifdef MRP_LL_TRACE  // diagnostic build only (-DMRP_LL_TRACE): progress words in a host-mapped buffer
+#define DBG(P, slot, val)                                                                      \
+  do {                                                                                         \
+    if ((P).debug && blockIdx.x < 4096) { /* all lanes store the same word */                  \
+      (P).debug[blockIdx.x * 16 + (slot)] = (uint32_t)(val);                                   \
+      __threadfence_system();                                                                  \
+    }                                                                                          \
+  } while (0)
+#else
+#define DBG(P, slot, val) do { } while (0)
+#endif
 
 DEVI uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 DEVI int32_t rfli(int32_t v) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)v); }
@@ -76,6 +87,7 @@ struct Ctx {  // wave-uniform job context
   const uint16_t* paths;
   uint32_t nAgentsPad, tPad;
   int64_t maxExp;
+  volatile uint32_t* debug;
 };
 
 struct SState {  // wave-uniform search state (kept in SGPRs by construction)
@@ -292,7 +304,9 @@ template <int AS, bool EPS>
 DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 obstLocal,
                    typename Mem<AS>::P32 ecLocal, bool useLocal, DevResult& res, uint16_t* outPath) {
   const uint32_t lane = threadIdx.x;
+  uint32_t dbgIter = 0;
   for (;;) {
+    DBG(c, 5, ++dbgIter);
     if (s.nOpen == 0) return ST_NO_SOLUTION;
     uint64_t topE = ld64<AS>(m.open, 0);
     uint64_t curE = topE;
@@ -309,6 +323,8 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
     const uint32_t curFh = rfl(nd.z);
     const uint32_t curPos = rfl(nd.w);
     const bool isGoal = (x == c.gx) && (y == c.gy) && ((int32_t)t > c.lastGoal);
+    DBG(c, 6, xyt);
+    DBG(c, 7, isGoal ? 1 : 2);
     if (!isGoal) {
       if (s.nNodes + 5 > m.capNodes) return RUN_MIGRATE_NODES;
       if (t + 1 >= m.capRows) return RUN_MIGRATE_ROWS;
@@ -342,9 +358,10 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
       uint32_t nid = curId;
       for (int32_t k = (int32_t)t; k >= 0; --k) {  // follow cameFrom (a_star_epsilon.hpp:198-208)
         u32x4 pn = m.nodes[nid];
-        if (lane == 0) outPath[k] = (uint16_t)(pn.x & 0xFFFF);
+        outPath[k] = (uint16_t)(rfl(pn.x) & 0xFFFF);  // all lanes, same address, same value
         nid = rfl(pn.y);
       }
+      DBG(c, 8, 77);
       return ST_OK;
     }
 
@@ -451,6 +468,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   c.paths = P.paths + J.path_off;
   c.nAgentsPad = J.n_agents_pad; c.tPad = J.t_pad;
   c.maxExp = J.max_expansions;
+  c.debug = P.debug;
 
   SState s;
   int rc;
@@ -518,10 +536,13 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchPara
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t lane = threadIdx.x;
   uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
+  DBG(P, 0, 1);
   for (;;) {
-    uint32_t j = 0;
-    if (lane == 0) j = atomicAdd(P.queue_head, 1u);
+    // every lane takes part (lane 0 adds 1, the others 0): the kernel deliberately contains no `if (lane == 0)`
+    // blocks — hipcc once merged two of them into a wave-divergent wrapper loop that only lane 0 could leave.
+    uint32_t j = atomicAdd(P.queue_head, lane == 0 ? 1u : 0u);
     j = rfl(j);
+    DBG(P, 1, j + 1);
     if (j >= P.n_jobs) break;
     const DevJob& J = P.jobs[j];
     DevResult res;
@@ -533,8 +554,11 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchPara
       runJob<true>(P, J, smem, arenaSlot, res, outPath);
     else
       runJob<false>(P, J, smem, arenaSlot, res, outPath);
-    if (lane == 0) P.results[j] = res;
+    DBG(P, 2, res.status + 100);
+    P.results[j] = res;  // all lanes write the same 32 bytes
+    DBG(P, 3, j + 1);
   }
+  DBG(P, 4, 1);
 }
 
 }  // namespace mrp

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -92,12 +93,15 @@ struct mrp_ll_ctx {
   uint64_t arenaStride = 0;
   std::vector<Ticket> tickets;
   mrp_ll_stats stats;
+  uint32_t* debugHost = nullptr;  // MRP_LL_DEBUG: host-mapped trace buffer
 };
 
 namespace {
 
+static const bool kDebug = std::getenv("MRP_LL_DEBUG") != nullptr;
 #define HIPCHK(ctx, call)                                                                         \
   do {                                                                                            \
+    if (kDebug) { std::fprintf(stderr, "[mrp_ll] %s\n", #call); std::fflush(stderr); }            \
     hipError_t e__ = (call);                                                                      \
     if (e__ != hipSuccess) {                                                                      \
       (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                            \
@@ -444,6 +448,15 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
   P.lds_nodes = ldsNodes;
   P.lds_rows = rows;
   P.lds_row_words = rowWords;
+  if (kDebug) {
+    if (!ctx->debugHost) {
+      HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->debugHost), 16 * 4 * 4096, hipHostMallocMapped | hipHostMallocCoherent));
+    }
+    std::memset(ctx->debugHost, 0, 16 * 4 * 4096);
+    void* dptr = nullptr;
+    HIPCHK(ctx, hipHostGetDevicePointer(&dptr, ctx->debugHost, 0));
+    P.debug = static_cast<volatile uint32_t*>(dptr);
+  }
   uint32_t grid = std::min<uint32_t>(static_cast<uint32_t>(nJobs), static_cast<uint32_t>(ctx->opt.slots));
   HIPCHK(ctx, hipEventRecord(t.evK0, t.stream));
   HIPCHK(ctx, mrp_ll_launch(&P, grid, ldsBytes, t.stream));
@@ -461,6 +474,22 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
   Ticket& t = ctx->tickets[ticket];
   if (!t.inFlight) return MRP_LL_E_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (kDebug && ctx->debugHost) {
+    for (int spin = 0; spin < 100 && hipEventQuery(t.evDone) == hipErrorNotReady; ++spin) {
+      struct timespec ts = {0, 100000000};
+      nanosleep(&ts, nullptr);
+    }
+    if (hipEventQuery(t.evDone) == hipErrorNotReady) {
+      std::fprintf(stderr, "[mrp_ll] kernel did not finish within 10 s; trace of the first workgroups:\n");
+      for (int b = 0; b < 4; ++b) {
+        std::fprintf(stderr, "  wg %d:", b);
+        for (int k = 0; k < 16; ++k) std::fprintf(stderr, " %u", ctx->debugHost[b * 16 + k]);
+        std::fprintf(stderr, "\n");
+      }
+      std::fflush(stderr);
+      std::_Exit(3);
+    }
+  }
   HIPCHK(ctx, hipEventSynchronize(t.evDone));
   t.inFlight = false;
   if (t.nJobs == 0) return MRP_LL_SUCCESS;

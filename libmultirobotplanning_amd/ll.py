@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_PKG, "lib", "libmrp_ll.so")
+_LIB_PATH = os.environ.get("MRP_LL_LIB") or os.path.join(_PKG, "lib", "libmrp_ll.so")
 
 ASTAR, ASTAR_EPS = 0, 1
 OK, NO_SOLUTION, CAP_EXPANSIONS, CAP_NODES, CAP_HORIZON, BAD_JOB, PATH_TRUNCATED, CAP_FOCAL = range(8)
