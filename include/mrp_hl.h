@@ -1,0 +1,98 @@
+/*
+ * mrp_hl.h — host-side conflict-tree drivers (libmrp_hl.so) that CALL the low-level C-ABI of mrp_ll.h.
+ *
+ * These are the callers of the hot path, restated so that many MAPF instances advance in lock-step and every round
+ * hands ALL ready low-level searches to the GPU in one mrp_ll_submit:
+ *   CBS::search   include/libMultiRobotPlanning/cbs.hpp:85-172   (root: N independent searches; then 2 per CT node)
+ *   ECBS::search  include/libMultiRobotPlanning/ecbs.hpp:109-288 (root: chain of N searches, each seeing the paths
+ *                 planned so far; then 2 per CT node; HL open by cost, HL focal by (focalHeuristic, cost))
+ * with the HL-side Environment methods of example/ecbs.cpp: getFirstConflict :401-452, createConstraintsFromConflict
+ * :454-472, focalHeuristic :315-350.  The high-level heaps replay boost::heap::d_ary_heap exactly (tie order decides
+ * which CT node is expanded), so cost / makespan / highLevelExpanded / lowLevelExpanded equal the reference's
+ * `statistics:` block (example/ecbs.cpp:594-599) — checked against the oracle in tests/.
+ *
+ * Also here: the seeded synthetic-instance generator used by bench.py and the YAML subset
+ * reader / schedule writer of example/ecbs.cpp:554-574,584-617.
+ */
+#ifndef MRP_HL_H
+#define MRP_HL_H
+
+#include <stdint.h>
+
+#include "mrp_ll.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRP_HL_CBS 0
+#define MRP_HL_ECBS 1
+
+/* mrp_hl_solution.status */
+#define MRP_HL_SOLVED 0       /* search() returned true                                                        */
+#define MRP_HL_NO_SOLUTION 1  /* search() returned false (a root search failed or the CT open list ran empty)   */
+#define MRP_HL_CAP 2          /* a harness cap was hit (the reference has none and would keep running)          */
+#define MRP_HL_LL_ERROR 3     /* a low-level job came back with a capacity status (MRP_LL_CAP_NODES/HORIZON/..) */
+
+typedef struct mrp_hl_instance {
+  int32_t dimx, dimy;
+  int32_t n_obstacles;
+  const int32_t* obstacles_xy; /* [n][2]  (map.obstacles, ecbs.cpp:564-566) */
+  int32_t n_agents;
+  const int32_t* starts_xy;    /* [n][2]  (agents[].start, ecbs.cpp:571)     */
+  const int32_t* goals_xy;     /* [n][2]  (agents[].goal,  ecbs.cpp:573)     */
+} mrp_hl_instance;
+
+typedef struct mrp_hl_solution {
+  int32_t status;
+  int32_t n_ll_searches;          /* low-level searches issued for this instance                                */
+  int64_t cost;                   /* statistics.cost      (sum of PlanResult::cost, ecbs.cpp:586-591)            */
+  int64_t makespan;               /* statistics.makespan                                                        */
+  int64_t high_level_expanded;    /* statistics.highLevelExpanded                                               */
+  int64_t low_level_expanded;     /* statistics.lowLevelExpanded  (the metric's numerator)                      */
+  int32_t* path_len;              /* caller buffer [n_agents] or NULL                                           */
+  int32_t* paths_xy;              /* caller buffer [n_agents][path_cap][2] or NULL                              */
+  int32_t path_cap;
+  int32_t reserved;
+} mrp_hl_solution;
+
+typedef struct mrp_hl_options {
+  int32_t algo;                   /* MRP_HL_CBS | MRP_HL_ECBS                                                    */
+  float w;                        /* ECBS suboptimality bound (binary32, ecbs.cpp:530,536)                        */
+  int64_t max_ll_expansions;      /* per instance, summed over its searches; < 0 unlimited                        */
+  int64_t max_hl_expansions;      /* per instance; < 0 unlimited                                                  */
+  int32_t n_threads;              /* host worker threads == instance groups in flight (0 = default)               */
+  int32_t reserved;
+} mrp_hl_options;
+
+typedef struct mrp_hl_batch_stats {
+  double wall_seconds;            /* timed region: all conflict-tree searches of the batch, first submit to last result */
+  int64_t rounds;                 /* mrp_ll_submit calls                                                          */
+  int64_t ll_searches;
+  int64_t ll_expansions;          /* over every search that was run (== sum of solutions' low_level_expanded)     */
+  int64_t solved;
+} mrp_hl_batch_stats;
+
+/* One engine context per calling thread is created internally for every worker thread on `device`. */
+int mrp_hl_solve_batch(int32_t device, const mrp_hl_options* opt, int32_t n_instances, const mrp_hl_instance* instances,
+                       mrp_hl_solution* solutions, mrp_hl_batch_stats* stats);
+
+/* Persistent form for benchmarking: engines (and their arenas) are created once and reused across batches. */
+typedef struct mrp_hl_solver mrp_hl_solver;
+int mrp_hl_solver_create(int32_t device, int32_t n_threads, const mrp_ll_options* ll_opt, mrp_hl_solver** out);
+void mrp_hl_solver_destroy(mrp_hl_solver* s);
+int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* opt, int32_t n_instances,
+                        const mrp_hl_instance* instances, mrp_hl_solution* solutions, mrp_hl_batch_stats* stats);
+int mrp_hl_solver_ll_stats(mrp_hl_solver* s, mrp_ll_stats* out, int32_t reset); /* summed over its engines */
+const char* mrp_hl_solver_last_error(const mrp_hl_solver* s);
+
+/* Seeded synthetic "32x32_obst204-shaped" instance: obstacles uniform without replacement, agents with
+ * distinct starts and distinct goals, every goal in the start's 4-connected free component. splitmix64(seed).
+ * Buffers: obstacles_xy [n_obstacles][2], starts_xy / goals_xy [n_agents][2]. Returns 0, or -1 if impossible. */
+int mrp_hl_generate_instance(uint64_t seed, int32_t dimx, int32_t dimy, int32_t n_obstacles, int32_t n_agents,
+                             int32_t* obstacles_xy, int32_t* starts_xy, int32_t* goals_xy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRP_HL_H */

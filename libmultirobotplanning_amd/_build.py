@@ -23,7 +23,7 @@ TARGETS = {
     "libmrp_hl.so": dict(srcs=["hl/mrp_hl.cpp"], deps=["hl/exact_heap.hpp", "hl/grid_mapf.hpp", "hl/ct_solver.hpp",
                                                        "hl/instance_io.hpp", "../../include/mrp_ll.h",
                                                        "../../include/mrp_hl.h"],
-                         extra=["-pthread"]),
+                         extra=["-pthread", "-L", LIBDIR, "-lmrp_ll", "-Wl,-rpath,$ORIGIN"]),
 }
 
 

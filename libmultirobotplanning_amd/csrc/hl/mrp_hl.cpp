@@ -1,0 +1,285 @@
+// C-ABI of the host-side conflict-tree drivers (include/mrp_hl.h).  Worker threads each own one low-level engine
+// context (mrp_ll_ctx is not thread-safe) and a share of the instances; every round a thread gathers the ready
+// low-level searches of all its instances into one mrp_ll_search_batch call.
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/mrp_hl.h"
+#include "ct_solver.hpp"
+#include "instance_io.hpp"
+
+using namespace mrp_hl;
+
+struct mrp_hl_solver {
+  int32_t device = 0;
+  std::vector<mrp_ll_ctx*> engines;
+  mrp_ll_options llOpt;
+  std::string err;
+};
+
+namespace {
+
+struct GroupResult {
+  int64_t rounds = 0, searches = 0, expansions = 0;
+  std::string err;
+};
+
+// Drives instances idx[...] to completion on one engine.
+void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance* instIn, mrp_hl_solution* sols,
+              const std::vector<int32_t>& idx, const std::vector<int32_t>& mapIds, int32_t horizon, GroupResult& out) {
+  const size_t n = idx.size();
+  std::vector<std::unique_ptr<Instance>> inst(n);
+  for (size_t k = 0; k < n; ++k) inst[k].reset(new Instance(instIn[idx[k]], mapIds[k], opt));
+  std::vector<std::vector<LLRequest>> req(n);
+  std::vector<std::vector<LLAnswer>> ans(n);
+  for (size_t k = 0; k < n; ++k) inst[k]->advance(ans[k], req[k]);
+
+  std::vector<mrp_ll_job> jobs;
+  std::vector<mrp_ll_result> results;
+  std::vector<int32_t> owner;           // job -> local instance
+  std::vector<int32_t> pathLenPool;     // per job: n_agents ints
+  std::vector<const int32_t*> pathPtrPool;
+  std::vector<size_t> poolOff;
+  std::vector<int32_t> statesPool;
+  const int32_t cap = horizon;
+
+  for (;;) {
+    jobs.clear();
+    owner.clear();
+    pathLenPool.clear();
+    pathPtrPool.clear();
+    poolOff.clear();
+    for (size_t k = 0; k < n; ++k) {
+      for (const LLRequest& r : req[k]) {
+        const Instance& I = *inst[k];
+        mrp_ll_job j;
+        std::memset(&j, 0, sizeof(j));
+        j.map_id = I.mapId();
+        j.algo = I.algo() == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR;
+        j.w = I.w();
+        j.agent_idx = r.agent;
+        j.start_x = I.start(r.agent)[0];
+        j.start_y = I.start(r.agent)[1];
+        j.goal_x = I.goal(r.agent)[0];
+        j.goal_y = I.goal(r.agent)[1];
+        j.n_vertex_constraints = static_cast<int32_t>(r.constraints->vertex.size() / 3);
+        j.vertex_constraints = r.constraints->vertex.data();
+        j.n_edge_constraints = static_cast<int32_t>(r.constraints->edge.size() / 5);
+        j.edge_constraints = r.constraints->edge.data();
+        j.max_expansions = I.remainingLL();
+        poolOff.push_back(pathLenPool.size());
+        if (r.context) {
+          j.n_agents = static_cast<int32_t>(r.context->size());
+          for (const PathPtr& p : *r.context) {
+            pathLenPool.push_back(p->len());
+            pathPtrPool.push_back(p->xy.data());
+          }
+        }
+        jobs.push_back(j);
+        owner.push_back(static_cast<int32_t>(k));
+      }
+    }
+    if (jobs.empty()) break;
+    // pools may have reallocated while growing: patch the pointers now
+    for (size_t q = 0; q < jobs.size(); ++q)
+      if (jobs[q].n_agents > 0) {
+        jobs[q].path_len = pathLenPool.data() + poolOff[q];
+        jobs[q].path_xy = pathPtrPool.data() + poolOff[q];
+      }
+    results.assign(jobs.size(), mrp_ll_result());
+    statesPool.resize(jobs.size() * static_cast<size_t>(cap) * 3);
+    for (size_t q = 0; q < jobs.size(); ++q) {
+      std::memset(&results[q], 0, sizeof(mrp_ll_result));
+      results[q].states_txy = statesPool.data() + q * static_cast<size_t>(cap) * 3;
+      results[q].actions = nullptr;
+      results[q].states_cap = cap;
+    }
+    int rc = mrp_ll_search_batch(ctx, static_cast<int32_t>(jobs.size()), jobs.data(), results.data());
+    if (rc != MRP_LL_SUCCESS) {
+      out.err = std::string("mrp_ll_search_batch: ") + mrp_ll_last_error(ctx);
+      return;
+    }
+    out.rounds += 1;
+    out.searches += static_cast<int64_t>(jobs.size());
+    for (size_t k = 0; k < n; ++k) ans[k].clear();
+    for (size_t q = 0; q < jobs.size(); ++q) {
+      const mrp_ll_result& r = results[q];
+      LLAnswer a;
+      a.status = r.status;
+      a.cost = r.cost;
+      a.fmin = r.fmin;
+      a.expanded = r.expanded;
+      out.expansions += r.expanded;
+      if (r.status == MRP_LL_OK) {
+        auto p = std::make_shared<Path>();
+        p->xy.resize(static_cast<size_t>(r.n_states) * 2);
+        for (int32_t s = 0; s < r.n_states; ++s) {
+          p->xy[2 * s] = r.states_txy[3 * s + 1];
+          p->xy[2 * s + 1] = r.states_txy[3 * s + 2];
+        }
+        p->cost = r.cost;
+        p->fmin = r.fmin;
+        a.path = p;
+      }
+      ans[owner[q]].push_back(a);
+    }
+    for (size_t k = 0; k < n; ++k) {
+      if (req[k].empty()) continue;
+      inst[k]->advance(ans[k], req[k]);
+    }
+  }
+  for (size_t k = 0; k < n; ++k) {
+    const Instance& I = *inst[k];
+    mrp_hl_solution& s = sols[idx[k]];
+    s.status = I.status();
+    s.n_ll_searches = I.llSearches();
+    s.high_level_expanded = I.hlExpanded();
+    s.low_level_expanded = I.llExpanded();
+    s.cost = 0;
+    s.makespan = 0;
+    if (I.status() == MRP_HL_SOLVED) {
+      const auto& sol = I.finalSolution();
+      for (int32_t a = 0; a < I.nAgents(); ++a) {
+        s.cost += sol[a]->cost;
+        s.makespan = std::max<int64_t>(s.makespan, sol[a]->cost);
+        if (s.path_len) s.path_len[a] = sol[a]->len();
+        if (s.paths_xy) {
+          int32_t m = std::min(sol[a]->len(), s.path_cap);
+          std::memcpy(s.paths_xy + static_cast<size_t>(a) * s.path_cap * 2, sol[a]->xy.data(), sizeof(int32_t) * 2 * m);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrp_hl_solver_create(int32_t device, int32_t nThreads, const mrp_ll_options* llOpt, mrp_hl_solver** out) {
+  if (!out) return MRP_LL_E_INVALID;
+  *out = nullptr;
+  if (nThreads <= 0) {
+    unsigned hc = std::thread::hardware_concurrency();
+    nThreads = static_cast<int32_t>(hc ? std::min<unsigned>(hc, 16) : 8);
+  }
+  auto* s = new mrp_hl_solver();
+  s->device = device;
+  std::memset(&s->llOpt, 0, sizeof(s->llOpt));
+  if (llOpt) s->llOpt = *llOpt;
+  s->llOpt.device = device;
+  if (s->llOpt.n_tickets <= 0) s->llOpt.n_tickets = 1;
+  if (s->llOpt.slots <= 0) s->llOpt.slots = 512;
+  if (s->llOpt.arena_nodes <= 0) s->llOpt.arena_nodes = 65536;
+  for (int32_t t = 0; t < nThreads; ++t) {
+    mrp_ll_ctx* ctx = nullptr;
+    int rc = mrp_ll_create(&s->llOpt, &ctx);
+    if (rc != MRP_LL_SUCCESS) {  // no GPU, no solver: there is no CPU path
+      for (auto* e : s->engines) mrp_ll_destroy(e);
+      delete s;
+      return rc;
+    }
+    s->engines.push_back(ctx);
+  }
+  *out = s;
+  return MRP_LL_SUCCESS;
+}
+
+void mrp_hl_solver_destroy(mrp_hl_solver* s) {
+  if (!s) return;
+  for (auto* e : s->engines) mrp_ll_destroy(e);
+  delete s;
+}
+
+const char* mrp_hl_solver_last_error(const mrp_hl_solver* s) { return s ? s->err.c_str() : "null solver"; }
+
+int mrp_hl_solver_ll_stats(mrp_hl_solver* s, mrp_ll_stats* out, int32_t reset) {
+  if (!s || !out) return MRP_LL_E_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  for (auto* e : s->engines) {
+    mrp_ll_stats st;
+    mrp_ll_get_stats(e, &st);
+    out->launches += st.launches;
+    out->jobs += st.jobs;
+    out->expansions += st.expansions;
+    out->nodes_created += st.nodes_created;
+    out->migrated += st.migrated;
+    out->kernel_ms += st.kernel_ms;
+    out->h2d_ms += st.h2d_ms;
+    out->d2h_ms += st.d2h_ms;
+    if (reset) mrp_ll_reset_stats(e);
+  }
+  return MRP_LL_SUCCESS;
+}
+
+int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* optIn, int32_t nInst, const mrp_hl_instance* instances,
+                        mrp_hl_solution* solutions, mrp_hl_batch_stats* stats) {
+  if (!s || !optIn || nInst < 0 || (nInst > 0 && (!instances || !solutions))) return MRP_LL_E_INVALID;
+  mrp_hl_options opt = *optIn;
+  int32_t nThreads = static_cast<int32_t>(s->engines.size());
+  if (opt.n_threads > 0) nThreads = std::min(nThreads, opt.n_threads);
+  nThreads = std::max(1, std::min(nThreads, std::max(nInst, 1)));
+  const int32_t horizon = s->llOpt.max_horizon > 0 ? s->llOpt.max_horizon : 512;
+  // instance k -> thread k % nThreads (interleaved, so easy and hard agent counts mix evenly)
+  std::vector<std::vector<int32_t>> idx(nThreads), mapIds(nThreads);
+  for (int32_t k = 0; k < nInst; ++k) idx[k % nThreads].push_back(k);
+  // Environment construction (ecbs.cpp:576) is outside the reference's timed region: upload the maps first
+  for (int32_t t = 0; t < nThreads; ++t)
+    for (int32_t k : idx[t]) {
+      const mrp_hl_instance& in = instances[k];
+      int32_t mid = -1;
+      int rc = mrp_ll_upload_map(s->engines[t], in.dimx, in.dimy, in.n_obstacles, in.obstacles_xy, &mid);
+      if (rc != MRP_LL_SUCCESS) {
+        s->err = std::string("mrp_ll_upload_map: ") + mrp_ll_last_error(s->engines[t]);
+        return rc;
+      }
+      mapIds[t].push_back(mid);
+    }
+  std::vector<GroupResult> gr(nThreads);
+  auto t0 = std::chrono::steady_clock::now();
+  {
+    std::vector<std::thread> th;
+    for (int32_t t = 0; t < nThreads; ++t)
+      th.emplace_back([&, t]() { runGroup(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, gr[t]); });
+    for (auto& x : th) x.join();
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  mrp_hl_batch_stats st;
+  std::memset(&st, 0, sizeof(st));
+  st.wall_seconds = std::chrono::duration<double>(t1 - t0).count();
+  for (auto& g : gr) {
+    if (!g.err.empty()) {
+      s->err = g.err;
+      return MRP_LL_E_DEVICE;
+    }
+    st.rounds += g.rounds;
+    st.ll_searches += g.searches;
+    st.ll_expansions += g.expansions;
+  }
+  for (int32_t k = 0; k < nInst; ++k) st.solved += solutions[k].status == MRP_HL_SOLVED ? 1 : 0;
+  if (stats) *stats = st;
+  return MRP_LL_SUCCESS;
+}
+
+int mrp_hl_solve_batch(int32_t device, const mrp_hl_options* opt, int32_t nInst, const mrp_hl_instance* instances,
+                       mrp_hl_solution* solutions, mrp_hl_batch_stats* stats) {
+  mrp_hl_solver* s = nullptr;
+  int rc = mrp_hl_solver_create(device, opt ? opt->n_threads : 0, nullptr, &s);
+  if (rc != MRP_LL_SUCCESS) return rc;
+  rc = mrp_hl_solver_solve(s, opt, nInst, instances, solutions, stats);
+  mrp_hl_solver_destroy(s);
+  return rc;
+}
+
+int mrp_hl_generate_instance(uint64_t seed, int32_t dimx, int32_t dimy, int32_t nObst, int32_t nAgents,
+                             int32_t* obstXY, int32_t* startsXY, int32_t* goalsXY) {
+  return generateInstance(seed, dimx, dimy, nObst, nAgents, obstXY, startsXY, goalsXY);
+}
+
+}  // extern "C"

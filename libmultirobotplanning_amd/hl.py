@@ -1,0 +1,165 @@
+"""ctypes binding of include/mrp_hl.h — the host-side CBS / ECBS conflict-tree drivers that call the HIP engine.
+
+Mirrors the reference's top-level calls ``CBS(env).search(starts, solution)`` (cbs.hpp:85) and
+``ECBS(env, w).search(starts, solution)`` (ecbs.hpp:109) for a whole batch of instances at once, and returns the
+``statistics:`` fields of example/ecbs.cpp:594-599 per instance.  No CPU fallback.
+"""
+import ctypes
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import ll as _ll
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG, "lib", "libmrp_hl.so")
+
+CBS, ECBS = 0, 1
+SOLVED, NO_SOLUTION, CAP, LL_ERROR = 0, 1, 2, 3
+I32P = ctypes.POINTER(ctypes.c_int32)
+
+
+class mrp_hl_instance(ctypes.Structure):
+    _fields_ = [("dimx", ctypes.c_int32), ("dimy", ctypes.c_int32), ("n_obstacles", ctypes.c_int32),
+                ("obstacles_xy", I32P), ("n_agents", ctypes.c_int32), ("starts_xy", I32P), ("goals_xy", I32P)]
+
+
+class mrp_hl_solution(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("n_ll_searches", ctypes.c_int32), ("cost", ctypes.c_int64),
+                ("makespan", ctypes.c_int64), ("high_level_expanded", ctypes.c_int64),
+                ("low_level_expanded", ctypes.c_int64), ("path_len", I32P), ("paths_xy", I32P),
+                ("path_cap", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class mrp_hl_options(ctypes.Structure):
+    _fields_ = [("algo", ctypes.c_int32), ("w", ctypes.c_float), ("max_ll_expansions", ctypes.c_int64),
+                ("max_hl_expansions", ctypes.c_int64), ("n_threads", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class mrp_hl_batch_stats(ctypes.Structure):
+    _fields_ = [("wall_seconds", ctypes.c_double), ("rounds", ctypes.c_int64), ("ll_searches", ctypes.c_int64),
+                ("ll_expansions", ctypes.c_int64), ("solved", ctypes.c_int64)]
+
+
+EXPORTS = ["mrp_hl_solve_batch", "mrp_hl_solver_create", "mrp_hl_solver_destroy", "mrp_hl_solver_solve",
+           "mrp_hl_solver_ll_stats", "mrp_hl_solver_last_error", "mrp_hl_generate_instance"]
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        _ll.load_library()  # libmrp_hl.so links against libmrp_ll.so
+        if not os.path.exists(_LIB_PATH):
+            raise OSError(f"{_LIB_PATH} not found: build it with `python -m libmultirobotplanning_amd._build`")
+        lib = ctypes.CDLL(_LIB_PATH)
+        lib.mrp_hl_solver_create.restype = ctypes.c_int
+        lib.mrp_hl_solver_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_ll.mrp_ll_options),
+                                             ctypes.POINTER(ctypes.c_void_p)]
+        lib.mrp_hl_solver_destroy.restype = None
+        lib.mrp_hl_solver_destroy.argtypes = [ctypes.c_void_p]
+        lib.mrp_hl_solver_solve.restype = ctypes.c_int
+        lib.mrp_hl_solver_solve.argtypes = [ctypes.c_void_p, ctypes.POINTER(mrp_hl_options), ctypes.c_int32,
+                                            ctypes.POINTER(mrp_hl_instance), ctypes.POINTER(mrp_hl_solution),
+                                            ctypes.POINTER(mrp_hl_batch_stats)]
+        lib.mrp_hl_solver_ll_stats.restype = ctypes.c_int
+        lib.mrp_hl_solver_ll_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ll.mrp_ll_stats), ctypes.c_int32]
+        lib.mrp_hl_solver_last_error.restype = ctypes.c_char_p
+        lib.mrp_hl_solver_last_error.argtypes = [ctypes.c_void_p]
+        lib.mrp_hl_solve_batch.restype = ctypes.c_int
+        lib.mrp_hl_solve_batch.argtypes = [ctypes.c_int32, ctypes.POINTER(mrp_hl_options), ctypes.c_int32,
+                                           ctypes.POINTER(mrp_hl_instance), ctypes.POINTER(mrp_hl_solution),
+                                           ctypes.POINTER(mrp_hl_batch_stats)]
+        lib.mrp_hl_generate_instance.restype = ctypes.c_int
+        lib.mrp_hl_generate_instance.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                 ctypes.c_int32, I32P, I32P, I32P]
+        _lib = lib
+    return _lib
+
+
+def generate_instance(seed: int, dimx: int = 32, dimy: int = 32, n_obstacles: int = 204, n_agents: int = 10) -> Dict:
+    """Seeded synthetic 32x32_obst204-shaped instance (identical on every box)."""
+    lib = load_library()
+    ob = np.zeros((n_obstacles, 2), dtype=np.int32)
+    st = np.zeros((n_agents, 2), dtype=np.int32)
+    go = np.zeros((n_agents, 2), dtype=np.int32)
+    rc = lib.mrp_hl_generate_instance(seed, dimx, dimy, n_obstacles, n_agents, ob.ctypes.data_as(I32P),
+                                      st.ctypes.data_as(I32P), go.ctypes.data_as(I32P))
+    if rc != 0:
+        raise ValueError("instance generation failed")
+    return dict(dimx=dimx, dimy=dimy, obstacles=ob.tolist(), starts=st.tolist(), goals=go.tolist())
+
+
+class BatchSolver:
+    """Persistent solver: engines/arenas are created once; solve() may be called repeatedly."""
+
+    def __init__(self, device: int = 0, n_threads: int = 0, slots: int = 0, arena_nodes: int = 0,
+                 max_horizon: int = 0, lds_nodes: int = 0, max_cells: int = 0):
+        self._lib = load_library()
+        opt = _ll.mrp_ll_options(device, 1, slots, arena_nodes, max_horizon, max_cells, lds_nodes, 0)
+        h = ctypes.c_void_p()
+        rc = self._lib.mrp_hl_solver_create(device, n_threads, ctypes.byref(opt), ctypes.byref(h))
+        if rc != 0 or not h:
+            raise RuntimeError(f"mrp_hl_solver_create failed (rc={rc}): a HIP device is required (no CPU fallback)")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mrp_hl_solver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, instances: Sequence[Dict], algo: int = ECBS, w: float = 1.3, max_ll_expansions: int = -1,
+              max_hl_expansions: int = -1, n_threads: int = 0, want_paths: bool = True, path_cap: int = 512):
+        n = len(instances)
+        cin = (mrp_hl_instance * max(n, 1))()
+        csol = (mrp_hl_solution * max(n, 1))()
+        keep = []
+        plen: List[Optional[np.ndarray]] = []
+        pxy: List[Optional[np.ndarray]] = []
+        for i, inst in enumerate(instances):
+            ob = np.ascontiguousarray(np.asarray(inst["obstacles"], dtype=np.int32).reshape(-1, 2))
+            st = np.ascontiguousarray(np.asarray(inst["starts"], dtype=np.int32).reshape(-1, 2))
+            go = np.ascontiguousarray(np.asarray(inst["goals"], dtype=np.int32).reshape(-1, 2))
+            keep.append((ob, st, go))
+            c = cin[i]
+            c.dimx, c.dimy = inst["dimx"], inst["dimy"]
+            c.n_obstacles, c.obstacles_xy = len(ob), ob.ctypes.data_as(I32P)
+            c.n_agents, c.starts_xy, c.goals_xy = len(st), st.ctypes.data_as(I32P), go.ctypes.data_as(I32P)
+            if want_paths:
+                a = np.zeros(len(st), dtype=np.int32)
+                b = np.zeros((len(st), path_cap, 2), dtype=np.int32)
+                plen.append(a)
+                pxy.append(b)
+                csol[i].path_len = a.ctypes.data_as(I32P)
+                csol[i].paths_xy = b.ctypes.data_as(I32P)
+                csol[i].path_cap = path_cap
+        opt = mrp_hl_options(algo, w, max_ll_expansions, max_hl_expansions, n_threads, 0)
+        st = mrp_hl_batch_stats()
+        rc = self._lib.mrp_hl_solver_solve(self._h, ctypes.byref(opt), n, cin, csol, ctypes.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"mrp_hl_solver_solve failed rc={rc}: {self._lib.mrp_hl_solver_last_error(self._h).decode()}")
+        out = []
+        for i in range(n):
+            s = csol[i]
+            rec = dict(status=s.status, cost=s.cost, makespan=s.makespan, hl_expanded=s.high_level_expanded,
+                       ll_expanded=s.low_level_expanded, ll_searches=s.n_ll_searches)
+            if want_paths and s.status == SOLVED:
+                assert int(plen[i].max(initial=0)) <= path_cap
+                rec["paths"] = [pxy[i][a, :plen[i][a]].tolist() for a in range(len(plen[i]))]
+            out.append(rec)
+        stats = dict(wall_seconds=st.wall_seconds, rounds=st.rounds, ll_searches=st.ll_searches,
+                     ll_expansions=st.ll_expansions, solved=st.solved)
+        return out, stats
+
+    def ll_stats(self, reset: bool = False) -> dict:
+        st = _ll.mrp_ll_stats()
+        self._lib.mrp_hl_solver_ll_stats(self._h, ctypes.byref(st), 1 if reset else 0)
+        return {k: getattr(st, k) for k, _ in _ll.mrp_ll_stats._fields_}

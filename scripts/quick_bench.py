@@ -1,0 +1,21 @@
+"""Quick throughput probe of the batched ECBS driver (not the contract bench; see bench.py)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from libmultirobotplanning_amd import hl
+n_inst = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+agents = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+slots = int(sys.argv[4]) if len(sys.argv) > 4 else 512
+t0 = time.time()
+insts = [hl.generate_instance(1000 * agents + k, 32, 32, 204, agents) for k in range(n_inst)]
+print("generated %d instances in %.2fs" % (n_inst, time.time() - t0), flush=True)
+s = hl.BatchSolver(device=0, n_threads=threads, slots=slots)
+print("solver created %.2fs" % (time.time() - t0), flush=True)
+for rep in range(3):
+    s.ll_stats(reset=True)
+    res, st = s.solve(insts, algo=hl.ECBS, w=1.3, want_paths=False)
+    ls = s.ll_stats()
+    print("rep %d: wall %.3fs  solved %d/%d  LL exp %d  => %.3e exp/s, %.1f inst/s ; rounds %d searches %d ; kernel_ms(sum) %.1f launches %d migrated %d" % (
+        rep, st["wall_seconds"], st["solved"], n_inst, st["ll_expansions"], st["ll_expansions"] / st["wall_seconds"],
+        n_inst / st["wall_seconds"], st["rounds"], st["ll_searches"], ls["kernel_ms"], ls["launches"], ls["migrated"]), flush=True)
