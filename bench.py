@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: ECBS (w = 1.3) low-level searches on 32x32_obst204-shaped instances, batched on MI355X.
+
+Contract (one JSON line on rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one batch of B fresh synthetic instances per GPU solved to completion by the host conflict-tree driver, every
+low-level search of which runs in the HIP kernel (through the C-ABI).  metric = low-level node expansions per second
+(the reference's `lowLevelExpanded` counter, example/ecbs.cpp:476-479,599) over the whole job; `instances_per_s` rides
+along.  Instances are generated (splitmix64, seeds 1000*agents + k) before the timed region and their maps are uploaded
+to HBM before it starts, as the reference constructs its Environment before its Timer (example/ecbs.cpp:576-582).
+
+Extra objects:
+  roofline     — dominant kernel mrp_ll_search_kernel: achieved = 128 B/expansion x expansions of the
+                 timed launches / sum of their hipEvent durations; bound = HBM (8 TB/s).  See DESIGN.md for why this
+                 fraction is tiny by construction (the path is latency-bound heap replay in LDS, not streaming).
+  cpu_baseline — the oracle's CPU restatement (kind "port"; the reference needs Boost/yaml-cpp and cannot be built here)
+                 timed single-threaded on a bounded sample of the same workload, on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# One HIP stream per host worker thread: give each its own hardware queue (the ROCm default of 4 makes streams that
+# share a queue serialise their kernels).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+ALGO_BYTES_PER_EXPANSION = 128
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--instances", type=int, default=4096, help="instances per GPU per step")
+    ap.add_argument("--agents", type=int, default=10)
+    ap.add_argument("--threads", type=int, default=0, help="host worker threads per GPU (0 = auto)")
+    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--lds-nodes", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=1536, help="instances of step 0 timed on the CPU oracle (rank 0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-ll-expansions", type=int, default=50000,
+                    help="harness cap per instance (the reference has none and never returns on infeasible inputs); "
+                         "applied identically to the GPU path and to the CPU baseline")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist = dist_mod
+
+    from libmultirobotplanning_amd import hl
+    hc = os.cpu_count() or 8
+    threads = args.threads or max(2, min(16, hc // max(1, world)))
+    solver = hl.BatchSolver(device=local_rank, n_threads=threads, slots=args.slots, lds_nodes=args.lds_nodes)
+
+    B, K, W = args.instances, args.steps, args.warmup
+
+    def batch(step_idx):
+        # distinct seeds per (rank, step); step indices of the timed steps start after the warm-up ones
+        base = 1000 * args.agents + (rank * (K + W) + step_idx) * B
+        return [hl.generate_instance(base + k, 32, 32, 204, args.agents) for k in range(B)]
+
+    batches = [batch(i) for i in range(K + W)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(W):
+        solver.solve(batches[i], algo=hl.ECBS, w=1.3, want_paths=False, max_ll_expansions=args.max_ll_expansions)
+    solver.ll_stats(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    exp_total = 0
+    solved_total = 0
+    searches_total = 0
+    first_results = None
+    for i in range(W, W + K):
+        res, st = solver.solve(batches[i], algo=hl.ECBS, w=1.3, want_paths=False,
+                               max_ll_expansions=args.max_ll_expansions)
+        exp_total += st["ll_expansions"]
+        solved_total += st["solved"]
+        searches_total += st["ll_searches"]
+        if first_results is None:
+            first_results = res
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lls = solver.ll_stats()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    sums = torch.tensor([exp_total, solved_total, searches_total, K * B], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)   # incumbent totals: the only exchange this path needs
+    elapsed_max = float(t.item())
+    exp_all, solved_all, searches_all, inst_all = (float(x) for x in sums.tolist())
+
+    if rank == 0:
+        kernel_s = lls["kernel_ms"] / 1e3
+        achieved = ALGO_BYTES_PER_EXPANSION * lls["expansions"] / max(kernel_s, 1e-12) / 1e9
+        out = {
+            "metric": "low_level_node_expansions_per_sec",
+            "value": exp_all / elapsed_max,
+            "unit": "expansions/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * elapsed_max / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "ECBS w=1.3, synthetic 32x32_obst204-shaped instances, agents%d, %d instances/GPU/step "
+                                   "(configs[1] shape)" % (args.agents, B),
+                       "instances_per_gpu_per_step": B, "agents": args.agents, "host_threads_per_gpu": threads,
+                       "max_ll_expansions_per_instance": args.max_ll_expansions,
+                       "parallelism": "instances sharded per GPU, no data-path collective"},
+            "instances_per_s": inst_all / elapsed_max,
+            "solved": int(solved_all),
+            "instances": int(inst_all),
+            "ll_searches": int(searches_all),
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "mrp_ll_search_kernel",
+                "launches": lls["launches"],
+                "avg_launch_ms": lls["kernel_ms"] / max(lls["launches"], 1),
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EXPANSION * lls["expansions"] / max(lls["launches"], 1),
+                "note": "rank-0 launches of the timed region; launches of different host threads overlap in time",
+            },
+        }
+        if not args.no_cpu_baseline:
+            import oracle
+            oracle.build()
+            n = min(args.cpu_sample, B)
+            t_cpu = 0.0
+            e_cpu = 0
+            mism = 0
+            for inst, r in zip(batches[W][:n], first_results[:n]):
+                o = oracle.mapf_solve(oracle.ECBS, inst, w=1.3, cap_total=args.max_ll_expansions, path_cap=1024)
+                t_cpu += o["elapsed_ns"] / 1e9
+                e_cpu += o["ll_expanded"]
+                if o["rc"] == 1:
+                    if (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) != (
+                            hl.SOLVED, o["cost"], o["makespan"], o["hl_expanded"], o["ll_expanded"]):
+                        mism += 1
+                elif r["status"] != hl.CAP:  # capped on the CPU => must be capped on the GPU too
+                    mism += 1
+            out["cpu_baseline"] = {
+                "value": e_cpu / max(t_cpu, 1e-12), "unit": "expansions/s", "cores": 1, "kind": "port",
+                "sample": "first %d instances of timed step 0 (rank 0), oracle ECBS w=1.3, g++ -O3, search() time only"
+                          % n,
+                "instances_per_s": n / max(t_cpu, 1e-12), "seconds": t_cpu,
+                "host_cpus": hc, "parity_mismatches_vs_gpu": mism,
+            }
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,6 +71,8 @@ typedef struct mrp_hl_batch_stats {
   int64_t ll_searches;
   int64_t ll_expansions;          /* over every search that was run (== sum of solutions' low_level_expanded)     */
   int64_t solved;
+  /* host-side time summed over worker threads (diagnostic): building jobs, inside mrp_ll_search_batch, consuming results */
+  double build_seconds, ll_call_seconds, consume_seconds;
 } mrp_hl_batch_stats;
 
 /* One engine context per calling thread is created internally for every worker thread on `device`. */

@@ -8,6 +8,11 @@ Layout:
 
 The product path never imports ``oracle`` and has no CPU fallback.
 """
-from . import _build  # noqa: F401
+import os as _os
+
+# one hardware queue per host worker stream (ROCm default: 4); only effective if set before HIP initialises
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+from . import _build  # noqa: F401,E402
 
 __all__ = ["ll", "hl", "_build"]

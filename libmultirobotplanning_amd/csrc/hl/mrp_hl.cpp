@@ -27,6 +27,7 @@ namespace {
 
 struct GroupResult {
   int64_t rounds = 0, searches = 0, expansions = 0;
+  double buildS = 0, llS = 0, consumeS = 0;
   std::string err;
 };
 
@@ -49,7 +50,12 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
   std::vector<int32_t> statesPool;
   const int32_t cap = horizon;
 
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count();
+  };
   for (;;) {
+    auto tA = now();
     jobs.clear();
     owner.clear();
     pathLenPool.clear();
@@ -100,7 +106,9 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
       results[q].actions = nullptr;
       results[q].states_cap = cap;
     }
+    auto tB = now();
     int rc = mrp_ll_search_batch(ctx, static_cast<int32_t>(jobs.size()), jobs.data(), results.data());
+    auto tC = now();
     if (rc != MRP_LL_SUCCESS) {
       out.err = std::string("mrp_ll_search_batch: ") + mrp_ll_last_error(ctx);
       return;
@@ -133,6 +141,10 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
       if (req[k].empty()) continue;
       inst[k]->advance(ans[k], req[k]);
     }
+    auto tD = now();
+    out.buildS += secs(tA, tB);
+    out.llS += secs(tB, tC);
+    out.consumeS += secs(tC, tD);
   }
   for (size_t k = 0; k < n; ++k) {
     const Instance& I = *inst[k];
@@ -213,6 +225,9 @@ int mrp_hl_solver_ll_stats(mrp_hl_solver* s, mrp_ll_stats* out, int32_t reset) {
     out->kernel_ms += st.kernel_ms;
     out->h2d_ms += st.h2d_ms;
     out->d2h_ms += st.d2h_ms;
+    out->pack_ms += st.pack_ms;
+    out->unpack_ms += st.unpack_ms;
+    for (int q = 0; q < 8; ++q) out->prof[q] += st.prof[q];
     if (reset) mrp_ll_reset_stats(e);
   }
   return MRP_LL_SUCCESS;
@@ -261,6 +276,9 @@ int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* optIn, int32_t n
     st.rounds += g.rounds;
     st.ll_searches += g.searches;
     st.ll_expansions += g.expansions;
+    st.build_seconds += g.buildS;
+    st.ll_call_seconds += g.llS;
+    st.consume_seconds += g.consumeS;
   }
   for (int32_t k = 0; k < nInst; ++k) st.solved += solutions[k].status == MRP_HL_SOLVED ? 1 : 0;
   if (stats) *stats = st;

@@ -5,19 +5,20 @@
 namespace mrp {
 
 // ---- packed heap entry (uint64) ------------------------------------------------------------------------------
-//   [59:42] FH_MAXV - focalH   [41:31] F_MAXV - f   [30:20] g   [19:0] node id
-// A larger (entry >> 20) is a BETTER node in the reference's orders:
-//   open  (a_star_epsilon.hpp:312-323, a_star.hpp:168-179): lowest f, then highest g      -> bits [41:20]
-//   focal (a_star_epsilon.hpp:346-366): lowest focalH, then lowest f, then highest g      -> bits [59:20]
-// Entries with equal keys compare EQUAL (the id bits never take part), exactly like the reference's comparators;
-// which of two equal entries comes out first is decided by the heap layout, which the kernels replay verbatim.
-constexpr uint32_t kIdBits = 20;
-constexpr uint32_t kIdMask = (1u << kIdBits) - 1;
-constexpr uint32_t kGBits = 11, kFBits = 11, kFhBits = 18;
+//   high word (the key): [31:21] FH_MAXV - focalH   [20:10] F_MAXV - f   [9:0] g        low word: node id
+// A larger key is a BETTER node in the reference's orders:
+//   open  (a_star_epsilon.hpp:312-323, a_star.hpp:168-179): lowest f, then highest g      -> key bits [20:0]
+//   focal (a_star_epsilon.hpp:346-366): lowest focalH, then lowest f, then highest g      -> key bits [31:0]
+// Entries with equal keys compare EQUAL (the id never takes part), exactly like the reference's comparators; which
+// of two equal entries comes out first is decided by the heap layout, which the kernels replay verbatim.
+constexpr uint32_t kGBits = 10, kFBits = 11, kFhBits = 11;
+constexpr uint32_t kGMask = (1u << kGBits) - 1;
 constexpr uint32_t kFMax = (1u << kFBits) - 1;
-constexpr uint32_t kFhMax = (1u << kFhBits) - 1;
-constexpr uint32_t kOpenKeyMask = (1u << (kGBits + kFBits)) - 1;  // applied to (entry >> kIdBits)
-constexpr uint32_t kMaxHorizon = 1024;                             // t < 1024  (g field has 11 bits)
+constexpr uint32_t kFhMax = (1u << kFhBits) - 1;                   // focalH beyond this -> MRP_LL_CAP_FOCAL (loud)
+constexpr uint32_t kOpenKeyMask = (1u << (kGBits + kFBits)) - 1;   // applied to the key word
+constexpr uint32_t kMaxHorizon = 1024;                             // t <= 1023  (g field has 10 bits)
+constexpr uint32_t kMaxArenaNodes = 1u << 22;
+constexpr uint32_t kConsLocalWords = 2048;                        // constraint words copied into the arena slot
 constexpr uint32_t kNoParent = 0xFFFFFFFFu;
 constexpr uint32_t kEmptyCell = 0xFFFFu;                           // "no agent here" in the path table
 
@@ -40,7 +41,7 @@ struct DevJob {            // 80 bytes, 16-byte aligned
   int64_t max_expansions;  // < 0: unlimited
 };
 
-struct DevResult {         // 32 bytes
+struct DevResult {         // 64 bytes
   int32_t status;
   int32_t cost;
   int32_t fmin;
@@ -48,18 +49,27 @@ struct DevResult {         // 32 bytes
   int64_t expanded;
   uint32_t nodes_created;
   uint32_t tier;
+  uint32_t prof[8];        // -DMRP_LL_TRACE builds only: cycles in walk / pops / pushes / successors / rows / total,
+                           // number of walks, nodes visited by walks (zero otherwise)
 };
 
+// Zero-copy staging: jobs / cons / paths / results / out_paths live in pinned host memory that the device reads and
+// writes directly (no hipMemcpy commands per batch); each workgroup bulk-copies what its job needs into LDS or its
+// arena slot at job start and writes the result back with coalesced stores.
 struct LaunchParams {
-  const DevJob* jobs;
-  DevResult* results;
-  uint16_t* out_paths;        // [n_jobs][out_stride] : x | y<<8 for t = 0..n_states-1
-  const uint32_t* maps;       // obstacle bitmaps
-  const uint32_t* cons;       // constraint words of the batch
-  const uint16_t* paths;      // path tables of the batch
-  uint32_t* queue_head;       // job counter of this launch (zeroed by the host before the launch)
+  const DevJob* jobs;         // host-mapped
+  DevResult* results;         // host-mapped
+  uint16_t* out_paths;        // host-mapped [n_jobs][out_stride] : x | y<<8 for t = 0..n_states-1
+  const uint32_t* maps;       // device: obstacle bitmaps
+  const uint32_t* cons;       // host-mapped: constraint words of the batch
+  const uint16_t* paths;      // host-mapped: path tables of the batch
+  uint32_t* queue_head;       // device: monotonic job counter of this ticket (job = counter - queue_base)
   uint8_t* arena;             // HBM tier: per resident workgroup `arena_stride` bytes
   uint64_t arena_stride;
+  uint32_t queue_base;
+  uint32_t arena_scratch_off; // byte offset inside a slot of [path out][constraint copy][path-table copy]
+  uint32_t arena_paths_bytes; // capacity of the path-table copy in the arena slot
+  uint32_t lds_paths_bytes;   // capacity of the path-table copy in LDS
   uint32_t n_jobs;
   uint32_t out_stride;
   uint32_t arena_nodes;       // node capacity in the HBM tier

@@ -40,6 +40,15 @@ typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 #else
 #define DBG(P, slot, val) do { } while (0)
 #endif
+#ifdef MRP_LL_TRACE
+#define PROF_T0() uint64_t prof_t0__ = __builtin_amdgcn_s_memtime()
+#define PROF_ADD(res, k) (res).prof[k] += (uint32_t)(__builtin_amdgcn_s_memtime() - prof_t0__)
+#define PROF_INC(res, k, v) (res).prof[k] += (uint32_t)(v)
+#else
+#define PROF_T0() do { } while (0)
+#define PROF_ADD(res, k) do { } while (0)
+#define PROF_INC(res, k, v) do { } while (0)
+#endif
 
 DEVI uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 DEVI int32_t rfli(int32_t v) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)v); }
@@ -51,13 +60,13 @@ DEVI uint64_t rfl64(uint64_t v) {
 
 // ---- entry packing ---------------------------------------------------------------------------------------------
 DEVI uint64_t packEntry(uint32_t fh, uint32_t f, uint32_t g, uint32_t id) {
-  return ((uint64_t)(kFhMax - fh) << (kIdBits + kGBits + kFBits)) | ((uint64_t)(kFMax - f) << (kIdBits + kGBits)) |
-         ((uint64_t)g << kIdBits) | id;
+  const uint32_t key = ((kFhMax - fh) << (kGBits + kFBits)) | ((kFMax - f) << kGBits) | g;
+  return ((uint64_t)key << 32) | id;
 }
-DEVI int32_t entryF(uint64_t e) { return (int32_t)(kFMax - (uint32_t)((e >> (kIdBits + kGBits)) & kFMax)); }
-DEVI uint32_t entryId(uint64_t e) { return (uint32_t)e & kIdMask; }
-DEVI uint32_t openKey(uint64_t e) { return (uint32_t)(e >> kIdBits) & kOpenKeyMask; }
-DEVI uint64_t focalKey(uint64_t e) { return e >> kIdBits; }
+DEVI uint32_t entryKey(uint64_t e) { return (uint32_t)(e >> 32); }
+DEVI int32_t entryF(uint64_t e) { return (int32_t)(kFMax - ((entryKey(e) >> kGBits) & kFMax)); }
+DEVI uint32_t entryId(uint64_t e) { return (uint32_t)e; }
+DEVI uint32_t openKey(uint64_t e) { return entryKey(e) & kOpenKeyMask; }
 
 // ---- memory tiers ----------------------------------------------------------------------------------------------
 // AS = 3: LDS, AS = 1: global (HBM arena).  Heap arrays are stored with a one-element bias so that the two children
@@ -81,10 +90,10 @@ struct Ctx {  // wave-uniform job context
   int32_t lastGoal;
   float w;
   uint32_t nVc, nEc;
-  const uint32_t* vc;
+  const uint32_t* vc;       // generic pointers: LDS, arena copy, or (oversized lists only) host memory
   const uint32_t* ec;
   const uint32_t* obst;     // global obstacle bitmap
-  const uint16_t* paths;
+  const uint16_t* paths;    // generic: LDS copy, arena copy, or host memory
   uint32_t nAgentsPad, tPad;
   int64_t maxExp;
   volatile uint32_t* debug;
@@ -109,126 +118,154 @@ DEVI void ldPair(typename Mem<AS>::P64 p, uint32_t i, uint64_t& a, uint64_t& b) 
   b = rfl64(v.y);
 }
 
-// ---- heap primitives (wave-uniform; OPEN=true maintains the handle -> position map inside the node record) -----
-template <int AS, bool OPEN>
+// ---- heap primitives ------------------------------------------------------------------------------------------
+// The heaps are replayed EXACTLY (same array layout after every operation as boost::heap::d_ary_heap / libstdc++'s
+// std::push_heap / std::pop_heap would have), but not one element at a time: the data-independent part of every
+// operation is done by all lanes at once so that an operation costs O(1) memory round trips instead of O(log n):
+//   * sift-up      : lane k loads the k-th ancestor; one ballot finds where the sequential loop would have stopped;
+//                    the ancestors below that point move down one level in a single parallel store.
+//   * sift-down    : which child is "the larger one" does not depend on the element being sifted, so 63 lanes load
+//                    the child pairs of a whole 6-level subtree in one instruction and the path is then followed with
+//                    scalar bit tests / v_readlane (no further memory latency); repeated per 6 levels.
+//   * erase        : the unconditional bubble-to-root is a one-level shift of the ancestor chain (parallel).
+// KEY selects the comparator: 0 = open (f asc, g desc), 1 = focal (focalH, f asc, g desc), 2 = walk queue (open key
+// kept in the high word).  POS=true maintains handle -> position inside the node record (open list only).
+template <int KEY>
+DEVI bool kLess(uint64_t a, uint64_t b) {  // the reference's "operator<": a is WORSE than b
+  if (KEY == 0) return openKey(a) < openKey(b);
+  return entryKey(a) < entryKey(b);  // focal: whole key word; walk queue: the open key stored as its key word
+}
+
+template <int AS, bool POS>
 DEVI void heapStore(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx, uint64_t e) {
   heap[idx] = e;
-  if (OPEN) ((typename Mem<AS>::P32)m.nodes)[entryId(e) * 4 + 3] = idx;
-}
-template <bool OPEN>
-DEVI bool keyLess(uint64_t a, uint64_t b) {  // the reference's "operator<": a is WORSE than b
-  return OPEN ? (openKey(a) < openKey(b)) : (focalKey(a) < focalKey(b));
+  if (POS) ((typename Mem<AS>::P32)m.nodes)[entryId(e) * 4 + 3] = idx;
 }
 
-// boost siftup: while cmp(parent, child) swap
-template <int AS, bool OPEN>
+DEVI uint64_t readlane64(uint64_t v, uint32_t srcLane) {
+  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, srcLane);
+  uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), srcLane);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// boost siftup / libstdc++ __push_heap from position idx: while less(parent, e) the parent moves down.
+template <int AS, int KEY, bool POS>
 DEVI void siftUp(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx, uint64_t e) {
-  while (idx != 0) {
-    uint32_t parent = (idx - 1) >> 1;
-    uint64_t pe = ld64<AS>(heap, parent);
-    if (!keyLess<OPEN>(pe, e)) break;
-    heapStore<AS, OPEN>(m, heap, idx, pe);
-    idx = parent;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t depth = 31u - (uint32_t)__builtin_clz(idx + 1);  // number of ancestors of idx
+  uint32_t stop = 0;
+  if (depth != 0) {
+    const bool act = lane < depth;
+    const uint32_t anc = act ? ((idx + 1) >> (lane + 1)) - 1 : 0;     // lane k: k-th ancestor
+    const uint64_t ae = heap[anc];
+    const uint64_t worse = __ballot(act && kLess<KEY>(ae, e));
+    stop = (uint32_t)__builtin_ctzll(~worse);                          // first ancestor that is not worse than e
+    if (lane < stop) {                                                 // ancestors 0..stop-1 move down one level
+      const uint32_t dest = ((idx + 1) >> lane) - 1;
+      heap[dest] = ae;
+      if (POS) ((typename Mem<AS>::P32)m.nodes)[entryId(ae) * 4 + 3] = dest;
+    }
   }
-  heapStore<AS, OPEN>(m, heap, idx, e);
+  heapStore<AS, POS>(m, heap, ((idx + 1) >> stop) - 1, e);
 }
 
-// boost siftdown of element e starting from hole idx in a heap of n elements: choose the first maximal child,
-// move down while !cmp(child, e)
-template <int AS, bool OPEN>
-DEVI void siftDown(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t n, uint32_t idx, uint64_t e) {
+// Moves the hole at `idx` down a heap of n elements.
+//   STL=false (boost siftdown): prefer the FIRST maximal child; stop in front of a child that is less than x; x is
+//             stored at the final hole.
+//   STL=true  (libstdc++ __adjust_heap): prefer the right child unless it is less than the left one; always descend
+//             to a leaf; the final hole index is returned (the caller then sifts its value up from there).
+// Per 6 levels: one 16-byte load per lane (63 lanes = the whole subtree below the hole), two ballots, a scalar walk
+// over the two bit masks, and ONE predicated store in which every node on the path pulls its chosen child up.
+template <int AS, int KEY, bool POS, bool STL>
+DEVI uint32_t descend(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t n, uint32_t idx, uint64_t x) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lv = 31u - (uint32_t)__builtin_clz(lane + 1);  // level of this lane inside a 6-level subtree
+  const uint32_t off = (lane + 1) - (1u << lv);                 // position inside that level
+  const uint32_t xk = KEY == 0 ? openKey(x) : entryKey(x);
   for (;;) {
-    uint32_t c = 2 * idx + 1;
-    if (c >= n) break;
-    uint64_t e1, e2;
-    ldPair<AS>(heap, c, e1, e2);
-    uint32_t pick = c;
-    uint64_t pe = e1;
-    if (c + 1 < n && keyLess<OPEN>(e1, e2)) {
-      pick = c + 1;
-      pe = e2;
+    const uint32_t node = ((idx + 1) << lv) - 1 + off;          // lane l < 63 owns this node of the subtree
+    const uint32_t c = 2 * node + 1;
+    const bool has = (lane < 63) && (c < n);
+    u64x2 pr;
+    pr.x = 0;
+    pr.y = 0;
+    if (has) pr = *(typename Mem<AS>::PPair)(heap + c);         // children (c, c+1): one aligned 16-byte load
+    const uint32_t kl = KEY == 0 ? openKey(pr.x) : entryKey(pr.x);
+    const uint32_t kr = KEY == 0 ? openKey(pr.y) : entryKey(pr.y);
+    const bool hasR = has && (c + 1 < n);
+    const bool right = hasR && (STL ? !(kr < kl) : (kl < kr));
+    const uint64_t pe = right ? pr.y : pr.x;
+    const uint32_t pk = right ? kr : kl;
+    const bool go = has && (STL || !(pk < xk));                 // the hole moves below this node
+    const uint64_t goMask = __ballot(go);
+    const uint64_t rightMask = __ballot(right);
+    uint64_t pathMask = 0;
+    uint32_t rel = 0, steps = 0;
+#pragma unroll 1
+    while (steps < 6 && ((goMask >> rel) & 1ull)) {
+      pathMask |= 1ull << rel;
+      rel = 2 * rel + 1 + (uint32_t)((rightMask >> rel) & 1ull);
+      steps += 1;
     }
-    if (keyLess<OPEN>(pe, e)) break;
-    heapStore<AS, OPEN>(m, heap, idx, pe);
-    idx = pick;
+    if ((pathMask >> lane) & 1ull) {                            // every node on the path pulls its chosen child up
+      heap[node] = pe;
+      if (POS) ((typename Mem<AS>::P32)m.nodes)[entryId(pe) * 4 + 3] = node;
+    }
+    idx = ((idx + 1) << steps) - 1 + (rel + 1 - (1u << steps)); // absolute index of the new hole
+    if (steps < 6) break;
   }
-  heapStore<AS, OPEN>(m, heap, idx, e);
+  if (!STL) heapStore<AS, POS>(m, heap, idx, x);
+  return idx;
 }
 
 // boost pop: swap(front, back), drop back, siftdown(0)
-template <int AS, bool OPEN>
+template <int AS, int KEY, bool POS>
 DEVI void heapPop(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t& n) {
   n -= 1;
   if (n == 0) return;
-  uint64_t last = ld64<AS>(heap, n);
-  siftDown<AS, OPEN>(m, heap, n, 0, last);
+  const uint64_t last = ld64<AS>(heap, n);
+  descend<AS, KEY, POS, false>(m, heap, n, 0, last);
 }
 
 // boost erase(handle): swap the element up to the root unconditionally, then pop
 template <int AS>
 DEVI void openErase(Mem<AS>& m, uint32_t& n, uint32_t idx) {
-  while (idx != 0) {
-    uint32_t parent = (idx - 1) >> 1;
-    uint64_t pe = ld64<AS>(m.open, parent);
-    heapStore<AS, true>(m, m.open, idx, pe);
-    idx = parent;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t depth = 31u - (uint32_t)__builtin_clz(idx + 1);
+  if (depth != 0) {  // every ancestor moves down one level along the path to idx
+    const bool act = lane < depth;
+    const uint32_t anc = act ? ((idx + 1) >> (lane + 1)) - 1 : 0;
+    const uint64_t ae = m.open[anc];
+    if (act) {
+      const uint32_t dest = ((idx + 1) >> lane) - 1;
+      m.open[dest] = ae;
+      ((typename Mem<AS>::P32)m.nodes)[entryId(ae) * 4 + 3] = dest;
+    }
   }
-  heapPop<AS, true>(m, m.open, n);
+  heapPop<AS, 0, true>(m, m.open, n);
 }
 
 // ---- ordered walk (open.ordered_begin(), a_star_epsilon.hpp:141-152) ----------------------------------------
-// libstdc++ std::priority_queue<…> restated: __push_heap / __adjust_heap of bits/stl_heap.h.
+// libstdc++ std::priority_queue<…> restated: push = __push_heap, pop = __pop_heap/__adjust_heap (bits/stl_heap.h).
 template <int AS>
 DEVI void auxPush(Mem<AS>& m, uint32_t& npq, uint64_t v) {
-  uint32_t hole = npq++;
-  while (hole > 0) {
-    uint32_t parent = (hole - 1) >> 1;
-    uint64_t pe = ld64<AS>(m.aux, parent);
-    if (!((uint32_t)(pe >> 32) < (uint32_t)(v >> 32))) break;
-    m.aux[hole] = pe;
-    hole = parent;
-  }
-  m.aux[hole] = v;
+  siftUp<AS, 2, false>(m, m.aux, npq, v);
+  npq += 1;
 }
 template <int AS>
 DEVI uint32_t auxPop(Mem<AS>& m, uint32_t& npq) {
-  uint64_t result = ld64<AS>(m.aux, 0);
-  uint64_t value = ld64<AS>(m.aux, npq - 1);
+  const uint64_t result = ld64<AS>(m.aux, 0);
   npq -= 1;
-  int32_t len = (int32_t)npq;
-  if (len > 0) {
-    int32_t hole = 0, child = 0;
-    while (child < (len - 1) / 2) {
-      child = 2 * (child + 1);
-      uint64_t l, r;  // l = aux[child-1] (odd index), r = aux[child]
-      ldPair<AS>(m.aux, (uint32_t)child - 1, l, r);
-      uint64_t pe = r;
-      if ((uint32_t)(r >> 32) < (uint32_t)(l >> 32)) {
-        child--;
-        pe = l;
-      }
-      m.aux[hole] = pe;
-      hole = child;
-    }
-    if ((len & 1) == 0 && child == (len - 2) / 2) {
-      child = 2 * (child + 1);
-      m.aux[hole] = ld64<AS>(m.aux, (uint32_t)child - 1);
-      hole = child - 1;
-    }
-    while (hole > 0) {
-      int32_t parent = (hole - 1) / 2;
-      uint64_t pe = ld64<AS>(m.aux, (uint32_t)parent);
-      if (!((uint32_t)(pe >> 32) < (uint32_t)(value >> 32))) break;
-      m.aux[hole] = pe;
-      hole = parent;
-    }
-    m.aux[hole] = value;
+  if (npq > 0) {
+    const uint64_t value = ld64<AS>(m.aux, npq);  // *(last - 1)
+    const uint32_t hole = descend<AS, 2, false, true>(m, m.aux, npq, 0, value);
+    siftUp<AS, 2, false>(m, m.aux, hole, value);
   }
   return (uint32_t)result;  // low 32 bits = index into the open array
 }
 
 template <int AS>
-DEVI void orderedWalk(Mem<AS>& m, SState& s, const Ctx& c, int32_t oldBest) {
+DEVI void orderedWalk(Mem<AS>& m, SState& s, const Ctx& c, int32_t oldBest, DevResult& res) {
   // int * float products in binary32, no contraction (a_star_epsilon.hpp:145,149)
   const float lo = __fmul_rn((float)oldBest, c.w);
   const float hi = __fmul_rn((float)s.bestF, c.w);
@@ -241,10 +278,11 @@ DEVI void orderedWalk(Mem<AS>& m, SState& s, const Ctx& c, int32_t oldBest) {
       auxPush<AS>(m, npq, ((uint64_t)openKey(e1) << 32) | first);
       if (first + 1 < s.nOpen) auxPush<AS>(m, npq, ((uint64_t)openKey(e2) << 32) | (first + 1));
     }
+    PROF_INC(res, 7, 1);
     uint64_t e = ld64<AS>(m.open, cur);
     float fv = (float)entryF(e);
     if (fv > lo && fv <= hi) {
-      siftUp<AS, false>(m, m.focal, s.nFocal, e);
+      siftUp<AS, 1, false>(m, m.focal, s.nFocal, e);
       s.nFocal += 1;
     }
     if (fv > hi) break;
@@ -313,7 +351,12 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
     if (EPS) {
       int32_t oldBest = s.bestF;
       s.bestF = entryF(topE);
-      if (s.bestF > oldBest) orderedWalk<AS>(m, s, c, oldBest);
+      if (s.bestF > oldBest) {
+        PROF_T0();
+        orderedWalk<AS>(m, s, c, oldBest, res);
+        PROF_ADD(res, 0);
+        PROF_INC(res, 6, 1);
+      }
       curE = ld64<AS>(m.focal, 0);
     }
     const uint32_t curId = entryId(curE);
@@ -365,15 +408,24 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
       return ST_OK;
     }
 
-    if (EPS) {
-      heapPop<AS, false>(m, m.focal, s.nFocal);
-      openErase<AS>(m, s.nOpen, curPos);
-    } else {
-      heapPop<AS, true>(m, m.open, s.nOpen);
+    {
+      PROF_T0();
+      if (EPS) {
+        heapPop<AS, 1, false>(m, m.focal, s.nFocal);
+        openErase<AS>(m, s.nOpen, curPos);
+      } else {
+        heapPop<AS, 0, true>(m, m.open, s.nOpen);
+      }
+      PROF_ADD(res, 1);
     }
 
     const uint32_t t1 = t + 1;
-    ensureRows<AS>(m, s, c, t1, c.obst, obstLocal, useLocal);
+    {
+      PROF_T0();
+      ensureRows<AS>(m, s, c, t1, c.obst, obstLocal, useLocal);
+      PROF_ADD(res, 4);
+    }
+    PROF_T0();
 
     // successors in the reference's order Wait, Left, Right, Up, Down (ecbs.cpp:365-398) on lanes 0..4
     const int32_t dx = (lane == 2) - (lane == 1);
@@ -392,6 +444,7 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
       }
     }
     uint64_t mask = __ballot(ok) & 0x1Full;
+    PROF_ADD(res, 3);
 
     while (mask) {
       const uint32_t k = (uint32_t)__builtin_ctzll(mask);
@@ -433,23 +486,25 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
         m.bits[wi] = wv | (1u << (cc & 31));
       }
       const uint64_t e = packEntry(fh, f, t1, nid);
-      siftUp<AS, true>(m, m.open, s.nOpen, e);
+      PROF_T0();
+      siftUp<AS, 0, true>(m, m.open, s.nOpen, e);
       s.nOpen += 1;
       if (EPS) {
         if ((float)(int32_t)f <= __fmul_rn((float)s.bestF, c.w)) {  // a_star_epsilon.hpp:240
-          siftUp<AS, false>(m, m.focal, s.nFocal, e);
+          siftUp<AS, 1, false>(m, m.focal, s.nFocal, e);
           s.nFocal += 1;
         }
       }
+      PROF_ADD(res, 2);
     }
   }
 }
 
 // ---- LDS layout ------------------------------------------------------------------------------------------------
 constexpr uint32_t kEcLocal = 64;
-__host__ __device__ inline uint32_t ldsBytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords) {
-  // nodes 16 B, three biased heaps 8 B (+16 B bias pad each), bitmap rows, obstacle row, edge constraints
-  return capNodes * 16 + 3 * (capNodes * 8 + 16) + rows * rowWords * 4 + rowWords * 4 + kEcLocal * 4;
+__host__ __device__ inline uint32_t ldsBytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes) {
+  // nodes 16 B, three biased heaps 8 B (+16 B bias pad each), bitmap rows, obstacle row, edge constraints, path table
+  return capNodes * 16 + 3 * (capNodes * 8 + 16) + rows * rowWords * 4 + rowWords * 4 + kEcLocal * 4 + pathBytes;
 }
 
 template <bool EPS>
@@ -462,13 +517,44 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   c.lastGoal = J.last_goal_constraint;
   c.w = J.w;
   c.nVc = J.n_vc; c.nEc = J.n_ec;
-  c.vc = P.cons + J.vc_off;
-  c.ec = P.cons + J.ec_off;
   c.obst = P.maps + J.map_word_off;
-  c.paths = P.paths + J.path_off;
   c.nAgentsPad = J.n_agents_pad; c.tPad = J.t_pad;
   c.maxExp = J.max_expansions;
   c.debug = P.debug;
+
+  // ---- bulk-copy the job's constraint words and path table out of host memory (one pass, coalesced) ----
+  uint8_t* scratch = arenaSlot + P.arena_scratch_off;
+  uint32_t* consLocal = (uint32_t*)(scratch + (size_t)P.out_stride * 2);
+  uint8_t* pathsArena = (uint8_t*)(consLocal + kConsLocalWords);
+  {
+    const uint32_t* src = P.cons + J.vc_off;          // vertex words, then edge words (contiguous)
+    const uint32_t nWords = c.nVc + c.nEc;
+    if (nWords <= kConsLocalWords) {
+      for (uint32_t i = lane; i < nWords; i += 64) consLocal[i] = src[i];
+      c.vc = consLocal;
+      c.ec = consLocal + c.nVc;
+    } else {
+      c.vc = src;
+      c.ec = P.cons + J.ec_off;
+    }
+    const uint32_t pathBytes = c.tPad * c.nAgentsPad * 2;  // multiple of 32
+    const uint32_t* psrc = (const uint32_t*)(P.paths + J.path_off);
+    uint8_t* ldsPaths = smem + ldsBytes(P.lds_nodes, P.lds_rows, P.lds_row_words, 0);
+    if (pathBytes == 0) {
+      c.paths = nullptr;
+    } else if (P.lds_nodes != 0 && pathBytes <= P.lds_paths_bytes) {
+      uint32_t* dst = (uint32_t*)ldsPaths;
+      for (uint32_t i = lane; i < pathBytes / 4; i += 64) dst[i] = psrc[i];
+      c.paths = (const uint16_t*)ldsPaths;
+    } else if (pathBytes <= P.arena_paths_bytes) {
+      uint32_t* dst = (uint32_t*)pathsArena;
+      for (uint32_t i = lane; i < pathBytes / 4; i += 64) dst[i] = psrc[i];
+      c.paths = (const uint16_t*)pathsArena;
+    } else {
+      c.paths = P.paths + J.path_off;
+    }
+  }
+  __syncthreads();
 
   SState s;
   int rc;
@@ -534,6 +620,8 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
 // One workgroup == one wavefront; persistent over the batch's job queue (exit: queue exhausted).
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ DevJob jobS;
+  __shared__ DevResult resS;
   const uint32_t lane = threadIdx.x;
   uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
   DBG(P, 0, 1);
@@ -541,21 +629,40 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchPara
     // every lane takes part (lane 0 adds 1, the others 0): the kernel deliberately contains no `if (lane == 0)`
     // blocks — hipcc once merged two of them into a wave-divergent wrapper loop that only lane 0 could leave.
     uint32_t j = atomicAdd(P.queue_head, lane == 0 ? 1u : 0u);
-    j = rfl(j);
+    j = rfl(j) - P.queue_base;
     DBG(P, 1, j + 1);
     if (j >= P.n_jobs) break;
-    const DevJob& J = P.jobs[j];
+    __syncthreads();
+    {  // one coalesced read of the 80-byte descriptor from host memory
+      const uint32_t* src = (const uint32_t*)(P.jobs + j);
+      if (lane < sizeof(DevJob) / 4) ((uint32_t*)&jobS)[lane] = src[lane];
+    }
+    __syncthreads();
+    const DevJob& J = jobS;
     DevResult res;
     res.status = ST_BAD; res.cost = 0; res.fmin = 0; res.n_states = 0; res.expanded = 0; res.nodes_created = 0;
     res.tier = 0;
-    uint16_t* outPath = P.out_paths + (size_t)j * P.out_stride;
+    for (int q = 0; q < 8; ++q) res.prof[q] = 0;
+    PROF_T0();
+    uint16_t* outPath = (uint16_t*)(arenaSlot + P.arena_scratch_off);  // device scratch; copied out below
     const uint32_t algo = rfl(J.algo);
     if (algo == 1)
       runJob<true>(P, J, smem, arenaSlot, res, outPath);
     else
       runJob<false>(P, J, smem, arenaSlot, res, outPath);
+    PROF_ADD(res, 5);
     DBG(P, 2, res.status + 100);
-    P.results[j] = res;  // all lanes write the same 32 bytes
+    // result + path back to host memory with lane-parallel stores
+    __syncthreads();
+    resS = res;
+    __syncthreads();
+    if (lane < sizeof(DevResult) / 4) ((uint32_t*)(P.results + j))[lane] = ((const uint32_t*)&resS)[lane];
+    if (res.status == ST_OK) {
+      const uint32_t words = ((uint32_t)res.n_states + 1) / 2;
+      const uint32_t* src = (const uint32_t*)outPath;
+      uint32_t* dst = (uint32_t*)(P.out_paths + (size_t)j * P.out_stride);
+      for (uint32_t i = lane; i < words; i += 64) dst[i] = src[i];
+    }
     DBG(P, 3, j + 1);
   }
   DBG(P, 4, 1);
@@ -564,15 +671,15 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchPara
 }  // namespace mrp
 
 // ---- host-callable launcher (used by mrp_ll_host.cpp) -----------------------------------------------------------
-extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords) {
-  return mrp::ldsBytes(capNodes, rows, rowWords);
+extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes) {
+  return mrp::ldsBytes(capNodes, rows, rowWords, pathBytes);
 }
 
 extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, hipStream_t stream) {
   static bool attrSet = false;
   if (!attrSet) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mrp::mrp_ll_search_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);  // minus the static jobS/resS
     if (e != hipSuccess) return e;
     attrSet = true;
   }

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <ctime>
 #include <string>
@@ -13,7 +14,7 @@
 #include "../../include/mrp_ll.h"
 #include "ll_device.h"
 
-extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords);
+extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes);
 extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, hipStream_t stream);
 
 namespace {
@@ -26,55 +27,68 @@ struct MapRec {
   uint32_t wpr, wordOff;
 };
 
+// Growable pinned host buffer that the device accesses in place (zero-copy staging, see ll_device.h).
 template <typename T>
-struct DevBuf {  // growable device buffer + pinned host mirror
-  T* dev = nullptr;
+struct PinnedBuf {
   T* host = nullptr;
-  size_t cap = 0;
-  hipError_t reserve(size_t n, bool needHost) {
+  T* dev = nullptr;   // device-side address of the same memory
+  size_t cap = 0, size = 0;
+  hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
     size_t ncap = std::max<size_t>(n, cap * 2);
-    ncap = std::max<size_t>(ncap, 1024);
-    if (dev) (void)hipFree(dev);
-    if (host) (void)hipHostFree(host);
-    dev = nullptr;
-    host = nullptr;
-    cap = 0;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), ncap * sizeof(T));
+    ncap = std::max<size_t>(ncap, 4096);
+    T* nh = nullptr;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&nh), ncap * sizeof(T), hipHostMallocMapped);
     if (e != hipSuccess) return e;
-    if (needHost) {
-      e = hipHostMalloc(reinterpret_cast<void**>(&host), ncap * sizeof(T), hipHostMallocDefault);
-      if (e != hipSuccess) return e;
+    void* nd = nullptr;
+    e = hipHostGetDevicePointer(&nd, nh, 0);
+    if (e != hipSuccess) return e;
+    if (host) {
+      if (size) std::memcpy(nh, host, size * sizeof(T));
+      (void)hipHostFree(host);
     }
+    host = nh;
+    dev = static_cast<T*>(nd);
     cap = ncap;
     return hipSuccess;
   }
+  hipError_t resize(size_t n) {
+    hipError_t e = reserve(n);
+    if (e == hipSuccess) size = n;
+    return e;
+  }
+  hipError_t push(const T& v) {
+    if (size == cap) {
+      hipError_t e = reserve(size + 1);
+      if (e != hipSuccess) return e;
+    }
+    host[size++] = v;
+    return hipSuccess;
+  }
+  void clear() { size = 0; }
   void release() {
-    if (dev) (void)hipFree(dev);
     if (host) (void)hipHostFree(host);
-    dev = nullptr;
-    host = nullptr;
-    cap = 0;
+    host = dev = nullptr;
+    cap = size = 0;
   }
 };
 
 struct Ticket {
   hipStream_t stream = nullptr;
-  hipEvent_t evH2D0 = nullptr, evK0 = nullptr, evK1 = nullptr, evDone = nullptr;
-  DevBuf<DevJob> jobs;
-  DevBuf<uint32_t> cons;
-  DevBuf<uint16_t> paths;
-  DevBuf<DevResult> results;
-  DevBuf<uint16_t> outPaths;
-  uint32_t* queueHead = nullptr;
+  hipEvent_t evK0 = nullptr, evK1 = nullptr;
+  PinnedBuf<DevJob> jobs;
+  PinnedBuf<uint32_t> cons;
+  PinnedBuf<uint16_t> paths;
+  PinnedBuf<DevResult> results;
+  PinnedBuf<uint16_t> outPaths;
+  uint32_t* queueHead = nullptr;   // device, monotonic
+  uint32_t queueBase = 0;
   uint8_t* arena = nullptr;
   bool inFlight = false;
+  bool allocFailed = false;
   int32_t nJobs = 0;
   mrp_ll_result* userResults = nullptr;
   std::vector<uint8_t> rejected;  // per job: rejected on the host (MRP_LL_BAD_JOB)
-  std::vector<DevJob> jobStage;   // built in pageable memory first (sizes of cons/paths unknown until packed)
-  std::vector<uint32_t> consStage;
-  std::vector<uint16_t> pathStage;
 };
 
 }  // namespace
@@ -91,6 +105,8 @@ struct mrp_ll_ctx {
   uint32_t maxWpr = 1;
   uint32_t arenaRowWords = 0;
   uint64_t arenaStride = 0;
+  uint32_t arenaScratchOff = 0;
+  uint32_t arenaPathsBytes = 0;
   std::vector<Ticket> tickets;
   mrp_ll_stats stats;
   uint32_t* debugHost = nullptr;  // MRP_LL_DEBUG: host-mapped trace buffer
@@ -133,7 +149,7 @@ int syncMaps(mrp_ll_ctx* ctx) {
   size_t need = std::max<size_t>(ctx->mapWords.size(), 1);
   if (need > ctx->mapsDevCap) {
     for (auto& t : ctx->tickets)
-      if (t.inFlight) HIPCHK(ctx, hipEventSynchronize(t.evDone));
+      if (t.inFlight) HIPCHK(ctx, hipEventSynchronize(t.evK1));
     if (ctx->mapsDev) HIPCHK(ctx, hipFree(ctx->mapsDev));
     size_t ncap = std::max<size_t>(need * 2, 4096);
     HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mapsDev), ncap * sizeof(uint32_t)));
@@ -173,24 +189,26 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, Ticket& t, DevJob& d) {
   d.max_expansions = j.max_expansions;
   // setLowLevelContext (ecbs.cpp:264-274): last vertex constraint on the goal cell
   int lastGoal = -1;
-  d.vc_off = static_cast<uint32_t>(t.consStage.size());
+  d.vc_off = static_cast<uint32_t>(t.cons.size);
   for (int i = 0; i < j.n_vertex_constraints; ++i) {
     const int32_t* v = j.vertex_constraints + 3 * i;
     if (v[1] == j.goal_x && v[2] == j.goal_y) lastGoal = std::max(lastGoal, v[0]);
     if (v[0] < 0 || v[0] >= horizon || !inGrid(v[1], v[2])) continue;  // can never match a generated state
-    t.consStage.push_back((static_cast<uint32_t>(v[0]) << 16) | static_cast<uint32_t>(v[2] * mp.dimx + v[1]));
+    if (t.cons.push((static_cast<uint32_t>(v[0]) << 16) | static_cast<uint32_t>(v[2] * mp.dimx + v[1])) != hipSuccess)
+      t.allocFailed = true;
   }
-  d.n_vc = static_cast<uint32_t>(t.consStage.size()) - d.vc_off;
+  d.n_vc = static_cast<uint32_t>(t.cons.size) - d.vc_off;
   d.last_goal_constraint = lastGoal;
-  d.ec_off = static_cast<uint32_t>(t.consStage.size());
+  d.ec_off = static_cast<uint32_t>(t.cons.size);
   for (int i = 0; i < j.n_edge_constraints; ++i) {
     const int32_t* e = j.edge_constraints + 5 * i;
     int k = neighborIndexFromDelta(e[3] - e[1], e[4] - e[2]);
     if (k < 0 || e[0] < 0 || e[0] >= horizon || !inGrid(e[1], e[2])) continue;
-    t.consStage.push_back((static_cast<uint32_t>(e[0]) << 19) | (static_cast<uint32_t>(e[2] * mp.dimx + e[1]) << 3) |
-                          static_cast<uint32_t>(k));
+    if (t.cons.push((static_cast<uint32_t>(e[0]) << 19) | (static_cast<uint32_t>(e[2] * mp.dimx + e[1]) << 3) |
+                    static_cast<uint32_t>(k)) != hipSuccess)
+      t.allocFailed = true;
   }
-  d.n_ec = static_cast<uint32_t>(t.consStage.size()) - d.ec_off;
+  d.n_ec = static_cast<uint32_t>(t.cons.size) - d.ec_off;
   // focal context: time-major table of the other agents' cells, each path extended by its last cell
   d.n_agents_pad = 0;
   d.t_pad = 0;
@@ -206,23 +224,28 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, Ticket& t, DevJob& d) {
     if (tpad > 0) {
       uint32_t npad = (static_cast<uint32_t>(j.n_agents) + 15u) & ~15u;
       // 16-byte align the table start
-      while (t.pathStage.size() & 7u) t.pathStage.push_back(mrp::kEmptyCell);
-      d.path_off = static_cast<uint32_t>(t.pathStage.size());
+      size_t base = (t.paths.size + 7u) & ~size_t(7);
+      if (t.paths.resize(base + static_cast<size_t>(tpad) * npad) != hipSuccess) {
+        t.allocFailed = true;
+        return false;
+      }
+      d.path_off = static_cast<uint32_t>(base);
       d.n_agents_pad = npad;
       d.t_pad = static_cast<uint32_t>(tpad);
-      size_t base = t.pathStage.size();
-      t.pathStage.resize(base + static_cast<size_t>(tpad) * npad, static_cast<uint16_t>(mrp::kEmptyCell));
+      uint16_t* tab = t.paths.host + base;
+      const uint16_t none = static_cast<uint16_t>(mrp::kEmptyCell);
+      for (size_t q = 0; q < static_cast<size_t>(tpad) * npad; ++q) tab[q] = none;
       for (int a = 0; a < j.n_agents; ++a) {
         int len = j.path_len[a];
         if (a == j.agent_idx || len <= 0) continue;
         const int32_t* xy = j.path_xy[a];
-        uint16_t cell = static_cast<uint16_t>(mrp::kEmptyCell);
+        uint16_t cell = none;
         for (int tt = 0; tt < tpad; ++tt) {
           if (tt < len) {
             int x = xy[2 * tt], y = xy[2 * tt + 1];
-            cell = inGrid(x, y) ? static_cast<uint16_t>(y * mp.dimx + x) : static_cast<uint16_t>(mrp::kEmptyCell);
+            cell = inGrid(x, y) ? static_cast<uint16_t>(y * mp.dimx + x) : none;
           }
-          t.pathStage[base + static_cast<size_t>(tt) * npad + a] = cell;
+          tab[static_cast<size_t>(tt) * npad + a] = cell;
         }
       }
     }
@@ -247,7 +270,7 @@ int mrp_ll_create(const mrp_ll_options* optIn, mrp_ll_ctx** out) {
   if (o.n_tickets <= 0) o.n_tickets = 4;
   if (o.slots <= 0) o.slots = 1024;
   if (o.arena_nodes <= 0) o.arena_nodes = 131072;
-  if (o.arena_nodes > static_cast<int32_t>(mrp::kIdMask)) o.arena_nodes = mrp::kIdMask;
+  if (o.arena_nodes > static_cast<int32_t>(mrp::kMaxArenaNodes)) o.arena_nodes = mrp::kMaxArenaNodes;
   o.arena_nodes &= ~1;
   if (o.max_horizon <= 0) o.max_horizon = 512;
   if (o.max_horizon > static_cast<int32_t>(mrp::kMaxHorizon)) o.max_horizon = mrp::kMaxHorizon;
@@ -273,15 +296,19 @@ int mrp_ll_create(const mrp_ll_options* optIn, mrp_ll_ctx** out) {
   uint64_t stride = static_cast<uint64_t>(o.arena_nodes) * 16 + 3ull * (static_cast<uint64_t>(o.arena_nodes) * 8 + 16) +
                     static_cast<uint64_t>(o.max_horizon) * ctx->arenaRowWords * 4;
   stride = (stride + 255) & ~255ull;
+  // scratch tail of every slot: [path out: max_horizon u16][constraint copy][path-table copy]
+  ctx->arenaScratchOff = static_cast<uint32_t>(stride);
+  ctx->arenaPathsBytes = 128 * 1024;
+  stride += static_cast<uint64_t>(o.max_horizon) * 2 + mrp::kConsLocalWords * 4 + ctx->arenaPathsBytes;
+  stride = (stride + 255) & ~255ull;
   ctx->arenaStride = stride;
   ctx->tickets.resize(o.n_tickets);
   for (auto& t : ctx->tickets) {
     hipError_t e = hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&t.evH2D0);
     if (e == hipSuccess) e = hipEventCreate(&t.evK0);
     if (e == hipSuccess) e = hipEventCreate(&t.evK1);
-    if (e == hipSuccess) e = hipEventCreate(&t.evDone);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t.queueHead), 256);
+    if (e == hipSuccess) e = hipMemset(t.queueHead, 0, 256);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t.arena), stride * static_cast<uint64_t>(o.slots));
     if (e != hipSuccess) {
       ctx->err = std::string("mrp_ll_create: ") + hipGetErrorString(e);
@@ -297,7 +324,7 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (auto& t : ctx->tickets) {
-    if (t.inFlight && t.evDone) (void)hipEventSynchronize(t.evDone);
+    if (t.inFlight && t.evK1) (void)hipEventSynchronize(t.evK1);
     if (t.stream) (void)hipStreamSynchronize(t.stream);
     t.jobs.release();
     t.cons.release();
@@ -306,10 +333,8 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
     t.outPaths.release();
     if (t.queueHead) (void)hipFree(t.queueHead);
     if (t.arena) (void)hipFree(t.arena);
-    if (t.evH2D0) (void)hipEventDestroy(t.evH2D0);
     if (t.evK0) (void)hipEventDestroy(t.evK0);
     if (t.evK1) (void)hipEventDestroy(t.evK1);
-    if (t.evDone) (void)hipEventDestroy(t.evDone);
     if (t.stream) (void)hipStreamDestroy(t.stream);
   }
   if (ctx->mapsDev) (void)hipFree(ctx->mapsDev);
@@ -365,21 +390,23 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
   int rc = syncMaps(ctx);
   if (rc != MRP_LL_SUCCESS) return rc;
   Ticket& t = ctx->tickets[ti];
+  auto packT0 = std::chrono::steady_clock::now();
   t.nJobs = nJobs;
   t.userResults = results;
   t.rejected.assign(nJobs, 0);
-  t.jobStage.clear();
-  t.consStage.clear();
-  t.pathStage.clear();
-  t.jobStage.resize(nJobs);
+  t.allocFailed = false;
+  t.jobs.clear();
+  t.cons.clear();
+  t.paths.clear();
+  HIPCHK(ctx, t.jobs.resize(std::max(nJobs, 1)));
   for (int i = 0; i < nJobs; ++i) {
-    size_t c0 = t.consStage.size(), p0 = t.pathStage.size();
-    if (!packJob(ctx, jobs[i], t, t.jobStage[i])) {
-      // rejected: give the device a trivially failing job (no solution cap 0) and remember the rejection
-      t.consStage.resize(c0);
-      t.pathStage.resize(p0);
+    size_t c0 = t.cons.size, p0 = t.paths.size;
+    if (!packJob(ctx, jobs[i], t, t.jobs.host[i])) {
+      // rejected: give the device a trivially capped job and remember the rejection
+      t.cons.size = c0;
+      t.paths.size = p0;
       t.rejected[i] = 1;
-      DevJob& d = t.jobStage[i];
+      DevJob& d = t.jobs.host[i];
       std::memset(&d, 0, sizeof(d));
       d.dimx = 1; d.dimy = 1; d.words_per_row = 1;
       d.map_word_off = ctx->maps.empty() ? 0 : ctx->maps[0].wordOff;
@@ -387,31 +414,19 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
       d.max_expansions = 0;
     }
   }
+  if (t.allocFailed) {
+    ctx->err = "mrp_ll_submit: pinned staging allocation failed";
+    return MRP_LL_E_NOMEM;
+  }
   *ticketOut = ti;
   t.inFlight = true;
-  if (nJobs == 0) {
-    HIPCHK(ctx, hipEventRecord(t.evDone, t.stream));
-    return MRP_LL_SUCCESS;
-  }
+  if (nJobs == 0) return MRP_LL_SUCCESS;
   const uint32_t outStride = static_cast<uint32_t>(ctx->opt.max_horizon);
-  HIPCHK(ctx, t.jobs.reserve(nJobs, true));
-  HIPCHK(ctx, t.cons.reserve(std::max<size_t>(t.consStage.size(), 1), true));
-  HIPCHK(ctx, t.paths.reserve(std::max<size_t>(t.pathStage.size(), 8), true));
-  HIPCHK(ctx, t.results.reserve(nJobs, true));
-  HIPCHK(ctx, t.outPaths.reserve(static_cast<size_t>(nJobs) * outStride, true));
-  std::memcpy(t.jobs.host, t.jobStage.data(), sizeof(DevJob) * nJobs);
-  if (!t.consStage.empty()) std::memcpy(t.cons.host, t.consStage.data(), sizeof(uint32_t) * t.consStage.size());
-  if (!t.pathStage.empty()) std::memcpy(t.paths.host, t.pathStage.data(), sizeof(uint16_t) * t.pathStage.size());
-
-  HIPCHK(ctx, hipEventRecord(t.evH2D0, t.stream));
-  HIPCHK(ctx, hipMemcpyAsync(t.jobs.dev, t.jobs.host, sizeof(DevJob) * nJobs, hipMemcpyHostToDevice, t.stream));
-  if (!t.consStage.empty())
-    HIPCHK(ctx, hipMemcpyAsync(t.cons.dev, t.cons.host, sizeof(uint32_t) * t.consStage.size(), hipMemcpyHostToDevice,
-                               t.stream));
-  if (!t.pathStage.empty())
-    HIPCHK(ctx, hipMemcpyAsync(t.paths.dev, t.paths.host, sizeof(uint16_t) * t.pathStage.size(),
-                               hipMemcpyHostToDevice, t.stream));
-  HIPCHK(ctx, hipMemsetAsync(t.queueHead, 0, 4, t.stream));
+  HIPCHK(ctx, t.cons.reserve(16));
+  HIPCHK(ctx, t.paths.reserve(16));
+  HIPCHK(ctx, t.results.resize(nJobs));
+  HIPCHK(ctx, t.outPaths.resize(static_cast<size_t>(nJobs) * outStride));
+  ctx->stats.pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - packT0).count();
 
   mrp::LaunchParams P;
   std::memset(&P, 0, sizeof(P));
@@ -422,25 +437,30 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
   P.cons = t.cons.dev;
   P.paths = t.paths.dev;
   P.queue_head = t.queueHead;
+  P.queue_base = t.queueBase;
   P.arena = t.arena;
   P.arena_stride = ctx->arenaStride;
+  P.arena_scratch_off = ctx->arenaScratchOff;
+  P.arena_paths_bytes = ctx->arenaPathsBytes;
   P.n_jobs = static_cast<uint32_t>(nJobs);
   P.out_stride = outStride;
   P.arena_nodes = static_cast<uint32_t>(ctx->opt.arena_nodes);
   P.arena_rows = static_cast<uint32_t>(ctx->opt.max_horizon);
   P.arena_row_words = ctx->arenaRowWords;
-  // LDS tier geometry: rows sized for the widest uploaded map, within a fixed budget per workgroup
+  // LDS tier geometry: rows sized for the widest uploaded map; a workgroup may take up to the CU's whole 160 KiB
+  // (minus the kernel's small static LDS); occupancy is floor(160 KiB / ldsBytes) workgroups per CU
   uint32_t ldsNodes = static_cast<uint32_t>(ctx->opt.lds_nodes);
   uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
   uint32_t rows = 0;
   uint32_t ldsBytes = 0;
+  const uint32_t ldsPaths = 4096;
   if (ldsNodes) {
-    const uint32_t budget = 40 * 1024;
-    uint32_t fixed = mrp_ll_lds_bytes(ldsNodes, 0, rowWords);
-    if (fixed + 8 * rowWords * 4 <= budget) {
+    const uint32_t budget = 160 * 1024 - 512;
+    uint32_t fixed = mrp_ll_lds_bytes(ldsNodes, 0, rowWords, ldsPaths);
+    if (fixed + 16 * rowWords * 4 <= budget) {
       rows = std::min<uint32_t>(64, (budget - fixed) / (rowWords * 4));
       rows = std::min<uint32_t>(rows, static_cast<uint32_t>(ctx->opt.max_horizon));
-      ldsBytes = mrp_ll_lds_bytes(ldsNodes, rows, rowWords);
+      ldsBytes = mrp_ll_lds_bytes(ldsNodes, rows, rowWords, ldsPaths);
     } else {
       ldsNodes = 0;
     }
@@ -448,6 +468,7 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
   P.lds_nodes = ldsNodes;
   P.lds_rows = rows;
   P.lds_row_words = rowWords;
+  P.lds_paths_bytes = ldsNodes ? ldsPaths : 0;
   if (kDebug) {
     if (!ctx->debugHost) {
       HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->debugHost), 16 * 4 * 4096, hipHostMallocMapped | hipHostMallocCoherent));
@@ -458,13 +479,10 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
     P.debug = static_cast<volatile uint32_t*>(dptr);
   }
   uint32_t grid = std::min<uint32_t>(static_cast<uint32_t>(nJobs), static_cast<uint32_t>(ctx->opt.slots));
+  t.queueBase += static_cast<uint32_t>(nJobs) + grid;  // every workgroup takes one ticket past the end when it exits
   HIPCHK(ctx, hipEventRecord(t.evK0, t.stream));
   HIPCHK(ctx, mrp_ll_launch(&P, grid, ldsBytes, t.stream));
   HIPCHK(ctx, hipEventRecord(t.evK1, t.stream));
-  HIPCHK(ctx, hipMemcpyAsync(t.results.host, t.results.dev, sizeof(DevResult) * nJobs, hipMemcpyDeviceToHost, t.stream));
-  HIPCHK(ctx, hipMemcpyAsync(t.outPaths.host, t.outPaths.dev, sizeof(uint16_t) * static_cast<size_t>(nJobs) * outStride,
-                             hipMemcpyDeviceToHost, t.stream));
-  HIPCHK(ctx, hipEventRecord(t.evDone, t.stream));
   ctx->stats.launches += 1;
   return MRP_LL_SUCCESS;
 }
@@ -475,11 +493,11 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
   if (!t.inFlight) return MRP_LL_E_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (kDebug && ctx->debugHost) {
-    for (int spin = 0; spin < 100 && hipEventQuery(t.evDone) == hipErrorNotReady; ++spin) {
+    for (int spin = 0; spin < 100 && hipEventQuery(t.evK1) == hipErrorNotReady; ++spin) {
       struct timespec ts = {0, 100000000};
       nanosleep(&ts, nullptr);
     }
-    if (hipEventQuery(t.evDone) == hipErrorNotReady) {
+    if (hipEventQuery(t.evK1) == hipErrorNotReady) {
       std::fprintf(stderr, "[mrp_ll] kernel did not finish within 10 s; trace of the first workgroups:\n");
       for (int b = 0; b < 4; ++b) {
         std::fprintf(stderr, "  wg %d:", b);
@@ -490,14 +508,14 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
       std::_Exit(3);
     }
   }
-  HIPCHK(ctx, hipEventSynchronize(t.evDone));
   t.inFlight = false;
+  if (t.nJobs == 0) return MRP_LL_SUCCESS;
+  HIPCHK(ctx, hipEventSynchronize(t.evK1));
   if (t.nJobs == 0) return MRP_LL_SUCCESS;
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, t.evK0, t.evK1) == hipSuccess) ctx->stats.kernel_ms += ms;
-  if (hipEventElapsedTime(&ms, t.evH2D0, t.evK0) == hipSuccess) ctx->stats.h2d_ms += ms;
-  if (hipEventElapsedTime(&ms, t.evK1, t.evDone) == hipSuccess) ctx->stats.d2h_ms += ms;
   const uint32_t outStride = static_cast<uint32_t>(ctx->opt.max_horizon);
+  auto unpackT0 = std::chrono::steady_clock::now();
   for (int i = 0; i < t.nJobs; ++i) {
     mrp_ll_result& r = t.userResults[i];
     const DevResult& d = t.results.host[i];
@@ -518,6 +536,7 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
     ctx->stats.expansions += d.expanded;
     ctx->stats.nodes_created += d.nodes_created;
     ctx->stats.migrated += d.tier ? 1 : 0;
+    for (int q = 0; q < 8; ++q) ctx->stats.prof[q] += d.prof[q];
     if (d.status == mrp::ST_OK) {
       const uint16_t* p = t.outPaths.host + static_cast<size_t>(i) * outStride;
       int n = d.n_states;
@@ -534,6 +553,7 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
       if ((r.states_txy || r.actions) && r.states_cap < n) r.status = MRP_LL_PATH_TRUNCATED;
     }
   }
+  ctx->stats.unpack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - unpackT0).count();
   return MRP_LL_SUCCESS;
 }
 

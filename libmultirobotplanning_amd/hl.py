@@ -39,7 +39,8 @@ class mrp_hl_options(ctypes.Structure):
 
 class mrp_hl_batch_stats(ctypes.Structure):
     _fields_ = [("wall_seconds", ctypes.c_double), ("rounds", ctypes.c_int64), ("ll_searches", ctypes.c_int64),
-                ("ll_expansions", ctypes.c_int64), ("solved", ctypes.c_int64)]
+                ("ll_expansions", ctypes.c_int64), ("solved", ctypes.c_int64), ("build_seconds", ctypes.c_double),
+                ("ll_call_seconds", ctypes.c_double), ("consume_seconds", ctypes.c_double)]
 
 
 EXPORTS = ["mrp_hl_solve_batch", "mrp_hl_solver_create", "mrp_hl_solver_destroy", "mrp_hl_solver_solve",
@@ -156,10 +157,11 @@ class BatchSolver:
                 rec["paths"] = [pxy[i][a, :plen[i][a]].tolist() for a in range(len(plen[i]))]
             out.append(rec)
         stats = dict(wall_seconds=st.wall_seconds, rounds=st.rounds, ll_searches=st.ll_searches,
-                     ll_expansions=st.ll_expansions, solved=st.solved)
+                     ll_expansions=st.ll_expansions, solved=st.solved, build_seconds=st.build_seconds,
+                     ll_call_seconds=st.ll_call_seconds, consume_seconds=st.consume_seconds)
         return out, stats
 
     def ll_stats(self, reset: bool = False) -> dict:
         st = _ll.mrp_ll_stats()
         self._lib.mrp_hl_solver_ll_stats(self._h, ctypes.byref(st), 1 if reset else 0)
-        return {k: getattr(st, k) for k, _ in _ll.mrp_ll_stats._fields_}
+        return {k: (list(getattr(st, k)) if k == "prof" else getattr(st, k)) for k, _ in _ll.mrp_ll_stats._fields_}

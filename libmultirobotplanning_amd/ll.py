@@ -47,7 +47,8 @@ class mrp_ll_result(ctypes.Structure):
 class mrp_ll_stats(ctypes.Structure):
     _fields_ = [("launches", ctypes.c_int64), ("jobs", ctypes.c_int64), ("expansions", ctypes.c_int64),
                 ("nodes_created", ctypes.c_int64), ("migrated", ctypes.c_int64), ("kernel_ms", ctypes.c_double),
-                ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double)]
+                ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("pack_ms", ctypes.c_double),
+                ("unpack_ms", ctypes.c_double), ("prof", ctypes.c_int64 * 8)]
 
 
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
@@ -196,7 +197,7 @@ class LowLevelEngine:
     def stats(self) -> dict:
         st = mrp_ll_stats()
         self._check(self._lib.mrp_ll_get_stats(self._h, ctypes.byref(st)), "mrp_ll_get_stats")
-        return {k: getattr(st, k) for k, _ in mrp_ll_stats._fields_}
+        return {k: (list(getattr(st, k)) if k == "prof" else getattr(st, k)) for k, _ in mrp_ll_stats._fields_}
 
     def reset_stats(self):
         self._check(self._lib.mrp_ll_reset_stats(self._h), "mrp_ll_reset_stats")

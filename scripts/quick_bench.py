@@ -14,8 +14,11 @@ s = hl.BatchSolver(device=0, n_threads=threads, slots=slots)
 print("solver created %.2fs" % (time.time() - t0), flush=True)
 for rep in range(3):
     s.ll_stats(reset=True)
-    res, st = s.solve(insts, algo=hl.ECBS, w=1.3, want_paths=False)
+    res, st = s.solve(insts, algo=hl.ECBS, w=1.3, want_paths=False, max_ll_expansions=50000)
     ls = s.ll_stats()
     print("rep %d: wall %.3fs  solved %d/%d  LL exp %d  => %.3e exp/s, %.1f inst/s ; rounds %d searches %d ; kernel_ms(sum) %.1f launches %d migrated %d" % (
         rep, st["wall_seconds"], st["solved"], n_inst, st["ll_expansions"], st["ll_expansions"] / st["wall_seconds"],
         n_inst / st["wall_seconds"], st["rounds"], st["ll_searches"], ls["kernel_ms"], ls["launches"], ls["migrated"]), flush=True)
+    print("   host thread-seconds: build %.3f  ll_call %.3f (pack %.3f unpack %.3f kernel %.3f h2d %.3f d2h %.3f)  consume %.3f" % (
+        st["build_seconds"], st["ll_call_seconds"], ls["pack_ms"] / 1e3, ls["unpack_ms"] / 1e3, ls["kernel_ms"] / 1e3,
+        ls["h2d_ms"] / 1e3, ls["d2h_ms"] / 1e3, st["consume_seconds"]), flush=True)
