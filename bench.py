@@ -77,9 +77,11 @@ def main():
 
     B, K, W = args.instances, args.steps, args.warmup
 
+    from libmultirobotplanning_amd import sharding
+
     def batch(step_idx):
         # distinct seeds per (rank, step); step indices of the timed steps start after the warm-up ones
-        base = 1000 * args.agents + (rank * (K + W) + step_idx) * B
+        base = sharding.seed_base(args.agents, rank, K + W, step_idx, B)
         return [hl.generate_instance(base + k, 32, 32, 204, args.agents) for k in range(B)]
 
     batches = [batch(i) for i in range(K + W)]
@@ -111,13 +113,9 @@ def main():
     elapsed = time.perf_counter() - t0
     lls = solver.ll_stats()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    sums = torch.tensor([exp_total, solved_total, searches_total, K * B], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)   # incumbent totals: the only exchange this path needs
-    elapsed_max = float(t.item())
-    exp_all, solved_all, searches_all, inst_all = (float(x) for x in sums.tolist())
+    # totals: the only exchange this path needs (max of the elapsed times, sum of the counters)
+    elapsed_max, (exp_all, solved_all, searches_all, inst_all) = sharding.reduce_totals(
+        dist, "cuda", elapsed, [exp_total, solved_total, searches_total, K * B])
 
     if rank == 0:
         kernel_s = lls["kernel_ms"] / 1e3

@@ -55,6 +55,7 @@ extern "C" {
 #define MRP_LL_CAP_HORIZON 4    /* a state beyond mrp_ll_options.max_horizon would have been generated         */
 #define MRP_LL_BAD_JOB 5        /* job rejected on the host (unknown map, start/goal outside the grid, ...)    */
 #define MRP_LL_PATH_TRUNCATED 6 /* solved, but result.states_cap was too small; cost/fmin/expanded are valid    */
+#define MRP_LL_CAP_FOCAL 7      /* a node's focal value exceeded the 11-bit key field (2047 accumulated conflicts)  */
 
 /* Action codes == enum class Action of example/ecbs.cpp:49-55 */
 #define MRP_LL_ACT_UP 0

@@ -49,13 +49,15 @@ EXPORTS = ["mrp_hl_solve_batch", "mrp_hl_solver_create", "mrp_hl_solver_destroy"
 _lib = None
 
 
-def load_library():
+def load_library(path: Optional[str] = None):
+    """Load libmrp_hl.so.  `path` is for tests that bind the same ABI from another build of the drivers."""
     global _lib
-    if _lib is None:
-        _ll.load_library()  # libmrp_hl.so links against libmrp_ll.so
-        if not os.path.exists(_LIB_PATH):
-            raise OSError(f"{_LIB_PATH} not found: build it with `python -m libmultirobotplanning_amd._build`")
-        lib = ctypes.CDLL(_LIB_PATH)
+    if _lib is None or path is not None:
+        if path is None:
+            _ll.load_library()  # libmrp_hl.so links against libmrp_ll.so
+            if not os.path.exists(_LIB_PATH):
+                raise OSError(f"{_LIB_PATH} not found: build it with `python -m libmultirobotplanning_amd._build`")
+        lib = ctypes.CDLL(path or _LIB_PATH)
         lib.mrp_hl_solver_create.restype = ctypes.c_int
         lib.mrp_hl_solver_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_ll.mrp_ll_options),
                                              ctypes.POINTER(ctypes.c_void_p)]
@@ -76,6 +78,8 @@ def load_library():
         lib.mrp_hl_generate_instance.restype = ctypes.c_int
         lib.mrp_hl_generate_instance.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int32, I32P, I32P, I32P]
+        if path is not None:
+            return lib
         _lib = lib
     return _lib
 
@@ -97,8 +101,8 @@ class BatchSolver:
     """Persistent solver: engines/arenas are created once; solve() may be called repeatedly."""
 
     def __init__(self, device: int = 0, n_threads: int = 0, slots: int = 0, arena_nodes: int = 0,
-                 max_horizon: int = 0, lds_nodes: int = 0, max_cells: int = 0):
-        self._lib = load_library()
+                 max_horizon: int = 0, lds_nodes: int = 0, max_cells: int = 0, _lib_path: Optional[str] = None):
+        self._lib = load_library(_lib_path)
         opt = _ll.mrp_ll_options(device, 1, slots, arena_nodes, max_horizon, max_cells, lds_nodes, 0)
         h = ctypes.c_void_p()
         rc = self._lib.mrp_hl_solver_create(device, n_threads, ctypes.byref(opt), ctypes.byref(h))

@@ -1,0 +1,102 @@
+// TEST INFRASTRUCTURE ONLY — never shipped, never built into libmultirobotplanning_amd/lib.
+// Implements the C-ABI of include/mrp_ll.h on top of the ORACLE's low-level search (oracle_ll_search) so that the
+// host-side conflict-tree drivers (csrc/hl/) can be exercised on a machine without a GPU (`-m "not gpu"` tests).
+// The product library has no such path: libmrp_ll.so fails with MRP_LL_E_DEVICE when no HIP device exists.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mrp_ll.h"
+
+extern "C" int oracle_ll_search(int algo, float w, int dimx, int dimy, int nObst, const int32_t* obstXY, int agentIdx,
+                                int startX, int startY, int goalX, int goalY, int nVC, const int32_t* vc, int nEC,
+                                const int32_t* ec, int nCtx, const int32_t* ctxLen, const int32_t* ctxXY,
+                                int64_t capExpansions, int32_t* out, int64_t* expanded, int32_t* statesTXY,
+                                int32_t* actions, int cap);
+
+struct MockMap {
+  int dimx, dimy;
+  std::vector<int32_t> obst;
+};
+struct mrp_ll_ctx {
+  std::vector<MockMap> maps;
+  mrp_ll_stats stats;
+  std::string err;
+  int32_t pendingJobs = 0;
+  const mrp_ll_job* jobs = nullptr;
+  mrp_ll_result* results = nullptr;
+};
+
+extern "C" {
+const char* mrp_ll_version(void) { return "mrp_ll MOCK (oracle-backed, tests only)"; }
+const char* mrp_ll_last_error(const mrp_ll_ctx* c) { return c ? c->err.c_str() : "null"; }
+int mrp_ll_create(const mrp_ll_options*, mrp_ll_ctx** out) {
+  *out = new mrp_ll_ctx();
+  std::memset(&(*out)->stats, 0, sizeof(mrp_ll_stats));
+  return MRP_LL_SUCCESS;
+}
+void mrp_ll_destroy(mrp_ll_ctx* c) { delete c; }
+int mrp_ll_upload_map(mrp_ll_ctx* c, int32_t dimx, int32_t dimy, int32_t n, const int32_t* xy, int32_t* id) {
+  MockMap m{dimx, dimy, std::vector<int32_t>(xy, xy + 2 * n)};
+  c->maps.push_back(m);
+  *id = static_cast<int32_t>(c->maps.size()) - 1;
+  return MRP_LL_SUCCESS;
+}
+int mrp_ll_search_batch(mrp_ll_ctx* c, int32_t n, const mrp_ll_job* jobs, mrp_ll_result* res) {
+  for (int i = 0; i < n; ++i) {
+    const mrp_ll_job& j = jobs[i];
+    mrp_ll_result& r = res[i];
+    if (j.map_id < 0 || j.map_id >= static_cast<int>(c->maps.size())) {
+      r.status = MRP_LL_BAD_JOB;
+      continue;
+    }
+    const MockMap& m = c->maps[j.map_id];
+    std::vector<int32_t> ctxLen, ctxXY;
+    int nCtx = j.algo == MRP_LL_ASTAR_EPS ? j.n_agents : 0;
+    for (int a = 0; a < nCtx; ++a) {
+      int len = a == j.agent_idx ? 0 : j.path_len[a];
+      ctxLen.push_back(len);
+      for (int k = 0; k < 2 * len; ++k) ctxXY.push_back(j.path_xy[a][k]);
+    }
+    int32_t out[4];
+    int64_t expanded = 0;
+    std::vector<int32_t> st(3 * 2048), ac(2048);
+    int rc = oracle_ll_search(j.algo, j.w, m.dimx, m.dimy, static_cast<int>(m.obst.size() / 2), m.obst.data(),
+                              j.agent_idx, j.start_x, j.start_y, j.goal_x, j.goal_y, j.n_vertex_constraints,
+                              j.vertex_constraints, j.n_edge_constraints, j.edge_constraints, nCtx, ctxLen.data(),
+                              ctxXY.data(), j.max_expansions, out, &expanded, st.data(), ac.data(), 2048);
+    r.expanded = expanded;
+    r.tier = 0;
+    if (rc == -1) {
+      r.status = MRP_LL_CAP_EXPANSIONS;
+      continue;
+    }
+    r.status = out[0] ? MRP_LL_OK : MRP_LL_NO_SOLUTION;
+    r.cost = out[1];
+    r.fmin = out[2];
+    r.n_states = out[0] ? out[3] : 0;
+    for (int k = 0; k < r.n_states && k < r.states_cap; ++k) {
+      if (r.states_txy) std::memcpy(r.states_txy + 3 * k, st.data() + 3 * k, 12);
+      if (r.actions && k + 1 < r.n_states) r.actions[k] = ac[k];
+    }
+    c->stats.jobs += 1;
+    c->stats.expansions += expanded;
+  }
+  c->stats.launches += 1;
+  return MRP_LL_SUCCESS;
+}
+int mrp_ll_submit(mrp_ll_ctx* c, int32_t n, const mrp_ll_job* jobs, mrp_ll_result* res, int32_t* ticket) {
+  *ticket = 0;
+  return mrp_ll_search_batch(c, n, jobs, res);
+}
+int mrp_ll_wait(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
+int mrp_ll_get_stats(const mrp_ll_ctx* c, mrp_ll_stats* out) {
+  *out = c->stats;
+  return MRP_LL_SUCCESS;
+}
+int mrp_ll_reset_stats(mrp_ll_ctx* c) {
+  std::memset(&c->stats, 0, sizeof(c->stats));
+  return MRP_LL_SUCCESS;
+}
+}

@@ -1,0 +1,104 @@
+"""Host-side logic (csrc/hl/: CT state machines, exact HL heaps, conflict scans, batching) on a machine without a GPU.
+
+The drivers are compiled with g++ against tests/support/mock_ll.cpp — a TEST-ONLY stand-in for libmrp_ll.so that answers
+every low-level job with the oracle's search — and must reproduce the oracle's whole-instance results.  This isolates
+the host logic from the kernel; the product library itself has no CPU path (see test_library_exports.py).
+"""
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "_build")
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(("|" + ",".join("%d:%d" % (x, y) for x, y in p)).encode())
+    return h.hexdigest()[:16]
+
+
+@pytest.fixture(scope="module")
+def cpu_solver(oracle_mod):
+    from libmultirobotplanning_amd import hl
+    os.makedirs(BUILD, exist_ok=True)
+    out = os.path.join(BUILD, "libmrp_hl_cpu.so")
+    srcs = [os.path.join(ROOT, "libmultirobotplanning_amd", "csrc", "hl", "mrp_hl.cpp"),
+            os.path.join(ROOT, "tests", "support", "mock_ll.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-I", os.path.join(ROOT, "include"),
+                           "-o", out] + srcs + ["-L", os.path.join(ROOT, "oracle"), "-loracle",
+                                                "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    s = hl.BatchSolver(device=0, n_threads=3, _lib_path=out)
+    yield s
+    s.close()
+
+
+def test_known_answers(cpu_solver, ref_tests):
+    from libmultirobotplanning_amd import hl
+    names = ["mapf_simple1", "mapf_circle", "mapf_atGoal"]
+    insts = [ref_tests["mapf"][n] for n in names]
+    res, _ = cpu_solver.solve(insts, algo=hl.CBS)
+    assert [r["cost"] for r in res] == [ref_tests["cbs_cost"][n] for n in names]
+    res, _ = cpu_solver.solve(insts, algo=hl.ECBS, w=1.0)
+    assert [r["cost"] for r in res] == [ref_tests["ecbs_w1_cost"][n] for n in names]
+
+
+def test_ecbs_batch_matches_oracle(cpu_solver, bench_instances, oracle_expected):
+    from libmultirobotplanning_amd import hl
+    names = [n for n in sorted(bench_instances) if "32by32" in n and ("agents10_" in n or "agents20_" in n
+                                                                     or "agents30_" in n)][:60]
+    names += ["map_32by32_obst204_agents50_ex0", "map_32by32_obst204_agents100_ex0"]
+    res, stats = cpu_solver.solve([bench_instances[n] for n in names], algo=hl.ECBS, w=1.3)
+    for n, r in zip(names, res):
+        e = oracle_expected[n]["ecbs_w1.3"]
+        assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
+            hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"]), n
+        assert _digest(r["paths"]) == e["digest"], n
+    assert stats["ll_expansions"] == sum(r["ll_expanded"] for r in res)
+
+
+def test_cbs_batch_matches_oracle(cpu_solver, bench_instances, oracle_expected):
+    from libmultirobotplanning_amd import hl
+    names = [n for n in sorted(bench_instances) if "8by8" in n and oracle_expected[n]["cbs"]["rc"] == 1]
+    res, _ = cpu_solver.solve([bench_instances[n] for n in names], algo=hl.CBS)
+    for n, r in zip(names, res):
+        e = oracle_expected[n]["cbs"]
+        assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
+            hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"]), n
+        assert _digest(r["paths"]) == e["digest"], n
+
+
+def test_caps_and_empty(cpu_solver, bench_instances, oracle_expected):
+    from libmultirobotplanning_amd import hl
+    hard = [n for n in sorted(bench_instances) if "8by8" in n and oracle_expected[n]["cbs"]["rc"] == -1][:2]
+    res, _ = cpu_solver.solve([bench_instances[n] for n in hard], algo=hl.CBS, max_ll_expansions=5000)
+    assert all(r["status"] == hl.CAP for r in res)
+    res, _ = cpu_solver.solve([bench_instances[n] for n in hard], algo=hl.CBS, max_hl_expansions=10)
+    assert all(r["status"] == hl.CAP and r["hl_expanded"] == 11 for r in res)
+    res, stats = cpu_solver.solve([], algo=hl.ECBS)
+    assert res == [] and stats["rounds"] == 0
+
+
+def test_generator_is_deterministic_and_well_formed():
+    from libmultirobotplanning_amd import hl
+    a = hl.generate_instance(10007, 32, 32, 204, 10)
+    b = hl.generate_instance(10007, 32, 32, 204, 10)
+    assert a == b
+    obst = {tuple(o) for o in a["obstacles"]}
+    assert len(obst) == 204
+    assert len({tuple(s) for s in a["starts"]}) == 10 and len({tuple(g) for g in a["goals"]}) == 10
+    assert not (obst & {tuple(s) for s in a["starts"]}) and not (obst & {tuple(g) for g in a["goals"]})
+    # every goal reachable from its start (4-connected)
+    free = {(x, y) for x in range(32) for y in range(32)} - obst
+    for s, g in zip(a["starts"], a["goals"]):
+        seen, todo = {tuple(s)}, [tuple(s)]
+        while todo:
+            x, y = todo.pop()
+            for c in ((x + 1, y), (x - 1, y), (x, y + 1), (x, y - 1)):
+                if c in free and c not in seen:
+                    seen.add(c)
+                    todo.append(c)
+        assert tuple(g) in seen
