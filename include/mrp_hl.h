@@ -62,7 +62,8 @@ typedef struct mrp_hl_options {
   int64_t max_ll_expansions;      /* per instance, summed over its searches; < 0 unlimited                        */
   int64_t max_hl_expansions;      /* per instance; < 0 unlimited                                                  */
   int32_t n_threads;              /* host worker threads == instance groups in flight (0 = default)               */
-  int32_t reserved;
+  int32_t mode;                   /* 0 = session (resident kernel, every instance advances on its own; default),   */
+                                  /* 1 = rounds (one launch per round of ready searches; simpler, slower)          */
 } mrp_hl_options;
 
 typedef struct mrp_hl_batch_stats {

@@ -136,6 +136,17 @@ int mrp_ll_search_batch(mrp_ll_ctx* ctx, int32_t n_jobs, const mrp_ll_job* jobs,
 int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t n_jobs, const mrp_ll_job* jobs, mrp_ll_result* results, int32_t* ticket);
 int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket);
 
+/* ---- session mode -------------------------------------------------------------------------------------------
+ * Between mrp_ll_session_begin and mrp_ll_session_end the context keeps `workgroups` wavefronts resident on the GPU
+ * and feeds them through a job ring in pinned host memory: mrp_ll_submit publishes its jobs immediately (no launch,
+ * no stream command) and returns MRP_LL_E_BUSY when the ring has no room for the whole batch (consume finished
+ * tickets, then retry); mrp_ll_poll is the non-blocking form of mrp_ll_wait.  Searches of different tickets finish in
+ * any order, so a caller can keep thousands of independent conflict trees moving without waiting for the slowest
+ * search of a batch.  Results are identical to the batch mode's. */
+int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups /* 0 = mrp_ll_options.slots */);
+int mrp_ll_session_end(mrp_ll_ctx* ctx);
+int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* done);
+
 int mrp_ll_get_stats(const mrp_ll_ctx* ctx, mrp_ll_stats* out);
 int mrp_ll_reset_stats(mrp_ll_ctx* ctx);
 

@@ -170,6 +170,190 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
   }
 }
 
+// Session mode: the engine keeps `workgroups` wavefronts resident (mrp_ll_session_begin) and every instance submits
+// its next searches the moment its previous ones have finished — no instance ever waits for another one's search.
+void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance* instIn, mrp_hl_solution* sols,
+                     const std::vector<int32_t>& idx, const std::vector<int32_t>& mapIds, int32_t horizon,
+                     int32_t workgroups, GroupResult& out) {
+  const size_t n = idx.size();
+  struct Live {
+    std::unique_ptr<Instance> inst;
+    std::vector<LLRequest> req;
+    std::vector<LLAnswer> ans;
+    std::vector<mrp_ll_result> res;
+    std::vector<int32_t> states;
+    int32_t ticket = -1;
+    bool waitingToSubmit = false;
+  };
+  std::vector<Live> live(n);
+  const int32_t cap = horizon;
+  std::vector<mrp_ll_job> jobs;
+  std::vector<int32_t> pathLenPool;
+  std::vector<const int32_t*> pathPtrPool;
+  std::vector<size_t> poolOff;
+
+  if (mrp_ll_session_begin(ctx, workgroups) != MRP_LL_SUCCESS) {
+    out.err = std::string("mrp_ll_session_begin: ") + mrp_ll_last_error(ctx);
+    return;
+  }
+  // returns 1 submitted, 0 ring full (retry later), -1 error
+  auto trySubmit = [&](Live& L) -> int {
+    const Instance& I = *L.inst;
+    jobs.clear();
+    pathLenPool.clear();
+    pathPtrPool.clear();
+    poolOff.clear();
+    for (const LLRequest& r : L.req) {
+      mrp_ll_job j;
+      std::memset(&j, 0, sizeof(j));
+      j.map_id = I.mapId();
+      j.algo = I.algo() == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR;
+      j.w = I.w();
+      j.agent_idx = r.agent;
+      j.start_x = I.start(r.agent)[0];
+      j.start_y = I.start(r.agent)[1];
+      j.goal_x = I.goal(r.agent)[0];
+      j.goal_y = I.goal(r.agent)[1];
+      j.n_vertex_constraints = static_cast<int32_t>(r.constraints->vertex.size() / 3);
+      j.vertex_constraints = r.constraints->vertex.data();
+      j.n_edge_constraints = static_cast<int32_t>(r.constraints->edge.size() / 5);
+      j.edge_constraints = r.constraints->edge.data();
+      j.max_expansions = I.remainingLL();
+      poolOff.push_back(pathLenPool.size());
+      if (r.context) {
+        j.n_agents = static_cast<int32_t>(r.context->size());
+        for (const PathPtr& p : *r.context) {
+          pathLenPool.push_back(p->len());
+          pathPtrPool.push_back(p->xy.data());
+        }
+      }
+      jobs.push_back(j);
+    }
+    for (size_t q = 0; q < jobs.size(); ++q)
+      if (jobs[q].n_agents > 0) {
+        jobs[q].path_len = pathLenPool.data() + poolOff[q];
+        jobs[q].path_xy = pathPtrPool.data() + poolOff[q];
+      }
+    L.res.assign(jobs.size(), mrp_ll_result());
+    L.states.resize(jobs.size() * static_cast<size_t>(cap) * 3);
+    for (size_t q = 0; q < jobs.size(); ++q) {
+      std::memset(&L.res[q], 0, sizeof(mrp_ll_result));
+      L.res[q].states_txy = L.states.data() + q * static_cast<size_t>(cap) * 3;
+      L.res[q].states_cap = cap;
+    }
+    int rc = mrp_ll_submit(ctx, static_cast<int32_t>(jobs.size()), jobs.data(), L.res.data(), &L.ticket);
+    if (rc == MRP_LL_E_BUSY) return 0;
+    if (rc != MRP_LL_SUCCESS) {
+      out.err = std::string("mrp_ll_submit: ") + mrp_ll_last_error(ctx);
+      return -1;
+    }
+    out.rounds += 1;
+    out.searches += static_cast<int64_t>(jobs.size());
+    return 1;
+  };
+
+  std::vector<size_t> inflight, backlog;
+  for (size_t k = 0; k < n; ++k) {
+    live[k].inst.reset(new Instance(instIn[idx[k]], mapIds[k], opt));
+    live[k].inst->advance(live[k].ans, live[k].req);
+    if (!live[k].req.empty()) backlog.push_back(k);
+  }
+  bool failed = false;
+  auto t0 = std::chrono::steady_clock::now();
+  uint64_t idleSpins = 0;
+  while (!failed && (!inflight.empty() || !backlog.empty())) {
+    bool progress = false;
+    // publish as many waiting instances as the ring takes
+    while (!backlog.empty()) {
+      size_t k = backlog.back();
+      int r = trySubmit(live[k]);
+      if (r < 0) {
+        failed = true;
+        break;
+      }
+      if (r == 0) break;
+      backlog.pop_back();
+      inflight.push_back(k);
+      progress = true;
+    }
+    if (failed) break;
+    // harvest
+    for (size_t q = 0; q < inflight.size();) {
+      Live& L = live[inflight[q]];
+      int32_t done = 0;
+      if (mrp_ll_poll(ctx, L.ticket, &done) != MRP_LL_SUCCESS) {
+        out.err = std::string("mrp_ll_poll: ") + mrp_ll_last_error(ctx);
+        failed = true;
+        break;
+      }
+      if (!done) {
+        ++q;
+        continue;
+      }
+      progress = true;
+      L.ans.clear();
+      for (const mrp_ll_result& r : L.res) {
+        LLAnswer a;
+        a.status = r.status;
+        a.cost = r.cost;
+        a.fmin = r.fmin;
+        a.expanded = r.expanded;
+        out.expansions += r.expanded;
+        if (r.status == MRP_LL_OK) {
+          auto p = std::make_shared<Path>();
+          p->xy.resize(static_cast<size_t>(r.n_states) * 2);
+          for (int32_t s = 0; s < r.n_states; ++s) {
+            p->xy[2 * s] = r.states_txy[3 * s + 1];
+            p->xy[2 * s + 1] = r.states_txy[3 * s + 2];
+          }
+          p->cost = r.cost;
+          p->fmin = r.fmin;
+          a.path = p;
+        }
+        L.ans.push_back(a);
+      }
+      L.inst->advance(L.ans, L.req);
+      size_t k = inflight[q];
+      inflight[q] = inflight.back();
+      inflight.pop_back();
+      if (!L.req.empty()) backlog.push_back(k);
+    }
+    if (progress) {
+      idleSpins = 0;
+    } else if ((++idleSpins & 0xFFFFF) == 0) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 600.0) {
+        out.err = "session: no progress for too long";
+        failed = true;
+      }
+    }
+  }
+  if (mrp_ll_session_end(ctx) != MRP_LL_SUCCESS && out.err.empty())
+    out.err = std::string("mrp_ll_session_end: ") + mrp_ll_last_error(ctx);
+  if (failed) return;
+  for (size_t k = 0; k < n; ++k) {
+    const Instance& I = *live[k].inst;
+    mrp_hl_solution& s = sols[idx[k]];
+    s.status = I.status();
+    s.n_ll_searches = I.llSearches();
+    s.high_level_expanded = I.hlExpanded();
+    s.low_level_expanded = I.llExpanded();
+    s.cost = 0;
+    s.makespan = 0;
+    if (I.status() == MRP_HL_SOLVED) {
+      const auto& sol = I.finalSolution();
+      for (int32_t a = 0; a < I.nAgents(); ++a) {
+        s.cost += sol[a]->cost;
+        s.makespan = std::max<int64_t>(s.makespan, sol[a]->cost);
+        if (s.path_len) s.path_len[a] = sol[a]->len();
+        if (s.paths_xy) {
+          int32_t m = std::min(sol[a]->len(), s.path_cap);
+          std::memcpy(s.paths_xy + static_cast<size_t>(a) * s.path_cap * 2, sol[a]->xy.data(), sizeof(int32_t) * 2 * m);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -257,11 +441,18 @@ int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* optIn, int32_t n
       mapIds[t].push_back(mid);
     }
   std::vector<GroupResult> gr(nThreads);
+  // resident wavefronts per engine: the chip holds about 256 CUs x 4 workgroups of this kernel at once
+  const int32_t sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, 1024 / nThreads));
   auto t0 = std::chrono::steady_clock::now();
   {
     std::vector<std::thread> th;
     for (int32_t t = 0; t < nThreads; ++t)
-      th.emplace_back([&, t]() { runGroup(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, gr[t]); });
+      th.emplace_back([&, t]() {
+        if (opt.mode == 1)
+          runGroup(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, gr[t]);
+        else
+          runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, gr[t]);
+      });
     for (auto& x : th) x.join();
   }
   auto t1 = std::chrono::steady_clock::now();

@@ -79,6 +79,13 @@ struct LaunchParams {
   uint32_t lds_rows;          // bitmap rows held in LDS
   uint32_t lds_row_words;     // words per row the LDS layout was sized for
   volatile uint32_t* debug;   // host-mapped trace words (MRP_LL_DEBUG only; nullptr otherwise)
+  // ---- session mode (mrp_ll_persistent_kernel): host-fed job ring in coherent pinned host memory ----
+  uint32_t* ring_state;       // [ring_size] host writes generation g when slot holds the job of ticket (g-1)*ring_size+slot
+  uint32_t* ring_done;        // [ring_size] device writes g when that job's result is in results[slot]
+  uint32_t* ring_stop;        // host sets != 0 to end the session
+  uint32_t* ring_head;        // host: number of tickets published so far (what waiting workgroups poll)
+  uint32_t ring_size;
+  uint32_t ring_idle_limit_s; // a workgroup that waited this long for a job exits (safety net if the host died)
 };
 
 }  // namespace mrp

@@ -617,7 +617,44 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   res.nodes_created = s.nNodes;
 }
 
-// One workgroup == one wavefront; persistent over the batch's job queue (exit: queue exhausted).
+// Runs the job whose descriptor is at `jobSrc` (host memory) and writes result + path to host memory.
+DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* resDst, uint16_t* pathDst, uint8_t* smem,
+                     uint8_t* arenaSlot, DevJob& jobS, DevResult& resS) {
+  const uint32_t lane = threadIdx.x;
+  __syncthreads();
+  {  // one coalesced read of the 80-byte descriptor from host memory
+    const uint32_t* src = (const uint32_t*)jobSrc;
+    if (lane < sizeof(DevJob) / 4) ((uint32_t*)&jobS)[lane] = src[lane];
+  }
+  __syncthreads();
+  const DevJob& J = jobS;
+  DevResult res;
+  res.status = ST_BAD; res.cost = 0; res.fmin = 0; res.n_states = 0; res.expanded = 0; res.nodes_created = 0;
+  res.tier = 0;
+  for (int q = 0; q < 8; ++q) res.prof[q] = 0;
+  PROF_T0();
+  uint16_t* outPath = (uint16_t*)(arenaSlot + P.arena_scratch_off);  // device scratch; copied out below
+  const uint32_t algo = rfl(J.algo);
+  if (algo == 1)
+    runJob<true>(P, J, smem, arenaSlot, res, outPath);
+  else
+    runJob<false>(P, J, smem, arenaSlot, res, outPath);
+  PROF_ADD(res, 5);
+  DBG(P, 2, res.status + 100);
+  // result + path back to host memory with lane-parallel stores
+  __syncthreads();
+  resS = res;
+  __syncthreads();
+  if (lane < sizeof(DevResult) / 4) ((uint32_t*)resDst)[lane] = ((const uint32_t*)&resS)[lane];
+  if (res.status == ST_OK) {
+    const uint32_t words = ((uint32_t)res.n_states + 1) / 2;
+    const uint32_t* src = (const uint32_t*)outPath;
+    uint32_t* dst = (uint32_t*)pathDst;
+    for (uint32_t i = lane; i < words; i += 64) dst[i] = src[i];
+  }
+}
+
+// Batch mode.  One workgroup == one wavefront; pulls jobs from the batch's queue (exit: queue exhausted).
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ DevJob jobS;
@@ -632,40 +669,54 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchPara
     j = rfl(j) - P.queue_base;
     DBG(P, 1, j + 1);
     if (j >= P.n_jobs) break;
-    __syncthreads();
-    {  // one coalesced read of the 80-byte descriptor from host memory
-      const uint32_t* src = (const uint32_t*)(P.jobs + j);
-      if (lane < sizeof(DevJob) / 4) ((uint32_t*)&jobS)[lane] = src[lane];
-    }
-    __syncthreads();
-    const DevJob& J = jobS;
-    DevResult res;
-    res.status = ST_BAD; res.cost = 0; res.fmin = 0; res.n_states = 0; res.expanded = 0; res.nodes_created = 0;
-    res.tier = 0;
-    for (int q = 0; q < 8; ++q) res.prof[q] = 0;
-    PROF_T0();
-    uint16_t* outPath = (uint16_t*)(arenaSlot + P.arena_scratch_off);  // device scratch; copied out below
-    const uint32_t algo = rfl(J.algo);
-    if (algo == 1)
-      runJob<true>(P, J, smem, arenaSlot, res, outPath);
-    else
-      runJob<false>(P, J, smem, arenaSlot, res, outPath);
-    PROF_ADD(res, 5);
-    DBG(P, 2, res.status + 100);
-    // result + path back to host memory with lane-parallel stores
-    __syncthreads();
-    resS = res;
-    __syncthreads();
-    if (lane < sizeof(DevResult) / 4) ((uint32_t*)(P.results + j))[lane] = ((const uint32_t*)&resS)[lane];
-    if (res.status == ST_OK) {
-      const uint32_t words = ((uint32_t)res.n_states + 1) / 2;
-      const uint32_t* src = (const uint32_t*)outPath;
-      uint32_t* dst = (uint32_t*)(P.out_paths + (size_t)j * P.out_stride);
-      for (uint32_t i = lane; i < words; i += 64) dst[i] = src[i];
-    }
+    processJob(P, P.jobs + j, P.results + j, P.out_paths + (size_t)j * P.out_stride, smem, arenaSlot, jobS, resS);
     DBG(P, 3, j + 1);
   }
   DBG(P, 4, 1);
+}
+
+// Session mode.  The same workgroups stay resident for a whole solve and are fed through a ring in coherent pinned
+// host memory: workgroup takes ticket t (device atomic), waits until the host has published generation t/R+1 in
+// ring_state[t%R], runs the job, writes the result to host memory and publishes the generation in ring_done.
+// Exit conditions every wave reaches: *ring_stop != 0, or no job for ring_idle_limit_s seconds.
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(LaunchParams P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ DevJob jobS;
+  __shared__ DevResult resS;
+  const uint32_t lane = threadIdx.x;
+  uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
+  const uint64_t idleLimit = (uint64_t)P.ring_idle_limit_s * 100000000ull;  // s_memrealtime ticks at 100 MHz
+  for (;;) {
+    uint32_t t = atomicAdd(P.queue_head, lane == 0 ? 1u : 0u);
+    t = rfl(t);
+    const uint32_t slot = t % P.ring_size;
+    const uint32_t gen = t / P.ring_size + 1;
+    bool stop = false;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      // Waiting workgroups poll ONE host word (the published-ticket count) and back off in proportion to how far
+      // ahead of it their ticket is: the next in line looks every ~2 us, the k-th every ~2k us (<= ~100 us), so a
+      // thousand idle wavefronts do not saturate PCIe with reads.
+      const uint32_t hd = rfl(__hip_atomic_load(P.ring_head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+      if ((int32_t)(hd - t) > 0) {
+        const uint32_t st = rfl(__hip_atomic_load(P.ring_state + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (st == gen) break;
+      }
+      const uint32_t sp = rfl(__hip_atomic_load(P.ring_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      if (sp != 0 || __builtin_amdgcn_s_memrealtime() - t0 > idleLimit) {
+        stop = true;
+        break;
+      }
+      uint32_t naps = (int32_t)(t - hd) > 0 ? 1 + (t - hd) : 1;
+      if (naps > 48) naps = 48;
+      for (uint32_t q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(64);
+    }
+    if (stop) break;
+    processJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, smem, arenaSlot, jobS,
+               resS);
+    __threadfence_system();
+    __hip_atomic_store(P.ring_done + slot, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 }  // namespace mrp
@@ -684,5 +735,18 @@ extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, u
     attrSet = true;
   }
   hipLaunchKernelGGL(mrp::mrp_ll_search_kernel, dim3(grid), dim3(64), ldsBytes, stream, *P);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mrp_ll_launch_persistent(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes,
+                                               hipStream_t stream) {
+  static bool attrSet = false;
+  if (!attrSet) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mrp::mrp_ll_persistent_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    if (e != hipSuccess) return e;
+    attrSet = true;
+  }
+  hipLaunchKernelGGL(mrp::mrp_ll_persistent_kernel, dim3(grid), dim3(64), ldsBytes, stream, *P);
   return hipGetLastError();
 }

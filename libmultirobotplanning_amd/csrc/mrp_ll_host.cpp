@@ -16,6 +16,8 @@
 
 extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes);
 extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t mrp_ll_launch_persistent(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes,
+                                               hipStream_t stream);
 
 namespace {
 
@@ -91,6 +93,33 @@ struct Ticket {
   std::vector<uint8_t> rejected;  // per job: rejected on the host (MRP_LL_BAD_JOB)
 };
 
+// ---- session mode: job ring in coherent pinned host memory --------------------------------------------------
+struct Ring {
+  static constexpr uint32_t kSlots = 2048;
+  static constexpr uint32_t kSlotConsWords = 1024;        // 4 KB of constraint words per job
+  static constexpr uint32_t kSlotPathHalfs = 16 * 1024;   // 32 KB path table per job
+  uint8_t* block = nullptr;        // one coherent allocation holding everything below
+  uint32_t *state = nullptr, *done = nullptr, *stop = nullptr, *headWord = nullptr;
+  DevJob* jobs = nullptr;
+  DevResult* results = nullptr;
+  uint16_t* outPaths = nullptr;
+  uint32_t* cons = nullptr;
+  uint16_t* paths = nullptr;
+  uint32_t outStride = 0;
+  uint64_t head = 0;               // next ticket number to publish
+  std::vector<uint8_t> busy;       // slot holds a job whose result the host has not consumed yet
+  bool active = false;
+  uint32_t grid = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+struct SessTicket {
+  bool used = false;
+  uint64_t first = 0;
+  int32_t n = 0, remaining = 0;
+  mrp_ll_result* res = nullptr;
+  std::vector<uint8_t> state;      // per job: 0 pending, 1 consumed, 2 rejected on the host
+};
+
 }  // namespace
 
 struct mrp_ll_ctx {
@@ -103,6 +132,7 @@ struct mrp_ll_ctx {
   size_t mapsDevCap = 0;
   bool mapsDirty = false;
   uint32_t maxWpr = 1;
+  uint32_t sessionRowWords = 0;   // LDS bitmap row width the resident kernel was launched with
   uint32_t arenaRowWords = 0;
   uint64_t arenaStride = 0;
   uint32_t arenaScratchOff = 0;
@@ -110,6 +140,8 @@ struct mrp_ll_ctx {
   std::vector<Ticket> tickets;
   mrp_ll_stats stats;
   uint32_t* debugHost = nullptr;  // MRP_LL_DEBUG: host-mapped trace buffer
+  Ring ring;
+  std::vector<SessTicket> sess;
 };
 
 namespace {
@@ -151,7 +183,7 @@ int syncMaps(mrp_ll_ctx* ctx) {
     for (auto& t : ctx->tickets)
       if (t.inFlight) HIPCHK(ctx, hipEventSynchronize(t.evK1));
     if (ctx->mapsDev) HIPCHK(ctx, hipFree(ctx->mapsDev));
-    size_t ncap = std::max<size_t>(need * 2, 4096);
+    size_t ncap = std::max<size_t>(need * 2, 1u << 20);  // >= 4 MB: room for in-session uploads
     HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mapsDev), ncap * sizeof(uint32_t)));
     ctx->mapsDevCap = ncap;
   }
@@ -161,8 +193,58 @@ int syncMaps(mrp_ll_ctx* ctx) {
   return MRP_LL_SUCCESS;
 }
 
+// Where a packed job's constraint words / path table go: a growable batch buffer or a fixed ring-slot area.
+struct ConsSinkBuf {
+  PinnedBuf<uint32_t>& b;
+  bool failed = false;
+  size_t size() const { return b.size; }
+  void push(uint32_t w) {
+    if (b.push(w) != hipSuccess) failed = true;
+  }
+};
+struct PathSinkBuf {
+  PinnedBuf<uint16_t>& b;
+  bool failed = false;
+  uint16_t* alloc(size_t n, uint32_t& off) {
+    size_t base = (b.size + 7u) & ~size_t(7);  // 16-byte aligned table start
+    if (b.resize(base + n) != hipSuccess) {
+      failed = true;
+      return nullptr;
+    }
+    off = static_cast<uint32_t>(base);
+    return b.host + base;
+  }
+};
+struct ConsSinkSlot {
+  uint32_t* area;
+  uint32_t baseOff, cap, used = 0;
+  bool failed = false;
+  size_t size() const { return baseOff + used; }
+  void push(uint32_t w) {
+    if (used >= cap) {
+      failed = true;
+      return;
+    }
+    area[used++] = w;
+  }
+};
+struct PathSinkSlot {
+  uint16_t* area;
+  uint32_t baseOff, cap;
+  bool failed = false;
+  uint16_t* alloc(size_t n, uint32_t& off) {
+    if (n > cap) {
+      failed = true;
+      return nullptr;
+    }
+    off = baseOff;
+    return area;
+  }
+};
+
 // Pack one job; returns false if the job is rejected (MRP_LL_BAD_JOB).
-bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, Ticket& t, DevJob& d) {
+template <class ConsSink, class PathSink>
+bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, DevJob& d) {
   if (j.map_id < 0 || j.map_id >= static_cast<int32_t>(ctx->maps.size())) return false;
   const MapRec& mp = ctx->maps[j.map_id];
   if (j.algo != MRP_LL_ASTAR && j.algo != MRP_LL_ASTAR_EPS) return false;
@@ -189,26 +271,25 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, Ticket& t, DevJob& d) {
   d.max_expansions = j.max_expansions;
   // setLowLevelContext (ecbs.cpp:264-274): last vertex constraint on the goal cell
   int lastGoal = -1;
-  d.vc_off = static_cast<uint32_t>(t.cons.size);
+  d.vc_off = static_cast<uint32_t>(cs.size());
   for (int i = 0; i < j.n_vertex_constraints; ++i) {
     const int32_t* v = j.vertex_constraints + 3 * i;
     if (v[1] == j.goal_x && v[2] == j.goal_y) lastGoal = std::max(lastGoal, v[0]);
     if (v[0] < 0 || v[0] >= horizon || !inGrid(v[1], v[2])) continue;  // can never match a generated state
-    if (t.cons.push((static_cast<uint32_t>(v[0]) << 16) | static_cast<uint32_t>(v[2] * mp.dimx + v[1])) != hipSuccess)
-      t.allocFailed = true;
+    cs.push((static_cast<uint32_t>(v[0]) << 16) | static_cast<uint32_t>(v[2] * mp.dimx + v[1]));
   }
-  d.n_vc = static_cast<uint32_t>(t.cons.size) - d.vc_off;
+  d.n_vc = static_cast<uint32_t>(cs.size()) - d.vc_off;
   d.last_goal_constraint = lastGoal;
-  d.ec_off = static_cast<uint32_t>(t.cons.size);
+  d.ec_off = static_cast<uint32_t>(cs.size());
   for (int i = 0; i < j.n_edge_constraints; ++i) {
     const int32_t* e = j.edge_constraints + 5 * i;
     int k = neighborIndexFromDelta(e[3] - e[1], e[4] - e[2]);
     if (k < 0 || e[0] < 0 || e[0] >= horizon || !inGrid(e[1], e[2])) continue;
-    if (t.cons.push((static_cast<uint32_t>(e[0]) << 19) | (static_cast<uint32_t>(e[2] * mp.dimx + e[1]) << 3) |
-                    static_cast<uint32_t>(k)) != hipSuccess)
-      t.allocFailed = true;
+    cs.push((static_cast<uint32_t>(e[0]) << 19) | (static_cast<uint32_t>(e[2] * mp.dimx + e[1]) << 3) |
+            static_cast<uint32_t>(k));
   }
-  d.n_ec = static_cast<uint32_t>(t.cons.size) - d.ec_off;
+  d.n_ec = static_cast<uint32_t>(cs.size()) - d.ec_off;
+  if (cs.failed) return false;
   // focal context: time-major table of the other agents' cells, each path extended by its last cell
   d.n_agents_pad = 0;
   d.t_pad = 0;
@@ -223,16 +304,12 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, Ticket& t, DevJob& d) {
       }
     if (tpad > 0) {
       uint32_t npad = (static_cast<uint32_t>(j.n_agents) + 15u) & ~15u;
-      // 16-byte align the table start
-      size_t base = (t.paths.size + 7u) & ~size_t(7);
-      if (t.paths.resize(base + static_cast<size_t>(tpad) * npad) != hipSuccess) {
-        t.allocFailed = true;
-        return false;
-      }
-      d.path_off = static_cast<uint32_t>(base);
+      uint32_t off = 0;
+      uint16_t* tab = ps.alloc(static_cast<size_t>(tpad) * npad, off);
+      if (!tab) return false;
+      d.path_off = off;
       d.n_agents_pad = npad;
       d.t_pad = static_cast<uint32_t>(tpad);
-      uint16_t* tab = t.paths.host + base;
       const uint16_t none = static_cast<uint16_t>(mrp::kEmptyCell);
       for (size_t q = 0; q < static_cast<size_t>(tpad) * npad; ++q) tab[q] = none;
       for (int a = 0; a < j.n_agents; ++a) {
@@ -251,6 +328,98 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, Ticket& t, DevJob& d) {
     }
   }
   return true;
+}
+
+// Fills the launch parameters that do not depend on where the jobs live; returns the dynamic LDS size.
+int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t& ldsBytesOut) {
+  P.maps = ctx->mapsDev;
+  P.queue_head = t.queueHead;
+  P.arena = t.arena;
+  P.arena_stride = ctx->arenaStride;
+  P.arena_scratch_off = ctx->arenaScratchOff;
+  P.arena_paths_bytes = ctx->arenaPathsBytes;
+  P.out_stride = static_cast<uint32_t>(ctx->opt.max_horizon);
+  P.arena_nodes = static_cast<uint32_t>(ctx->opt.arena_nodes);
+  P.arena_rows = static_cast<uint32_t>(ctx->opt.max_horizon);
+  P.arena_row_words = ctx->arenaRowWords;
+  // LDS tier geometry: rows sized for the widest uploaded map; a workgroup may take up to the CU's whole 160 KiB
+  // (minus the kernel's small static LDS); occupancy is floor(160 KiB / ldsBytes) workgroups per CU
+  uint32_t ldsNodes = static_cast<uint32_t>(ctx->opt.lds_nodes);
+  uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
+  uint32_t rows = 0;
+  uint32_t ldsBytes = 0;
+  const uint32_t ldsPaths = 4096;
+  if (ldsNodes) {
+    const uint32_t budget = 160 * 1024 - 512;
+    uint32_t fixed = mrp_ll_lds_bytes(ldsNodes, 0, rowWords, ldsPaths);
+    if (fixed + 16 * rowWords * 4 <= budget) {
+      rows = std::min<uint32_t>(64, (budget - fixed) / (rowWords * 4));
+      rows = std::min<uint32_t>(rows, static_cast<uint32_t>(ctx->opt.max_horizon));
+      ldsBytes = mrp_ll_lds_bytes(ldsNodes, rows, rowWords, ldsPaths);
+    } else {
+      ldsNodes = 0;
+    }
+  }
+  P.lds_nodes = ldsNodes;
+  P.lds_rows = rows;
+  P.lds_row_words = rowWords;
+  P.lds_paths_bytes = ldsNodes ? ldsPaths : 0;
+  if (kDebug) {
+    if (!ctx->debugHost) {
+      HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->debugHost), 16 * 4 * 4096,
+                                hipHostMallocMapped | hipHostMallocCoherent));
+    }
+    std::memset(ctx->debugHost, 0, 16 * 4 * 4096);
+    void* dptr = nullptr;
+    HIPCHK(ctx, hipHostGetDevicePointer(&dptr, ctx->debugHost, 0));
+    P.debug = static_cast<volatile uint32_t*>(dptr);
+  }
+  ldsBytesOut = ldsBytes;
+  return MRP_LL_SUCCESS;
+}
+
+// Device result -> caller's mrp_ll_result (+ statistics).
+void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool rejected, mrp_ll_result& r) {
+  if (rejected) {
+    r.status = MRP_LL_BAD_JOB;
+    r.cost = r.fmin = r.n_states = 0;
+    r.expanded = 0;
+    r.tier = 0;
+    return;
+  }
+  r.status = d.status;
+  r.cost = d.cost;
+  r.fmin = d.fmin;
+  r.n_states = d.status == mrp::ST_OK ? d.n_states : 0;
+  r.expanded = d.expanded;
+  r.tier = static_cast<int32_t>(d.tier);
+  ctx->stats.jobs += 1;
+  ctx->stats.expansions += d.expanded;
+  ctx->stats.nodes_created += d.nodes_created;
+  ctx->stats.migrated += d.tier ? 1 : 0;
+  for (int q = 0; q < 8; ++q) ctx->stats.prof[q] += d.prof[q];
+  if (d.status == mrp::ST_OK) {
+    int n = d.n_states;
+    int lim = std::min(n, r.states_cap);
+    if (r.states_txy)
+      for (int k = 0; k < lim; ++k) {
+        r.states_txy[3 * k] = k;
+        r.states_txy[3 * k + 1] = p[k] & 0xFF;
+        r.states_txy[3 * k + 2] = p[k] >> 8;
+      }
+    if (r.actions)
+      for (int k = 0; k + 1 < n && k < r.states_cap; ++k)
+        r.actions[k] = actionFromDelta((p[k + 1] & 0xFF) - (p[k] & 0xFF), (p[k + 1] >> 8) - (p[k] >> 8));
+    if ((r.states_txy || r.actions) && r.states_cap < n) r.status = MRP_LL_PATH_TRUNCATED;
+  }
+}
+
+void trivialRejectedJob(mrp_ll_ctx* ctx, DevJob& d) {
+  std::memset(&d, 0, sizeof(d));
+  d.dimx = 1; d.dimy = 1; d.words_per_row = 1;
+  d.map_word_off = ctx->maps.empty() ? 0 : ctx->maps[0].wordOff;
+  d.gx = 0; d.gy = 0; d.algo = 0; d.last_goal_constraint = -1;
+  d.max_expansions = 0;
 }
 
 }  // namespace
@@ -323,6 +492,10 @@ int mrp_ll_create(const mrp_ll_options* optIn, mrp_ll_ctx** out) {
 void mrp_ll_destroy(mrp_ll_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->ring.active) (void)mrp_ll_session_end(ctx);
+  if (ctx->ring.ev0) (void)hipEventDestroy(ctx->ring.ev0);
+  if (ctx->ring.ev1) (void)hipEventDestroy(ctx->ring.ev1);
+  if (ctx->ring.block) (void)hipHostFree(ctx->ring.block);
   for (auto& t : ctx->tickets) {
     if (t.inFlight && t.evK1) (void)hipEventSynchronize(t.evK1);
     if (t.stream) (void)hipStreamSynchronize(t.stream);
@@ -369,13 +542,231 @@ int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t nObst
   }
   ctx->maps.push_back(m);
   ctx->maxWpr = std::max(ctx->maxWpr, m.wpr);
-  ctx->mapsDirty = true;
+  if (ctx->ring.active) {
+    // a resident kernel is reading the maps buffer: it may be appended to, but neither moved nor re-laid-out
+    // (a map wider than the session's LDS rows is served from the HBM tier until the next session)
+    if (ctx->mapWords.size() > ctx->mapsDevCap) {
+      ctx->maps.pop_back();
+      ctx->mapWords.resize(m.wordOff);
+      ctx->err = "mrp_ll_upload_map: no room in the device map buffer during a session (upload maps before "
+                 "mrp_ll_session_begin, or end the session first)";
+      return MRP_LL_E_BUSY;
+    }
+    HIPCHK(ctx, hipMemcpy(ctx->mapsDev + m.wordOff, ctx->mapWords.data() + m.wordOff, m.wpr * sizeof(uint32_t),
+                          hipMemcpyHostToDevice));
+  } else {
+    ctx->mapsDirty = true;
+  }
   *mapId = static_cast<int32_t>(ctx->maps.size()) - 1;
   return MRP_LL_SUCCESS;
 }
 
+
+// ---- session mode ---------------------------------------------------------------------------------------------
+int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
+  if (!ctx) return MRP_LL_E_INVALID;
+  Ring& g = ctx->ring;
+  if (g.active) return MRP_LL_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Ticket& t = ctx->tickets[0];
+  if (t.inFlight) {
+    ctx->err = "mrp_ll_session_begin: a batch is still in flight";
+    return MRP_LL_E_BUSY;
+  }
+  int rc = syncMaps(ctx);
+  if (rc != MRP_LL_SUCCESS) return rc;
+  const uint32_t R = Ring::kSlots;
+  g.outStride = static_cast<uint32_t>(ctx->opt.max_horizon);
+  if (!g.block) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+      size_t o = off;
+      off += (bytes + 255) & ~size_t(255);
+      return o;
+    };
+    size_t oState = take(R * 4), oDone = take(R * 4), oStop = take(256), oHead = take(256), oJobs = take(R * sizeof(DevJob)),
+           oRes = take(R * sizeof(DevResult)), oOut = take(static_cast<size_t>(R) * g.outStride * 2),
+           oCons = take(static_cast<size_t>(R) * Ring::kSlotConsWords * 4),
+           oPaths = take(static_cast<size_t>(R) * Ring::kSlotPathHalfs * 2);
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&g.block), off, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(g.block, 0, off);
+    g.state = reinterpret_cast<uint32_t*>(g.block + oState);
+    g.done = reinterpret_cast<uint32_t*>(g.block + oDone);
+    g.stop = reinterpret_cast<uint32_t*>(g.block + oStop);
+    g.headWord = reinterpret_cast<uint32_t*>(g.block + oHead);
+    g.jobs = reinterpret_cast<DevJob*>(g.block + oJobs);
+    g.results = reinterpret_cast<DevResult*>(g.block + oRes);
+    g.outPaths = reinterpret_cast<uint16_t*>(g.block + oOut);
+    g.cons = reinterpret_cast<uint32_t*>(g.block + oCons);
+    g.paths = reinterpret_cast<uint16_t*>(g.block + oPaths);
+    HIPCHK(ctx, hipEventCreate(&g.ev0));
+    HIPCHK(ctx, hipEventCreate(&g.ev1));
+  }
+  std::memset(g.state, 0, R * 4);
+  std::memset(g.done, 0, R * 4);
+  __atomic_store_n(g.stop, 0u, __ATOMIC_RELEASE);
+  __atomic_store_n(g.headWord, 0u, __ATOMIC_RELEASE);
+  g.head = 0;
+  g.busy.assign(R, 0);
+  ctx->sess.clear();
+  auto devPtr = [&](void* hostPtr) {
+    void* d = nullptr;
+    (void)hipHostGetDevicePointer(&d, hostPtr, 0);
+    return d;
+  };
+  mrp::LaunchParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.jobs = static_cast<const DevJob*>(devPtr(g.jobs));
+  P.results = static_cast<DevResult*>(devPtr(g.results));
+  P.out_paths = static_cast<uint16_t*>(devPtr(g.outPaths));
+  P.cons = static_cast<const uint32_t*>(devPtr(g.cons));
+  P.paths = static_cast<const uint16_t*>(devPtr(g.paths));
+  P.ring_state = static_cast<uint32_t*>(devPtr(g.state));
+  P.ring_done = static_cast<uint32_t*>(devPtr(g.done));
+  P.ring_stop = static_cast<uint32_t*>(devPtr(g.stop));
+  P.ring_head = static_cast<uint32_t*>(devPtr(g.headWord));
+  P.ring_size = R;
+  P.ring_idle_limit_s = 20;
+  uint32_t ldsBytes = 0;
+  rc = fillCommonParams(ctx, t, P, ldsBytes);
+  if (rc != MRP_LL_SUCCESS) return rc;
+  ctx->sessionRowWords = P.lds_row_words;
+  g.grid = static_cast<uint32_t>(workgroups > 0 ? std::min(workgroups, ctx->opt.slots) : ctx->opt.slots);
+  HIPCHK(ctx, hipMemsetAsync(t.queueHead, 0, 4, t.stream));  // session tickets count from 0
+  t.queueBase = 0;
+  HIPCHK(ctx, hipEventRecord(g.ev0, t.stream));
+  HIPCHK(ctx, mrp_ll_launch_persistent(&P, g.grid, ldsBytes, t.stream));
+  HIPCHK(ctx, hipEventRecord(g.ev1, t.stream));
+  g.active = true;
+  ctx->stats.launches += 1;
+  return MRP_LL_SUCCESS;
+}
+
+int mrp_ll_session_end(mrp_ll_ctx* ctx) {
+  if (!ctx) return MRP_LL_E_INVALID;
+  Ring& g = ctx->ring;
+  if (!g.active) return MRP_LL_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  __atomic_store_n(g.stop, 1u, __ATOMIC_RELEASE);
+  HIPCHK(ctx, hipEventSynchronize(g.ev1));
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) ctx->stats.kernel_ms += ms;
+  g.active = false;
+  // the device counter is past the published tickets: the next batch-mode launch starts from a clean base
+  Ticket& t = ctx->tickets[0];
+  HIPCHK(ctx, hipMemset(t.queueHead, 0, 4));
+  t.queueBase = 0;
+  return MRP_LL_SUCCESS;
+}
+
+static int sessionSubmit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results,
+                         int32_t* ticketOut) {
+  Ring& g = ctx->ring;
+  const uint32_t R = Ring::kSlots;
+  if (nJobs > static_cast<int32_t>(R)) {
+    ctx->err = "mrp_ll_submit (session): batch larger than the ring";
+    return MRP_LL_E_INVALID;
+  }
+  for (int i = 0; i < nJobs; ++i)
+    if (g.busy[(g.head + i) % R]) return MRP_LL_E_BUSY;  // caller must consume finished tickets first
+  auto packT0 = std::chrono::steady_clock::now();
+  int ti = -1;
+  for (size_t i = 0; i < ctx->sess.size(); ++i)
+    if (!ctx->sess[i].used) {
+      ti = static_cast<int>(i);
+      break;
+    }
+  if (ti < 0) {
+    ctx->sess.emplace_back();
+    ti = static_cast<int>(ctx->sess.size()) - 1;
+  }
+  SessTicket& st = ctx->sess[ti];
+  st.used = true;
+  st.first = g.head;
+  st.n = nJobs;
+  st.remaining = nJobs;
+  st.res = results;
+  st.state.assign(nJobs, 0);
+  for (int i = 0; i < nJobs; ++i) {
+    const uint64_t tk = g.head + i;
+    const uint32_t slot = static_cast<uint32_t>(tk % R);
+    const uint32_t gen = static_cast<uint32_t>(tk / R) + 1;
+    ConsSinkSlot cs{g.cons + static_cast<size_t>(slot) * Ring::kSlotConsWords, slot * Ring::kSlotConsWords,
+                    Ring::kSlotConsWords};
+    PathSinkSlot ps{g.paths + static_cast<size_t>(slot) * Ring::kSlotPathHalfs, slot * Ring::kSlotPathHalfs,
+                    Ring::kSlotPathHalfs};
+    DevJob d;
+    if (!packJob(ctx, jobs[i], cs, ps, d)) {  // also: constraint list / path table larger than a ring slot
+      trivialRejectedJob(ctx, d);
+      st.state[i] = 2;
+    }
+    g.jobs[slot] = d;
+    g.busy[slot] = 1;
+    __atomic_store_n(g.state + slot, gen, __ATOMIC_RELEASE);  // publish: the job data above is visible first
+  }
+  g.head += static_cast<uint64_t>(nJobs);
+  __atomic_store_n(g.headWord, static_cast<uint32_t>(g.head), __ATOMIC_RELEASE);  // after every slot's state word
+  ctx->stats.pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - packT0).count();
+  *ticketOut = ti;
+  return MRP_LL_SUCCESS;
+}
+
+int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
+  if (!ctx || !doneOut) return MRP_LL_E_INVALID;
+  Ring& g = ctx->ring;
+  if (!g.active) {  // batch mode: completion of the launch
+    if (ticket < 0 || ticket >= static_cast<int32_t>(ctx->tickets.size()) || !ctx->tickets[ticket].inFlight)
+      return MRP_LL_E_INVALID;
+    if (ctx->tickets[ticket].nJobs > 0 && hipEventQuery(ctx->tickets[ticket].evK1) == hipErrorNotReady) {
+      *doneOut = 0;
+      return MRP_LL_SUCCESS;
+    }
+    *doneOut = 1;
+    return mrp_ll_wait(ctx, ticket);
+  }
+  if (ticket < 0 || ticket >= static_cast<int32_t>(ctx->sess.size()) || !ctx->sess[ticket].used) return MRP_LL_E_INVALID;
+  SessTicket& st = ctx->sess[ticket];
+  const uint32_t R = Ring::kSlots;
+  for (int i = 0; i < st.n && st.remaining > 0; ++i) {
+    if (st.state[i] == 1) continue;
+    const uint64_t tk = st.first + i;
+    const uint32_t slot = static_cast<uint32_t>(tk % R);
+    const uint32_t gen = static_cast<uint32_t>(tk / R) + 1;
+    if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != gen) continue;
+    unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
+                 st.res[i]);
+    st.state[i] = 1;
+    st.remaining -= 1;
+    g.busy[slot] = 0;
+  }
+  *doneOut = st.remaining == 0 ? 1 : 0;
+  if (st.remaining == 0) st.used = false;
+  return MRP_LL_SUCCESS;
+}
+
+static int sessionWait(mrp_ll_ctx* ctx, int32_t ticket) {
+  auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spin = 0;; ++spin) {
+    int32_t done = 0;
+    int rc = mrp_ll_poll(ctx, ticket, &done);
+    if (rc != MRP_LL_SUCCESS) return rc;
+    if (done) return MRP_LL_SUCCESS;
+    if ((spin & 0xFFF) == 0xFFF) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+        ctx->err = "mrp_ll_wait (session): no completion within 120 s";
+        return MRP_LL_E_DEVICE;
+      }
+      if (hipEventQuery(ctx->ring.ev1) != hipErrorNotReady) {
+        ctx->err = "mrp_ll_wait (session): the resident kernel has exited (idle limit or fault)";
+        return MRP_LL_E_DEVICE;
+      }
+    }
+  }
+}
+
 int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results, int32_t* ticketOut) {
   if (!ctx || !ticketOut || nJobs < 0 || (nJobs > 0 && (!jobs || !results))) return MRP_LL_E_INVALID;
+  if (ctx->ring.active) return sessionSubmit(ctx, nJobs, jobs, results, ticketOut);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int ti = -1;
   for (size_t i = 0; i < ctx->tickets.size(); ++i)
@@ -401,17 +792,16 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
   HIPCHK(ctx, t.jobs.resize(std::max(nJobs, 1)));
   for (int i = 0; i < nJobs; ++i) {
     size_t c0 = t.cons.size, p0 = t.paths.size;
-    if (!packJob(ctx, jobs[i], t, t.jobs.host[i])) {
+    ConsSinkBuf cs{t.cons};
+    PathSinkBuf ps{t.paths};
+    bool ok = packJob(ctx, jobs[i], cs, ps, t.jobs.host[i]);
+    if (cs.failed || ps.failed) t.allocFailed = true;
+    if (!ok) {
       // rejected: give the device a trivially capped job and remember the rejection
       t.cons.size = c0;
       t.paths.size = p0;
       t.rejected[i] = 1;
-      DevJob& d = t.jobs.host[i];
-      std::memset(&d, 0, sizeof(d));
-      d.dimx = 1; d.dimy = 1; d.words_per_row = 1;
-      d.map_word_off = ctx->maps.empty() ? 0 : ctx->maps[0].wordOff;
-      d.gx = 0; d.gy = 0; d.algo = 0; d.last_goal_constraint = -1;
-      d.max_expansions = 0;
+      trivialRejectedJob(ctx, t.jobs.host[i]);
     }
   }
   if (t.allocFailed) {
@@ -433,50 +823,14 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
   P.jobs = t.jobs.dev;
   P.results = t.results.dev;
   P.out_paths = t.outPaths.dev;
-  P.maps = ctx->mapsDev;
   P.cons = t.cons.dev;
   P.paths = t.paths.dev;
-  P.queue_head = t.queueHead;
   P.queue_base = t.queueBase;
-  P.arena = t.arena;
-  P.arena_stride = ctx->arenaStride;
-  P.arena_scratch_off = ctx->arenaScratchOff;
-  P.arena_paths_bytes = ctx->arenaPathsBytes;
   P.n_jobs = static_cast<uint32_t>(nJobs);
-  P.out_stride = outStride;
-  P.arena_nodes = static_cast<uint32_t>(ctx->opt.arena_nodes);
-  P.arena_rows = static_cast<uint32_t>(ctx->opt.max_horizon);
-  P.arena_row_words = ctx->arenaRowWords;
-  // LDS tier geometry: rows sized for the widest uploaded map; a workgroup may take up to the CU's whole 160 KiB
-  // (minus the kernel's small static LDS); occupancy is floor(160 KiB / ldsBytes) workgroups per CU
-  uint32_t ldsNodes = static_cast<uint32_t>(ctx->opt.lds_nodes);
-  uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
-  uint32_t rows = 0;
   uint32_t ldsBytes = 0;
-  const uint32_t ldsPaths = 4096;
-  if (ldsNodes) {
-    const uint32_t budget = 160 * 1024 - 512;
-    uint32_t fixed = mrp_ll_lds_bytes(ldsNodes, 0, rowWords, ldsPaths);
-    if (fixed + 16 * rowWords * 4 <= budget) {
-      rows = std::min<uint32_t>(64, (budget - fixed) / (rowWords * 4));
-      rows = std::min<uint32_t>(rows, static_cast<uint32_t>(ctx->opt.max_horizon));
-      ldsBytes = mrp_ll_lds_bytes(ldsNodes, rows, rowWords, ldsPaths);
-    } else {
-      ldsNodes = 0;
-    }
-  }
-  P.lds_nodes = ldsNodes;
-  P.lds_rows = rows;
-  P.lds_row_words = rowWords;
-  P.lds_paths_bytes = ldsNodes ? ldsPaths : 0;
-  if (kDebug) {
-    if (!ctx->debugHost) {
-      HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->debugHost), 16 * 4 * 4096, hipHostMallocMapped | hipHostMallocCoherent));
-    }
-    std::memset(ctx->debugHost, 0, 16 * 4 * 4096);
-    void* dptr = nullptr;
-    HIPCHK(ctx, hipHostGetDevicePointer(&dptr, ctx->debugHost, 0));
-    P.debug = static_cast<volatile uint32_t*>(dptr);
+  {
+    int rcp = fillCommonParams(ctx, t, P, ldsBytes);
+    if (rcp != MRP_LL_SUCCESS) return rcp;
   }
   uint32_t grid = std::min<uint32_t>(static_cast<uint32_t>(nJobs), static_cast<uint32_t>(ctx->opt.slots));
   t.queueBase += static_cast<uint32_t>(nJobs) + grid;  // every workgroup takes one ticket past the end when it exits
@@ -488,6 +842,7 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
 }
 
 int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
+  if (ctx && ctx->ring.active) return sessionWait(ctx, ticket);
   if (!ctx || ticket < 0 || ticket >= static_cast<int32_t>(ctx->tickets.size())) return MRP_LL_E_INVALID;
   Ticket& t = ctx->tickets[ticket];
   if (!t.inFlight) return MRP_LL_E_INVALID;
@@ -516,43 +871,9 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
   if (hipEventElapsedTime(&ms, t.evK0, t.evK1) == hipSuccess) ctx->stats.kernel_ms += ms;
   const uint32_t outStride = static_cast<uint32_t>(ctx->opt.max_horizon);
   auto unpackT0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < t.nJobs; ++i) {
-    mrp_ll_result& r = t.userResults[i];
-    const DevResult& d = t.results.host[i];
-    if (t.rejected[i]) {
-      r.status = MRP_LL_BAD_JOB;
-      r.cost = r.fmin = r.n_states = 0;
-      r.expanded = 0;
-      r.tier = 0;
-      continue;
-    }
-    r.status = d.status;
-    r.cost = d.cost;
-    r.fmin = d.fmin;
-    r.n_states = d.status == mrp::ST_OK ? d.n_states : 0;
-    r.expanded = d.expanded;
-    r.tier = static_cast<int32_t>(d.tier);
-    ctx->stats.jobs += 1;
-    ctx->stats.expansions += d.expanded;
-    ctx->stats.nodes_created += d.nodes_created;
-    ctx->stats.migrated += d.tier ? 1 : 0;
-    for (int q = 0; q < 8; ++q) ctx->stats.prof[q] += d.prof[q];
-    if (d.status == mrp::ST_OK) {
-      const uint16_t* p = t.outPaths.host + static_cast<size_t>(i) * outStride;
-      int n = d.n_states;
-      int lim = std::min(n, r.states_cap);
-      if (r.states_txy)
-        for (int k = 0; k < lim; ++k) {
-          r.states_txy[3 * k] = k;
-          r.states_txy[3 * k + 1] = p[k] & 0xFF;
-          r.states_txy[3 * k + 2] = p[k] >> 8;
-        }
-      if (r.actions)
-        for (int k = 0; k + 1 < n && k < r.states_cap; ++k)
-          r.actions[k] = actionFromDelta((p[k + 1] & 0xFF) - (p[k] & 0xFF), (p[k + 1] >> 8) - (p[k] >> 8));
-      if ((r.states_txy || r.actions) && r.states_cap < n) r.status = MRP_LL_PATH_TRUNCATED;
-    }
-  }
+  for (int i = 0; i < t.nJobs; ++i)
+    unpackResult(ctx, t.results.host[i], t.outPaths.host + static_cast<size_t>(i) * outStride, t.rejected[i] != 0,
+                 t.userResults[i]);
   ctx->stats.unpack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - unpackT0).count();
   return MRP_LL_SUCCESS;
 }

@@ -34,7 +34,7 @@ class mrp_hl_solution(ctypes.Structure):
 
 class mrp_hl_options(ctypes.Structure):
     _fields_ = [("algo", ctypes.c_int32), ("w", ctypes.c_float), ("max_ll_expansions", ctypes.c_int64),
-                ("max_hl_expansions", ctypes.c_int64), ("n_threads", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("max_hl_expansions", ctypes.c_int64), ("n_threads", ctypes.c_int32), ("mode", ctypes.c_int32)]
 
 
 class mrp_hl_batch_stats(ctypes.Structure):
@@ -122,7 +122,8 @@ class BatchSolver:
             pass
 
     def solve(self, instances: Sequence[Dict], algo: int = ECBS, w: float = 1.3, max_ll_expansions: int = -1,
-              max_hl_expansions: int = -1, n_threads: int = 0, want_paths: bool = True, path_cap: int = 512):
+              max_hl_expansions: int = -1, n_threads: int = 0, want_paths: bool = True, path_cap: int = 512,
+              mode: int = 0):
         n = len(instances)
         cin = (mrp_hl_instance * max(n, 1))()
         csol = (mrp_hl_solution * max(n, 1))()
@@ -146,7 +147,7 @@ class BatchSolver:
                 csol[i].path_len = a.ctypes.data_as(I32P)
                 csol[i].paths_xy = b.ctypes.data_as(I32P)
                 csol[i].path_cap = path_cap
-        opt = mrp_hl_options(algo, w, max_ll_expansions, max_hl_expansions, n_threads, 0)
+        opt = mrp_hl_options(algo, w, max_ll_expansions, max_hl_expansions, n_threads, mode)
         st = mrp_hl_batch_stats()
         rc = self._lib.mrp_hl_solver_solve(self._h, ctypes.byref(opt), n, cin, csol, ctypes.byref(st))
         if rc != 0:

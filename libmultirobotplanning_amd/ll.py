@@ -52,7 +52,8 @@ class mrp_ll_stats(ctypes.Structure):
 
 
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
-           "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version"]
+           "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version",
+           "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll"]
 
 _lib = None
 
@@ -89,6 +90,12 @@ def load_library(path: Optional[str] = None):
     lib.mrp_ll_reset_stats.argtypes = [ctypes.c_void_p]
     lib.mrp_ll_version.restype = ctypes.c_char_p
     lib.mrp_ll_version.argtypes = []
+    lib.mrp_ll_session_begin.restype = ctypes.c_int
+    lib.mrp_ll_session_begin.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.mrp_ll_session_end.restype = ctypes.c_int
+    lib.mrp_ll_session_end.argtypes = [ctypes.c_void_p]
+    lib.mrp_ll_poll.restype = ctypes.c_int
+    lib.mrp_ll_poll.argtypes = [ctypes.c_void_p, ctypes.c_int32, I32P]
     if path is None:
         _lib = lib
     return lib
@@ -193,6 +200,13 @@ class LowLevelEngine:
                                 expanded=r.expanded, states=states[i, :m].tolist(),
                                 actions=actions[i, :max(m - 1, 0)].tolist(), tier=r.tier))
         return out
+
+    def session_begin(self, workgroups: int = 0):
+        """Keep `workgroups` wavefronts resident and feed them through the host job ring (see mrp_ll.h)."""
+        self._check(self._lib.mrp_ll_session_begin(self._h, workgroups), "mrp_ll_session_begin")
+
+    def session_end(self):
+        self._check(self._lib.mrp_ll_session_end(self._h), "mrp_ll_session_end")
 
     def stats(self) -> dict:
         st = mrp_ll_stats()

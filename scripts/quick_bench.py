@@ -12,9 +12,11 @@ insts = [hl.generate_instance(1000 * agents + k, 32, 32, 204, agents) for k in r
 print("generated %d instances in %.2fs" % (n_inst, time.time() - t0), flush=True)
 s = hl.BatchSolver(device=0, n_threads=threads, slots=slots)
 print("solver created %.2fs" % (time.time() - t0), flush=True)
+cpu_n = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+mode = int(os.environ.get('MRP_HL_MODE', '0'))
 for rep in range(3):
     s.ll_stats(reset=True)
-    res, st = s.solve(insts, algo=hl.ECBS, w=1.3, want_paths=False, max_ll_expansions=50000)
+    res, st = s.solve(insts, algo=hl.ECBS, w=1.3, want_paths=False, max_ll_expansions=50000, mode=mode)
     ls = s.ll_stats()
     print("rep %d: wall %.3fs  solved %d/%d  LL exp %d  => %.3e exp/s, %.1f inst/s ; rounds %d searches %d ; kernel_ms(sum) %.1f launches %d migrated %d" % (
         rep, st["wall_seconds"], st["solved"], n_inst, st["ll_expansions"], st["ll_expansions"] / st["wall_seconds"],
@@ -22,3 +24,13 @@ for rep in range(3):
     print("   host thread-seconds: build %.3f  ll_call %.3f (pack %.3f unpack %.3f kernel %.3f h2d %.3f d2h %.3f)  consume %.3f" % (
         st["build_seconds"], st["ll_call_seconds"], ls["pack_ms"] / 1e3, ls["unpack_ms"] / 1e3, ls["kernel_ms"] / 1e3,
         ls["h2d_ms"] / 1e3, ls["d2h_ms"] / 1e3, st["consume_seconds"]), flush=True)
+
+if cpu_n:
+    import oracle
+    t = 0.0; e = 0; mism = 0
+    for inst, r in zip(insts[:cpu_n], res[:cpu_n]):
+        o = oracle.mapf_solve(oracle.ECBS, inst, w=1.3, cap_total=50000, path_cap=2048)
+        t += o["elapsed_ns"] / 1e9; e += o["ll_expanded"]
+        if o["rc"] == 1 and (r["status"], r["cost"], r["hl_expanded"], r["ll_expanded"]) != (0, o["cost"], o["hl_expanded"], o["ll_expanded"]):
+            mism += 1
+    print("cpu oracle on first %d: %.3e exp/s, %.2f inst/s, mismatches %d" % (cpu_n, e / t, cpu_n / t, mism), flush=True)

@@ -91,6 +91,12 @@ int mrp_ll_submit(mrp_ll_ctx* c, int32_t n, const mrp_ll_job* jobs, mrp_ll_resul
   return mrp_ll_search_batch(c, n, jobs, res);
 }
 int mrp_ll_wait(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
+int mrp_ll_session_begin(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
+int mrp_ll_session_end(mrp_ll_ctx*) { return MRP_LL_SUCCESS; }
+int mrp_ll_poll(mrp_ll_ctx*, int32_t, int32_t* done) {
+  *done = 1;  // the mock runs every job synchronously inside mrp_ll_submit
+  return MRP_LL_SUCCESS;
+}
 int mrp_ll_get_stats(const mrp_ll_ctx* c, mrp_ll_stats* out) {
   *out = c->stats;
   return MRP_LL_SUCCESS;

@@ -54,6 +54,17 @@ def test_ecbs_w13_benchmark_instances(solver, bench_instances, oracle_expected):
     assert stats["ll_expansions"] == sum(r["ll_expanded"] for r in res)
 
 
+def test_rounds_mode_gives_the_same_results(solver, bench_instances, oracle_expected):
+    """mode=1 (one launch per round) and the default session mode are two schedules of the same searches."""
+    from libmultirobotplanning_amd import hl
+    names = [n for n in sorted(bench_instances) if "32by32" in n and ("agents10_" in n or "agents50_" in n)][:60]
+    res, _ = solver.solve([bench_instances[n] for n in names], algo=hl.ECBS, w=1.3, mode=1)
+    for n, r in zip(names, res):
+        e = oracle_expected[n]["ecbs_w1.3"]
+        assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"], _digest(r["paths"])) == (
+            hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"], e["digest"]), n
+
+
 def test_cbs_and_ecbs_8x8(solver, bench_instances, oracle_expected):
     from libmultirobotplanning_amd import hl
     names = [n for n in sorted(bench_instances) if "8by8" in n]

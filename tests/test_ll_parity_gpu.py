@@ -29,9 +29,9 @@ def _harvest(oracle_mod, bench_instances, names, algo, w, cap_total):
     return cases
 
 
-def _run_and_compare(engine, cases, algo_ll, w):
+def _run_and_compare(engine, cases, algo_ll, w, map_ids=None):
     from libmultirobotplanning_amd import ll
-    map_ids = {}
+    map_ids = {} if map_ids is None else map_ids
     jobs = []
     for name, inst, c in cases:
         if name not in map_ids:
@@ -103,6 +103,30 @@ def test_tiers_agree(oracle_mod, bench_instances):
             assert any(r.tier == 1 for r in res)
         finally:
             eng.close()
+
+
+def test_session_mode_matches_oracle(oracle_mod, bench_instances):
+    """Session mode (resident wavefronts fed through the pinned-host job ring): same jobs, same bits, any order."""
+    from libmultirobotplanning_amd import ll
+    cases = _harvest(oracle_mod, bench_instances, ["map_32by32_obst204_agents10_ex%d" % k for k in range(8)] +
+                     ["map_32by32_obst204_agents50_ex1"], oracle_mod.ECBS, 1.3, 3_000_000)
+    eng = ll.LowLevelEngine(device=0, n_tickets=1, slots=256)
+    try:
+        map_ids = {}
+        for name, inst, _ in cases[:-40]:  # all but the last instance's map are known before the session starts
+            if name not in map_ids:
+                map_ids[name] = eng.upload_map(inst["dimx"], inst["dimy"], inst["obstacles"])
+        for rep in range(2):  # a second session on the same context must start clean
+            eng.session_begin(128)
+            try:
+                for lo in range(0, len(cases), 500):  # batches smaller than the ring; one map is uploaded in-session
+                    res = _run_and_compare(eng, cases[lo:lo + 500], ll.ASTAR_EPS, 1.3, map_ids)
+                    assert any(r.tier == 0 for r in res)
+            finally:
+                eng.session_end()
+        _run_and_compare(eng, cases[:300], ll.ASTAR_EPS, 1.3, map_ids)  # and batch mode still works afterwards
+    finally:
+        eng.close()
 
 
 def test_edge_cases(engine, oracle_mod):
