@@ -146,6 +146,10 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket);
 int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups /* 0 = mrp_ll_options.slots */);
 int mrp_ll_session_end(mrp_ll_ctx* ctx);
 int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* done);
+/* Session mode only: collect every ticket that has completed since the last call (its results are filled in and the
+ * ticket is released, exactly as after mrp_ll_wait).  One pass over the ring's completion words, independent of how
+ * many tickets are in flight.  Writes at most `cap` ticket ids to `tickets`, their number to *n. */
+int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* n);
 
 int mrp_ll_get_stats(const mrp_ll_ctx* ctx, mrp_ll_stats* out);
 int mrp_ll_reset_stats(mrp_ll_ctx* ctx);

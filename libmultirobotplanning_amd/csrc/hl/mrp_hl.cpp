@@ -252,7 +252,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     return 1;
   };
 
-  std::vector<size_t> inflight, backlog;
+  std::vector<size_t> backlog;
+  size_t nInflight = 0;
+  std::vector<int32_t> doneTickets(4096);
+  std::vector<size_t> ticketOwner;  // session ticket id -> local instance
   for (size_t k = 0; k < n; ++k) {
     live[k].inst.reset(new Instance(instIn[idx[k]], mapIds[k], opt));
     live[k].inst->advance(live[k].ans, live[k].req);
@@ -261,7 +264,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   bool failed = false;
   auto t0 = std::chrono::steady_clock::now();
   uint64_t idleSpins = 0;
-  while (!failed && (!inflight.empty() || !backlog.empty())) {
+  while (!failed && (nInflight != 0 || !backlog.empty())) {
     bool progress = false;
     // publish as many waiting instances as the ring takes
     while (!backlog.empty()) {
@@ -273,24 +276,24 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       }
       if (r == 0) break;
       backlog.pop_back();
-      inflight.push_back(k);
+      if (static_cast<size_t>(live[k].ticket) >= ticketOwner.size()) ticketOwner.resize(live[k].ticket + 1, 0);
+      ticketOwner[live[k].ticket] = k;
+      nInflight += 1;
       progress = true;
     }
     if (failed) break;
-    // harvest
-    for (size_t q = 0; q < inflight.size();) {
-      Live& L = live[inflight[q]];
-      int32_t done = 0;
-      if (mrp_ll_poll(ctx, L.ticket, &done) != MRP_LL_SUCCESS) {
-        out.err = std::string("mrp_ll_poll: ") + mrp_ll_last_error(ctx);
-        failed = true;
-        break;
-      }
-      if (!done) {
-        ++q;
-        continue;
-      }
+    // harvest: one pass over the ring's completion words, whatever the number of instances in flight
+    int32_t nDone = 0;
+    if (mrp_ll_poll_any(ctx, doneTickets.data(), static_cast<int32_t>(doneTickets.size()), &nDone) != MRP_LL_SUCCESS) {
+      out.err = std::string("mrp_ll_poll_any: ") + mrp_ll_last_error(ctx);
+      failed = true;
+      break;
+    }
+    for (int32_t d = 0; d < nDone; ++d) {
+      const size_t k = ticketOwner[doneTickets[d]];
+      Live& L = live[k];
       progress = true;
+      nInflight -= 1;
       L.ans.clear();
       for (const mrp_ll_result& r : L.res) {
         LLAnswer a;
@@ -313,9 +316,6 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
         L.ans.push_back(a);
       }
       L.inst->advance(L.ans, L.req);
-      size_t k = inflight[q];
-      inflight[q] = inflight.back();
-      inflight.pop_back();
       if (!L.req.empty()) backlog.push_back(k);
     }
     if (progress) {

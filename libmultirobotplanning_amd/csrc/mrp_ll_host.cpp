@@ -108,6 +108,10 @@ struct Ring {
   uint32_t outStride = 0;
   uint64_t head = 0;               // next ticket number to publish
   std::vector<uint8_t> busy;       // slot holds a job whose result the host has not consumed yet
+  std::vector<int32_t> slotTicket; // slot -> session ticket id / job index inside it
+  std::vector<int32_t> slotJob;
+  std::vector<uint64_t> slotTk;    // ticket number currently occupying the slot (valid while busy)
+  uint64_t tail = 0;               // oldest ticket number whose slot may still be busy
   bool active = false;
   uint32_t grid = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -608,6 +612,10 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   __atomic_store_n(g.headWord, 0u, __ATOMIC_RELEASE);
   g.head = 0;
   g.busy.assign(R, 0);
+  g.slotTicket.assign(R, -1);
+  g.slotJob.assign(R, 0);
+  g.slotTk.assign(R, 0);
+  g.tail = 0;
   ctx->sess.clear();
   auto devPtr = [&](void* hostPtr) {
     void* d = nullptr;
@@ -702,6 +710,9 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs,
     }
     g.jobs[slot] = d;
     g.busy[slot] = 1;
+    g.slotTicket[slot] = ti;
+    g.slotJob[slot] = i;
+    g.slotTk[slot] = tk;
     __atomic_store_n(g.state + slot, gen, __ATOMIC_RELEASE);  // publish: the job data above is visible first
   }
   g.head += static_cast<uint64_t>(nJobs);
@@ -741,6 +752,36 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
   }
   *doneOut = st.remaining == 0 ? 1 : 0;
   if (st.remaining == 0) st.used = false;
+  return MRP_LL_SUCCESS;
+}
+
+int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOut) {
+  if (!ctx || !tickets || !nOut || cap <= 0) return MRP_LL_E_INVALID;
+  Ring& g = ctx->ring;
+  if (!g.active) return MRP_LL_E_INVALID;
+  const uint32_t R = Ring::kSlots;
+  int32_t n = 0;
+  // a slot may already be busy with ticket tk + R while the scan still passes the consumed ticket tk: compare numbers
+  auto occupies = [&](uint64_t tk) { return g.busy[tk % R] && g.slotTk[tk % R] == tk; };
+  while (g.tail < g.head && !occupies(g.tail)) g.tail += 1;
+  for (uint64_t tk = g.tail; tk < g.head && n < cap; ++tk) {
+    const uint32_t slot = static_cast<uint32_t>(tk % R);
+    if (!occupies(tk)) continue;
+    const uint32_t gen = static_cast<uint32_t>(tk / R) + 1;
+    if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != gen) continue;
+    SessTicket& st = ctx->sess[g.slotTicket[slot]];
+    const int32_t i = g.slotJob[slot];
+    unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
+                 st.res[i]);
+    st.state[i] = 1;
+    st.remaining -= 1;
+    g.busy[slot] = 0;
+    if (st.remaining == 0) {
+      st.used = false;
+      tickets[n++] = g.slotTicket[slot];
+    }
+  }
+  *nOut = n;
   return MRP_LL_SUCCESS;
 }
 

@@ -53,7 +53,7 @@ class mrp_ll_stats(ctypes.Structure):
 
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
            "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version",
-           "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll"]
+           "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any"]
 
 _lib = None
 
@@ -96,6 +96,8 @@ def load_library(path: Optional[str] = None):
     lib.mrp_ll_session_end.argtypes = [ctypes.c_void_p]
     lib.mrp_ll_poll.restype = ctypes.c_int
     lib.mrp_ll_poll.argtypes = [ctypes.c_void_p, ctypes.c_int32, I32P]
+    lib.mrp_ll_poll_any.restype = ctypes.c_int
+    lib.mrp_ll_poll_any.argtypes = [ctypes.c_void_p, I32P, ctypes.c_int32, I32P]
     if path is None:
         _lib = lib
     return lib
@@ -162,9 +164,9 @@ class LowLevelEngine:
                                                 ctypes.byref(mid)), "mrp_ll_upload_map")
         return mid.value
 
-    def search_batch(self, jobs: Sequence[LLJob], states_cap: Optional[int] = None) -> List[LLResult]:
+    def _marshal(self, jobs: Sequence[LLJob], cap: int):
+        """Build the ctypes job/result arrays for `jobs`; returns (cjobs, cres, keepalive)."""
         n = len(jobs)
-        cap = states_cap or self.max_horizon
         cjobs = (mrp_ll_job * max(n, 1))()
         cres = (mrp_ll_result * max(n, 1))()
         keep = []
@@ -190,6 +192,12 @@ class LowLevelEngine:
             cres[i].states_txy = states[i].ctypes.data_as(I32P)
             cres[i].actions = actions[i].ctypes.data_as(I32P)
             cres[i].states_cap = cap
+        return cjobs, cres, (keep, states, actions)
+
+    def search_batch(self, jobs: Sequence[LLJob], states_cap: Optional[int] = None) -> List[LLResult]:
+        n = len(jobs)
+        cap = states_cap or self.max_horizon
+        cjobs, cres, (keep, states, actions) = self._marshal(jobs, cap)
         self._check(self._lib.mrp_ll_search_batch(self._h, n, cjobs, cres), "mrp_ll_search_batch")
         out = []
         for i in range(n):

@@ -24,6 +24,8 @@ struct mrp_ll_ctx {
   mrp_ll_stats stats;
   std::string err;
   int32_t pendingJobs = 0;
+  std::vector<int32_t> doneTickets;  // completed (synchronously in mrp_ll_submit), not yet reported by poll_any
+  int32_t nextTicket = 0;
   const mrp_ll_job* jobs = nullptr;
   mrp_ll_result* results = nullptr;
 };
@@ -87,8 +89,18 @@ int mrp_ll_search_batch(mrp_ll_ctx* c, int32_t n, const mrp_ll_job* jobs, mrp_ll
   return MRP_LL_SUCCESS;
 }
 int mrp_ll_submit(mrp_ll_ctx* c, int32_t n, const mrp_ll_job* jobs, mrp_ll_result* res, int32_t* ticket) {
-  *ticket = 0;
+  *ticket = c->nextTicket++ & 0xFFFF;
+  c->doneTickets.push_back(*ticket);
   return mrp_ll_search_batch(c, n, jobs, res);
+}
+int mrp_ll_poll_any(mrp_ll_ctx* c, int32_t* tickets, int32_t cap, int32_t* n) {
+  int32_t k = 0;
+  while (!c->doneTickets.empty() && k < cap) {
+    tickets[k++] = c->doneTickets.back();
+    c->doneTickets.pop_back();
+  }
+  *n = k;
+  return MRP_LL_SUCCESS;
 }
 int mrp_ll_wait(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
 int mrp_ll_session_begin(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }

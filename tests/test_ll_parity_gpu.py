@@ -125,6 +125,43 @@ def test_session_mode_matches_oracle(oracle_mod, bench_instances):
             finally:
                 eng.session_end()
         _run_and_compare(eng, cases[:300], ll.ASTAR_EPS, 1.3, map_ids)  # and batch mode still works afterwards
+        # ring wrap-around: many more tickets than ring slots, consumed out of order through mrp_ll_poll_any
+        import ctypes
+        import numpy as np
+        lib = ll.load_library()
+        eng.session_begin(64)
+        try:
+            small = cases[:40]
+            total = 6000  # ring has 2048 slots
+            inflight = {}
+            done_buf = (ctypes.c_int32 * 256)()
+            n_done = ctypes.c_int32(0)
+            submitted = completed = 0
+            keep = {}
+            while completed < total:
+                while submitted < total and len(inflight) < 300:
+                    name, inst, c = small[submitted % len(small)]
+                    a = c["agent"]
+                    job = ll.LLJob(map_id=map_ids[name], algo=ll.ASTAR_EPS, start=inst["starts"][a],
+                                   goal=inst["goals"][a], agent_idx=a, w=1.3,
+                                   vertex_constraints=c["vertex_constraints"],
+                                   edge_constraints=c["edge_constraints"], ctx_paths=c["ctx_paths"])
+                    cj, cr, hold = eng._marshal([job], 512)
+                    tk = ctypes.c_int32(-1)
+                    rc = lib.mrp_ll_submit(eng._h, 1, cj, cr, ctypes.byref(tk))
+                    if rc == -4:
+                        break
+                    assert rc == 0
+                    inflight[tk.value] = (submitted % len(small), cr, hold, cj)
+                    submitted += 1
+                assert lib.mrp_ll_poll_any(eng._h, done_buf, 256, ctypes.byref(n_done)) == 0
+                for q in range(n_done.value):
+                    which, cr, hold, cj = inflight.pop(done_buf[q])
+                    c = small[which][2]
+                    assert cr[0].expanded == c["expanded"] and cr[0].cost == c["cost"], (which, completed)
+                    completed += 1
+        finally:
+            eng.session_end()
     finally:
         eng.close()
 
