@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=4096, help="instances per GPU per step")
+    ap.add_argument("--instances", type=int, default=8192, help="instances per GPU per step")
     ap.add_argument("--agents", type=int, default=10)
     ap.add_argument("--threads", type=int, default=0, help="host worker threads per GPU (0 = auto)")
     ap.add_argument("--slots", type=int, default=0)
@@ -153,7 +153,8 @@ def main():
                 "launches": lls["launches"],
                 "avg_launch_ms": lls["kernel_ms"] / max(lls["launches"], 1),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EXPANSION * lls["expansions"] / max(lls["launches"], 1),
-                "note": "rank-0 launches of the timed region; launches of different host threads overlap in time",
+                "note": "rank-0 launches of the timed region: session mode keeps one resident launch per host thread "
+                        "per step (fed through the pinned-host job ring), and the launches of the threads overlap in time",
             },
         }
         if not args.no_cpu_baseline:

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -264,8 +265,13 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   bool failed = false;
   auto t0 = std::chrono::steady_clock::now();
   uint64_t idleSpins = 0;
+  auto nowS = []() { return std::chrono::steady_clock::now(); };
+  auto secsS = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count();
+  };
   while (!failed && (nInflight != 0 || !backlog.empty())) {
     bool progress = false;
+    auto tA = nowS();
     // publish as many waiting instances as the ring takes
     while (!backlog.empty()) {
       size_t k = backlog.back();
@@ -282,6 +288,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       progress = true;
     }
     if (failed) break;
+    auto tB = nowS();
     // harvest: one pass over the ring's completion words, whatever the number of instances in flight
     int32_t nDone = 0;
     if (mrp_ll_poll_any(ctx, doneTickets.data(), static_cast<int32_t>(doneTickets.size()), &nDone) != MRP_LL_SUCCESS) {
@@ -289,6 +296,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       failed = true;
       break;
     }
+    auto tC = nowS();
     for (int32_t d = 0; d < nDone; ++d) {
       const size_t k = ticketOwner[doneTickets[d]];
       Live& L = live[k];
@@ -318,6 +326,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       L.inst->advance(L.ans, L.req);
       if (!L.req.empty()) backlog.push_back(k);
     }
+    auto tD = nowS();
+    out.buildS += secsS(tA, tB);
+    out.llS += secsS(tB, tC);
+    out.consumeS += secsS(tC, tD);
     if (progress) {
       idleSpins = 0;
     } else if ((++idleSpins & 0xFFFFF) == 0) {
@@ -442,7 +454,8 @@ int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* optIn, int32_t n
     }
   std::vector<GroupResult> gr(nThreads);
   // resident wavefronts per engine: the chip holds about 256 CUs x 4 workgroups of this kernel at once
-  const int32_t sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, 1024 / nThreads));
+  int32_t sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, 1024 / nThreads));
+  if (const char* e = std::getenv("MRP_HL_SESSION_WGS")) sessionWgs = std::max(1, std::atoi(e));  // tuning knob
   auto t0 = std::chrono::steady_clock::now();
   {
     std::vector<std::thread> th;

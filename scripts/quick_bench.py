@@ -10,13 +10,13 @@ slots = int(sys.argv[4]) if len(sys.argv) > 4 else 512
 t0 = time.time()
 insts = [hl.generate_instance(1000 * agents + k, 32, 32, 204, agents) for k in range(n_inst)]
 print("generated %d instances in %.2fs" % (n_inst, time.time() - t0), flush=True)
-s = hl.BatchSolver(device=0, n_threads=threads, slots=slots)
+s = hl.BatchSolver(device=0, n_threads=threads, slots=slots, lds_nodes=int(os.environ.get('MRP_LDS_NODES', '0')))
 print("solver created %.2fs" % (time.time() - t0), flush=True)
 cpu_n = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 mode = int(os.environ.get('MRP_HL_MODE', '0'))
 for rep in range(3):
     s.ll_stats(reset=True)
-    res, st = s.solve(insts, algo=hl.ECBS, w=1.3, want_paths=False, max_ll_expansions=50000, mode=mode)
+    res, st = s.solve(insts, algo=hl.ECBS, w=1.3, want_paths=False, max_ll_expansions=int(os.environ.get("MRP_CAP", "50000")), mode=mode)
     ls = s.ll_stats()
     print("rep %d: wall %.3fs  solved %d/%d  LL exp %d  => %.3e exp/s, %.1f inst/s ; rounds %d searches %d ; kernel_ms(sum) %.1f launches %d migrated %d" % (
         rep, st["wall_seconds"], st["solved"], n_inst, st["ll_expansions"], st["ll_expansions"] / st["wall_seconds"],
