@@ -149,7 +149,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "kernel": "mrp_ll_search_kernel",
+                "kernel": "mrp_ll_persistent_kernel",
                 "launches": lls["launches"],
                 "avg_launch_ms": lls["kernel_ms"] / max(lls["launches"], 1),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EXPANSION * lls["expansions"] / max(lls["launches"], 1),
