@@ -1,0 +1,50 @@
+"""The YAML front-end (example/ecbs.cpp:554-617 schema) end to end on the GPU: reads the reference's input schema,
+writes the `statistics:` / `schedule:` schema that example/visualize.py consumes, with the oracle's numbers."""
+import yaml
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_input(path, inst):
+    doc = {"map": {"dimensions": [inst["dimx"], inst["dimy"]], "obstacles": inst["obstacles"]},
+           "agents": [{"name": "agent%d" % i, "start": s, "goal": g}
+                      for i, (s, g) in enumerate(zip(inst["starts"], inst["goals"]))]}
+    with open(path, "w") as f:
+        yaml.safe_dump(doc, f)
+
+
+def test_ecbs_cli_roundtrip(tmp_path, ref_tests, bench_instances, oracle_expected):
+    from libmultirobotplanning_amd import cli
+    names = ["mapf_simple1", "map_32by32_obst204_agents10_ex3"]
+    insts = [ref_tests["mapf"]["mapf_simple1"], bench_instances["map_32by32_obst204_agents10_ex3"]]
+    args = ["ecbs", "-w", "1.3"]
+    for n, inst in zip(names, insts):
+        _write_input(tmp_path / (n + ".yaml"), inst)
+        args += ["-i", str(tmp_path / (n + ".yaml")), "-o", str(tmp_path / (n + ".out.yaml"))]
+    assert cli.main(args) == 0
+    out = yaml.safe_load(open(tmp_path / "map_32by32_obst204_agents10_ex3.out.yaml"))
+    e = oracle_expected["map_32by32_obst204_agents10_ex3"]["ecbs_w1.3"]
+    st = out["statistics"]
+    assert (st["cost"], st["makespan"], st["highLevelExpanded"], st["lowLevelExpanded"]) == (
+        e["cost"], e["makespan"], e["hl"], e["ll"])
+    assert list(st.keys()) == ["cost", "makespan", "runtime", "highLevelExpanded", "lowLevelExpanded"]
+    sched = out["schedule"]
+    assert sorted(sched.keys()) == sorted("agent%d" % i for i in range(10))
+    for i in range(10):
+        steps = sched["agent%d" % i]
+        assert [s["t"] for s in steps] == list(range(len(steps)))
+        assert [steps[0]["x"], steps[0]["y"]] == insts[1]["starts"][i]
+        assert [steps[-1]["x"], steps[-1]["y"]] == insts[1]["goals"][i]
+    assert sum(len(sched[a]) - 1 for a in sched) == e["cost"]
+    small = yaml.safe_load(open(tmp_path / "mapf_simple1.out.yaml"))
+    assert small["statistics"]["cost"] == 8   # ECBS(1.3) happens to be optimal here; test/test_ecbs.py:25-27 uses w=1.0
+
+
+def test_cbs_cli(tmp_path, ref_tests):
+    from libmultirobotplanning_amd import cli
+    _write_input(tmp_path / "c.yaml", ref_tests["mapf"]["mapf_circle"])
+    assert cli.main(["cbs", "-i", str(tmp_path / "c.yaml"), "-o", str(tmp_path / "c.out.yaml")]) == 0
+    out = yaml.safe_load(open(tmp_path / "c.out.yaml"))
+    assert out["statistics"]["cost"] == 4     # test/test_cbs.py:28-30
