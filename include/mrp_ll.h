@@ -46,6 +46,8 @@ extern "C" {
 /* ---- search algorithm of a job ----------------------------------------------------------------------------- */
 #define MRP_LL_ASTAR 0     /* a_star.hpp AStar::search          (CBS low level)  */
 #define MRP_LL_ASTAR_EPS 1 /* a_star_epsilon.hpp AStarEpsilon   (ECBS low level) */
+#define MRP_LL_SIPP 2      /* sipp.hpp SIPP::search over the grid Environment of example/mapf_prioritized_sipp.cpp;  */
+                           /* batch mode only, and a batch holds either SIPP jobs or A-star jobs, not both          */
 
 /* ---- per-job status (mrp_ll_result.status) ----------------------------------------------------------------- */
 #define MRP_LL_OK 0             /* search() returned true                                                    */
@@ -94,6 +96,12 @@ typedef struct mrp_ll_job {
   const int32_t* path_len;           /* [n_agents] states per path; 0 = empty path, skipped (ecbs.cpp:287)    */
   const int32_t* const* path_xy;     /* [n_agents] -> [path_len][2] = x, y at time 0,1,2,...                  */
   int64_t max_expansions;            /* < 0: unlimited                                                        */
+  /* MRP_LL_SIPP only — SIPP::setCollisionIntervals (sipp.hpp:82-85,245-284), one entry per location; a location
+   * given twice keeps the later list.  Ignored by the other algorithms (leave zero). */
+  int32_t n_collision_locations;
+  const int32_t* collision_xy;        /* [n][2]   x, y                                                        */
+  const int32_t* collision_count;     /* [n]      intervals of that location                                  */
+  const int32_t* collision_intervals; /* [sum][2] start, end (inclusive; end may be INT32_MAX)                 */
 } mrp_ll_job;
 
 typedef struct mrp_ll_result {
@@ -106,6 +114,8 @@ typedef struct mrp_ll_result {
   int32_t* actions;    /* caller buffer [states_cap]    = MRP_LL_ACT_* ; may be NULL                          */
   int32_t states_cap;
   int32_t tier;     /* 0 = finished in the LDS tier, 1 = migrated to the HBM arena (diagnostic)               */
+  int32_t* action_costs; /* caller buffer [states_cap] or NULL: PlanResult::actions[k].second (always 1 for the
+                          * A-star algorithms; Wait durations for MRP_LL_SIPP, sipp.hpp:105-128)                 */
 } mrp_ll_result;
 
 typedef struct mrp_ll_stats {

@@ -617,6 +617,202 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   res.nodes_created = s.nNodes;
 }
 
+
+// ---- SIPP (config 5): A* over (cell, safe interval) states ---------------------------------------------------
+// Reference: SIPP::search sipp.hpp:91-134 -> AStar::search a_star.hpp:63-161 over SIPPState with
+// SIPPEnvironment::getNeighbors sipp.hpp:191-223 (motions Up, Down, Left, Right of mapf_prioritized_sipp.cpp:99-121;
+// isCommandValid :129-142: arrival t = max(si.start, g + 1), cost t - g; swaps are not checked) and isSolution
+// sipp.hpp:185-189 (goal cell AND the interval ends at INT_MAX).  Edge costs vary, so the decrease-key branch
+// a_star.hpp:139-145 (`openSet.increase(handle)` == sift-up from the handle's position) is live here.
+// Job tables (packed by the host, copied into the arena slot): cellIdx[cells] (0 = single default interval
+// [0, INT_MAX], k+1 = special cell k), specFirst[K+1], ivals[total][2].  State id = cell for default cells,
+// cells + specFirst[k] + i for interval i of special cell k.  HBM tier only.
+constexpr int32_t kIntMax = 0x7FFFFFFF;
+constexpr uint32_t kStClosed = 0x80000000u;
+
+DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, DevResult& res, uint16_t* outPath) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t dimx = J.dimx, dimy = J.dimy, cells = dimx * dimy;
+  const uint32_t K = J.n_vc, totalIv = J.n_ec;
+  const uint32_t gx = J.gx, gy = J.gy;
+  const int64_t maxExp = J.max_expansions;
+  const uint32_t* obst = P.maps + J.map_word_off;
+  Mem<1> g;
+  {
+    uint8_t* p = arenaSlot;
+    g.nodes = (Mem<1>::PNode)p;                  p += (size_t)P.arena_nodes * 16;
+    g.open = (Mem<1>::P64)(p + 8);               p += (size_t)P.arena_nodes * 8 + 16;
+    g.focal = (Mem<1>::P64)(p + 8);              p += (size_t)P.arena_nodes * 8 + 16;
+    g.aux = (Mem<1>::P64)(p + 8);                p += (size_t)P.arena_nodes * 8 + 16;
+    g.bits = (Mem<1>::P32)p;
+    g.capNodes = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
+  }
+  uint8_t* scratch = arenaSlot + P.arena_scratch_off;
+  uint32_t* tab = (uint32_t*)((uint32_t*)(scratch + (size_t)P.out_stride * 2) + kConsLocalWords);  // path-table area
+  if (J.t_pad == 0xFFFFFFFFu) {  // no safe interval contains the start time: SIPP::search returns false (sipp.hpp:98-100)
+    res.status = ST_NO_SOLUTION;
+    return;
+  }
+  const uint32_t tabWords = cells + K + 1 + 2 * totalIv;
+  const uint32_t nStates = cells + totalIv;
+  if (tabWords * 4 > P.arena_paths_bytes || nStates > P.arena_rows * P.arena_row_words) {
+    res.status = ST_CAP_NODES;
+    return;
+  }
+  {
+    const uint32_t* src = P.cons + J.vc_off;
+    for (uint32_t i = lane; i < tabWords; i += 64) tab[i] = src[i];
+    for (uint32_t i = lane; i < nStates; i += 64) g.bits[i] = 0;  // status: 0 unseen, node+1 in open, bit 31 closed
+  }
+  __syncthreads();
+  const uint32_t* cellIdx = tab;
+  const uint32_t* specFirst = tab + cells;
+  const int32_t* ivals = (const int32_t*)(tab + cells + K + 1);
+
+  // start node
+  uint32_t nNodes = 1, nOpen = 1;
+  int64_t expansions = 0;
+  {
+    const uint32_t sc = J.sy * dimx + J.sx;
+    const uint32_t si = J.t_pad;  // start interval index (findSafeInterval, sipp.hpp:286-296, done by the host)
+    const uint32_t h0 = (J.sx > gx ? J.sx - gx : gx - J.sx) + (J.sy > gy ? J.sy - gy : gy - J.sy);
+    u32x4 n0;
+    n0.x = sc | (si << 16);
+    n0.y = kNoParent;
+    n0.z = 0;  // g = startTime = 0
+    n0.w = 0;
+    g.nodes[0] = n0;
+    g.open[0] = packEntry(0, h0, 0, 0);
+    const uint32_t k = rfl(cellIdx[sc]);
+    const uint32_t sid = k ? cells + rfl(specFirst[k - 1]) + si : sc;
+    g.bits[sid] = 1;
+  }
+  for (;;) {
+    if (nOpen == 0) {
+      res.status = ST_NO_SOLUTION;
+      break;
+    }
+    const uint64_t curE = ld64<1>(g.open, 0);
+    const uint32_t curId = entryId(curE);
+    const u32x4 nd = g.nodes[curId];
+    const uint32_t cw = rfl(nd.x);
+    const uint32_t cell = cw & 0xFFFF, iv = cw >> 16;
+    const uint32_t gcur = rfl(nd.z);
+    const uint32_t cx = cell % dimx, cy = cell / dimx;
+    const uint32_t ck = rfl(cellIdx[cell]);
+    int32_t endT = kIntMax;
+    uint32_t curSid = cell;
+    if (ck) {
+      const uint32_t f0 = rfl(specFirst[ck - 1]);
+      endT = rfli(ivals[2 * (f0 + iv) + 1]);
+      curSid = cells + f0 + iv;
+    }
+    expansions += 1;
+    if (maxExp >= 0 && expansions > maxExp) {
+      res.status = ST_CAP_EXP;
+      break;
+    }
+    if (cx == gx && cy == gy && endT == kIntMax) {
+      // raw A* solution: (cell, g) per state; the host inserts the explicit Wait actions (sipp.hpp:105-128)
+      uint32_t len = 0;
+      for (uint32_t nid = curId; nid != kNoParent; nid = rfl(g.nodes[nid].y)) len += 1;
+      if (len * 2 > P.out_stride) {
+        res.status = ST_CAP_HORIZON;
+        break;
+      }
+      uint32_t* out32 = (uint32_t*)outPath;
+      uint32_t nid = curId;
+      for (int32_t k = (int32_t)len - 1; k >= 0; --k) {
+        const u32x4 pn = g.nodes[nid];
+        out32[k] = (rfl(pn.x) & 0xFFFF) | (rfl(pn.z) << 16);
+        nid = rfl(pn.y);
+      }
+      res.status = ST_OK;
+      res.cost = (int32_t)gcur;
+      res.fmin = entryF(curE);
+      res.n_states = (int32_t)len;
+      break;
+    }
+    heapPop<1, 0, true>(g, g.open, nOpen);
+    g.bits[curSid] = kStClosed;
+    const uint32_t startT = gcur + 1;
+    if (startT > kGMask) {
+      res.status = ST_CAP_HORIZON;
+      break;
+    }
+    bool fail = false;
+    for (uint32_t m = 0; m < 4 && !fail; ++m) {  // Up, Down, Left, Right
+      const uint32_t nx = cx + (m == 3) - (m == 2), ny = cy + (m == 0) - (m == 1);
+      if (nx >= dimx || ny >= dimy) continue;
+      const uint32_t nc = ny * dimx + nx;
+      if ((rfl(obst[nc >> 5]) >> (nc & 31)) & 1u) continue;
+      const uint32_t nk = rfl(cellIdx[nc]);
+      uint32_t first = 0, cnt = 1;
+      if (nk) {
+        first = rfl(specFirst[nk - 1]);
+        cnt = rfl(specFirst[nk]) - first;
+      }
+      const uint32_t hN = (nx > gx ? nx - gx : gx - nx) + (ny > gy ? ny - gy : gy - ny);
+      for (uint32_t base = 0; base < cnt && !fail; base += 64) {
+        const uint32_t i = base + lane;
+        int32_t siS = 0, siE = kIntMax;
+        if (nk && i < cnt) {
+          siS = ivals[2 * (first + i)];
+          siE = ivals[2 * (first + i) + 1];
+        }
+        // sipp.hpp:209: skip if si.start - m_time > end_t || si.end < start_t
+        const bool cand = (i < cnt) && !((int64_t)siS - 1 > (int64_t)endT || siE < (int32_t)startT);
+        const uint32_t tArr = (uint32_t)(siS > (int32_t)startT ? siS : (int32_t)startT);
+        uint64_t mask = __ballot(cand);
+        while (mask) {
+          const uint32_t l = (uint32_t)__builtin_ctzll(mask);
+          mask &= mask - 1;
+          const uint32_t ii = base + l;
+          const uint32_t t = __builtin_amdgcn_readlane(tArr, l);
+          if (t > kGMask) {
+            res.status = ST_CAP_HORIZON;
+            fail = true;
+            break;
+          }
+          const uint32_t sid = nk ? cells + first + ii : nc;
+          const uint32_t st = rfl(g.bits[sid]);
+          if (st & kStClosed) continue;                   // closedSet.find (a_star.hpp:117)
+          if (st == 0) {                                   // new state (a_star.hpp:120-129)
+            if (nNodes >= g.capNodes) {
+              res.status = ST_CAP_NODES;
+              fail = true;
+              break;
+            }
+            const uint32_t nid = nNodes++;
+            u32x4 nn;
+            nn.x = nc | (ii << 16);
+            nn.y = curId;
+            nn.z = t;
+            nn.w = 0;
+            g.nodes[nid] = nn;
+            g.bits[sid] = nid + 1;
+            siftUp<1, 0, true>(g, g.open, nOpen, packEntry(0, t + hN, t, nid));
+            nOpen += 1;
+          } else {                                         // already in open (a_star.hpp:130-146)
+            const uint32_t nid = st - 1;
+            const u32x4 on = g.nodes[nid];
+            if (t >= rfl(on.z)) continue;
+            u32x4 nn = on;
+            nn.y = curId;
+            nn.z = t;
+            g.nodes[nid] = nn;                             // cameFrom update + new g
+            siftUp<1, 0, true>(g, g.open, rfl(on.w), packEntry(0, t + hN, t, nid));  // increase(handle)
+          }
+        }
+      }
+    }
+    if (fail) break;
+  }
+  res.expanded = expansions;
+  res.nodes_created = nNodes;
+  res.tier = 1;
+}
+
 // Runs the job whose descriptor is at `jobSrc` (host memory) and writes result + path to host memory.
 DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* resDst, uint16_t* pathDst, uint8_t* smem,
                      uint8_t* arenaSlot, DevJob& jobS, DevResult& resS) {
@@ -673,6 +869,41 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchPara
     DBG(P, 3, j + 1);
   }
   DBG(P, 4, 1);
+}
+
+// SIPP batches (MRP_LL_SIPP jobs only) run in their own kernel so that the CBS/ECBS kernels' register allocation is not
+// widened by a path they never take.  Same queue discipline as mrp_ll_search_kernel.
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams P) {
+  __shared__ DevJob jobS;
+  __shared__ DevResult resS;
+  const uint32_t lane = threadIdx.x;
+  uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
+  for (;;) {
+    uint32_t j = atomicAdd(P.queue_head, lane == 0 ? 1u : 0u);
+    j = rfl(j) - P.queue_base;
+    if (j >= P.n_jobs) break;
+    __syncthreads();
+    {
+      const uint32_t* src = (const uint32_t*)(P.jobs + j);
+      if (lane < sizeof(DevJob) / 4) ((uint32_t*)&jobS)[lane] = src[lane];
+    }
+    __syncthreads();
+    DevResult res;
+    res.status = ST_BAD; res.cost = 0; res.fmin = 0; res.n_states = 0; res.expanded = 0; res.nodes_created = 0;
+    res.tier = 1;
+    for (int q = 0; q < 8; ++q) res.prof[q] = 0;
+    uint16_t* outPath = (uint16_t*)(arenaSlot + P.arena_scratch_off);
+    runSipp(P, jobS, arenaSlot, res, outPath);
+    __syncthreads();
+    resS = res;
+    __syncthreads();
+    if (lane < sizeof(DevResult) / 4) ((uint32_t*)(P.results + j))[lane] = ((const uint32_t*)&resS)[lane];
+    if (res.status == ST_OK) {  // one u32 (cell | g << 16) per raw A* state
+      const uint32_t* src = (const uint32_t*)outPath;
+      uint32_t* dst = (uint32_t*)(P.out_paths + (size_t)j * P.out_stride);
+      for (uint32_t i = lane; i < (uint32_t)res.n_states; i += 64) dst[i] = src[i];
+    }
+  }
 }
 
 // Session mode.  The same workgroups stay resident for a whole solve and are fed through a ring in coherent pinned
@@ -735,6 +966,11 @@ extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, u
     attrSet = true;
   }
   hipLaunchKernelGGL(mrp::mrp_ll_search_kernel, dim3(grid), dim3(64), ldsBytes, stream, *P);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mrp_ll_launch_sipp(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(mrp::mrp_ll_sipp_kernel, dim3(grid), dim3(64), 0, stream, *P);
   return hipGetLastError();
 }
 

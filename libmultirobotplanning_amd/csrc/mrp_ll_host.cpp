@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <climits>
 #include <cstring>
 #include <ctime>
 #include <string>
@@ -16,6 +17,7 @@
 
 extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes);
 extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t mrp_ll_launch_sipp(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t mrp_ll_launch_persistent(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes,
                                                hipStream_t stream);
 
@@ -91,6 +93,8 @@ struct Ticket {
   int32_t nJobs = 0;
   mrp_ll_result* userResults = nullptr;
   std::vector<uint8_t> rejected;  // per job: rejected on the host (MRP_LL_BAD_JOB)
+  bool sipp = false;              // the batch holds MRP_LL_SIPP jobs (own kernel, own result format)
+  std::vector<int32_t> jobDimx;   // SIPP: grid width per job (cell -> x, y when unpacking)
 };
 
 // ---- session mode: job ring in coherent pinned host memory --------------------------------------------------
@@ -246,12 +250,96 @@ struct PathSinkSlot {
   }
 };
 
+// SIPP job tables (see runSipp in ll_kernel.hip).  Safe intervals are derived from the collision intervals exactly as
+// SIPPEnvironment::setCollisionIntervals does (sipp.hpp:245-284): sort by start; a safe interval [start, ci.start-1]
+// in front of every collision interval when non-empty; a final [start, INT_MAX] unless the last one ends at INT_MAX.
+template <class ConsSink>
+bool packSipp(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, ConsSink& cs, DevJob& d) {
+  (void)ctx;
+  const int cells = mp.dimx * mp.dimy;
+  if (j.n_collision_locations < 0) return false;
+  if (j.n_collision_locations > 0 && (!j.collision_xy || !j.collision_count || !j.collision_intervals)) return false;
+  struct Iv { int32_t s, e; };
+  std::vector<int32_t> cellIdx(cells, 0);
+  std::vector<std::vector<Iv>> safe;  // per special cell
+  size_t off = 0;
+  for (int n = 0; n < j.n_collision_locations; ++n) {
+    const int x = j.collision_xy[2 * n], y = j.collision_xy[2 * n + 1];
+    const int cnt = j.collision_count[n];
+    std::vector<Iv> ci;
+    for (int k = 0; k < cnt; ++k) ci.push_back(Iv{j.collision_intervals[2 * (off + k)], j.collision_intervals[2 * (off + k) + 1]});
+    off += cnt;
+    if (x < 0 || x >= mp.dimx || y < 0 || y >= mp.dimy) continue;  // never visited
+    const int cell = y * mp.dimx + x;
+    std::vector<Iv> si;
+    if (cnt > 0) {
+      std::stable_sort(ci.begin(), ci.end(), [](const Iv& a, const Iv& b) { return a.s < b.s; });
+      long long start = 0;
+      int32_t lastEnd = 0;
+      for (const Iv& c : ci) {
+        if (start <= static_cast<long long>(c.s) - 1) si.push_back(Iv{static_cast<int32_t>(start), c.s - 1});
+        start = static_cast<long long>(c.e) + 1;
+        lastEnd = c.e;
+      }
+      if (lastEnd < INT32_MAX) si.push_back(Iv{static_cast<int32_t>(start), INT32_MAX});
+    }
+    // erase + re-create (sipp.hpp:247-251): an empty list restores the default single interval
+    if (cellIdx[cell]) {
+      safe[cellIdx[cell] - 1] = si;
+      if (cnt == 0) safe[cellIdx[cell] - 1] = std::vector<Iv>{Iv{0, INT32_MAX}};
+    } else if (cnt > 0) {
+      safe.push_back(si);
+      cellIdx[cell] = static_cast<int32_t>(safe.size());
+    }
+  }
+  d.algo = MRP_LL_SIPP;
+  d.max_expansions = j.max_expansions;
+  d.vc_off = static_cast<uint32_t>(cs.size());
+  for (int c = 0; c < cells; ++c) cs.push(static_cast<uint32_t>(cellIdx[c]));
+  uint32_t total = 0;
+  for (const auto& v : safe) {
+    cs.push(total);
+    total += static_cast<uint32_t>(v.size());
+  }
+  cs.push(total);
+  for (const auto& v : safe)
+    for (const Iv& iv : v) {
+      cs.push(static_cast<uint32_t>(iv.s));
+      cs.push(static_cast<uint32_t>(iv.e));
+    }
+  d.n_vc = static_cast<uint32_t>(safe.size());
+  d.n_ec = total;
+  d.ec_off = 0;
+  d.n_agents_pad = 0;
+  d.path_off = 0;
+  d.last_goal_constraint = -1;
+  // findSafeInterval(start, startTime = 0) (sipp.hpp:98-100,286-296): no interval -> search() returns false
+  const int sc = j.start_y * mp.dimx + j.start_x;
+  int startIv = -1;
+  if (!cellIdx[sc]) {
+    startIv = 0;
+  } else {
+    const auto& v = safe[cellIdx[sc] - 1];
+    for (size_t k = 0; k < v.size(); ++k)
+      if (v[k].s <= 0 && v[k].e >= 0) {
+        startIv = static_cast<int>(k);
+        break;
+      }
+  }
+  if (startIv < 0) {  // make the device report NO_SOLUTION: an empty open list cannot be encoded, so cap at 0 ...
+    d.t_pad = 0xFFFFFFFFu;
+  } else {
+    d.t_pad = static_cast<uint32_t>(startIv);
+  }
+  return !cs.failed;
+}
+
 // Pack one job; returns false if the job is rejected (MRP_LL_BAD_JOB).
 template <class ConsSink, class PathSink>
 bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, DevJob& d) {
   if (j.map_id < 0 || j.map_id >= static_cast<int32_t>(ctx->maps.size())) return false;
   const MapRec& mp = ctx->maps[j.map_id];
-  if (j.algo != MRP_LL_ASTAR && j.algo != MRP_LL_ASTAR_EPS) return false;
+  if (j.algo != MRP_LL_ASTAR && j.algo != MRP_LL_ASTAR_EPS && j.algo != MRP_LL_SIPP) return false;
   auto inGrid = [&](int x, int y) { return x >= 0 && x < mp.dimx && y >= 0 && y < mp.dimy; };
   if (!inGrid(j.start_x, j.start_y)) return false;
   if (j.n_vertex_constraints < 0 || j.n_edge_constraints < 0 || j.n_agents < 0) return false;
@@ -273,6 +361,7 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   d.algo = j.algo;
   d.w = j.w;
   d.max_expansions = j.max_expansions;
+  if (j.algo == MRP_LL_SIPP) return packSipp(ctx, j, mp, cs, d);
   // setLowLevelContext (ecbs.cpp:264-274): last vertex constraint on the goal cell
   int lastGoal = -1;
   d.vc_off = static_cast<uint32_t>(cs.size());
@@ -383,7 +472,8 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
 }
 
 // Device result -> caller's mrp_ll_result (+ statistics).
-void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool rejected, mrp_ll_result& r) {
+void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool rejected, mrp_ll_result& r,
+                  bool sipp = false, int dimx = 0) {
   if (rejected) {
     r.status = MRP_LL_BAD_JOB;
     r.cost = r.fmin = r.n_states = 0;
@@ -402,6 +492,44 @@ void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool r
   ctx->stats.nodes_created += d.nodes_created;
   ctx->stats.migrated += d.tier ? 1 : 0;
   for (int q = 0; q < 8; ++q) ctx->stats.prof[q] += d.prof[q];
+  if (d.status == mrp::ST_OK && sipp) {
+    // raw A* states (cell | g << 16) -> PlanResult with explicit Wait actions (sipp.hpp:105-128)
+    const uint32_t* raw = reinterpret_cast<const uint32_t*>(p);
+    const int nRaw = d.n_states;
+    int out = 0;
+    bool trunc = false;
+    auto emit = [&](int cell, int t, int action, int cost, bool hasAction) {
+      if (out < r.states_cap) {
+        if (r.states_txy) {
+          r.states_txy[3 * out] = t;
+          r.states_txy[3 * out + 1] = cell % dimx;
+          r.states_txy[3 * out + 2] = cell / dimx;
+        }
+        if (hasAction) {
+          if (r.actions) r.actions[out] = action;
+          if (r.action_costs) r.action_costs[out] = cost;
+        }
+      } else {
+        trunc = true;
+      }
+      out += 1;
+    };
+    for (int k = 0; k + 1 < nRaw; ++k) {
+      const int c0 = raw[k] & 0xFFFF, g0 = raw[k] >> 16, c1 = raw[k + 1] & 0xFFFF, g1 = raw[k + 1] >> 16;
+      const int motion = actionFromDelta(c1 % dimx - c0 % dimx, c1 / dimx - c0 / dimx);
+      const int waitTime = (g1 - g0) - 1;
+      if (waitTime == 0) {
+        emit(c0, g0, motion, g1 - g0, true);
+      } else {
+        emit(c0, g0, MRP_LL_ACT_WAIT, waitTime, true);
+        emit(c0, g0 + waitTime, motion, 1, true);
+      }
+    }
+    if (nRaw > 0) emit(raw[nRaw - 1] & 0xFFFF, raw[nRaw - 1] >> 16, 0, 0, false);
+    r.n_states = out;
+    if (trunc && (r.states_txy || r.actions)) r.status = MRP_LL_PATH_TRUNCATED;
+    return;
+  }
   if (d.status == mrp::ST_OK) {
     int n = d.n_states;
     int lim = std::min(n, r.states_cap);
@@ -414,6 +542,8 @@ void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool r
     if (r.actions)
       for (int k = 0; k + 1 < n && k < r.states_cap; ++k)
         r.actions[k] = actionFromDelta((p[k + 1] & 0xFF) - (p[k] & 0xFF), (p[k + 1] >> 8) - (p[k] >> 8));
+    if (r.action_costs)
+      for (int k = 0; k + 1 < n && k < r.states_cap; ++k) r.action_costs[k] = 1;
     if ((r.states_txy || r.actions) && r.states_cap < n) r.status = MRP_LL_PATH_TRUNCATED;
   }
 }
@@ -704,7 +834,8 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs,
     PathSinkSlot ps{g.paths + static_cast<size_t>(slot) * Ring::kSlotPathHalfs, slot * Ring::kSlotPathHalfs,
                     Ring::kSlotPathHalfs};
     DevJob d;
-    if (!packJob(ctx, jobs[i], cs, ps, d)) {  // also: constraint list / path table larger than a ring slot
+    if (jobs[i].algo == MRP_LL_SIPP || !packJob(ctx, jobs[i], cs, ps, d)) {  // SIPP is batch-mode only; also:
+      // constraint list / path table larger than a ring slot
       trivialRejectedJob(ctx, d);
       st.state[i] = 2;
     }
@@ -827,6 +958,15 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
   t.userResults = results;
   t.rejected.assign(nJobs, 0);
   t.allocFailed = false;
+  {
+    int nSipp = 0;
+    for (int i = 0; i < nJobs; ++i) nSipp += jobs[i].algo == MRP_LL_SIPP ? 1 : 0;
+    if (nSipp != 0 && nSipp != nJobs) {
+      ctx->err = "mrp_ll_submit: a batch holds either MRP_LL_SIPP jobs or A-star jobs, not both";
+      return MRP_LL_E_INVALID;
+    }
+    t.sipp = nSipp != 0;
+  }
   t.jobs.clear();
   t.cons.clear();
   t.paths.clear();
@@ -836,6 +976,10 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
     ConsSinkBuf cs{t.cons};
     PathSinkBuf ps{t.paths};
     bool ok = packJob(ctx, jobs[i], cs, ps, t.jobs.host[i]);
+    if (t.sipp) {
+      if (static_cast<int>(t.jobDimx.size()) < nJobs) t.jobDimx.resize(nJobs);
+      t.jobDimx[i] = ok ? static_cast<int32_t>(t.jobs.host[i].dimx) : 1;
+    }
     if (cs.failed || ps.failed) t.allocFailed = true;
     if (!ok) {
       // rejected: give the device a trivially capped job and remember the rejection
@@ -876,7 +1020,10 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
   uint32_t grid = std::min<uint32_t>(static_cast<uint32_t>(nJobs), static_cast<uint32_t>(ctx->opt.slots));
   t.queueBase += static_cast<uint32_t>(nJobs) + grid;  // every workgroup takes one ticket past the end when it exits
   HIPCHK(ctx, hipEventRecord(t.evK0, t.stream));
-  HIPCHK(ctx, mrp_ll_launch(&P, grid, ldsBytes, t.stream));
+  if (t.sipp)
+    HIPCHK(ctx, mrp_ll_launch_sipp(&P, grid, t.stream));
+  else
+    HIPCHK(ctx, mrp_ll_launch(&P, grid, ldsBytes, t.stream));
   HIPCHK(ctx, hipEventRecord(t.evK1, t.stream));
   ctx->stats.launches += 1;
   return MRP_LL_SUCCESS;
@@ -914,7 +1061,7 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
   auto unpackT0 = std::chrono::steady_clock::now();
   for (int i = 0; i < t.nJobs; ++i)
     unpackResult(ctx, t.results.host[i], t.outPaths.host + static_cast<size_t>(i) * outStride, t.rejected[i] != 0,
-                 t.userResults[i]);
+                 t.userResults[i], t.sipp, t.sipp ? t.jobDimx[i] : 0);
   ctx->stats.unpack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - unpackT0).count();
   return MRP_LL_SUCCESS;
 }

@@ -15,7 +15,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MRP_LL_LIB") or os.path.join(_PKG, "lib", "libmrp_ll.so")
 
-ASTAR, ASTAR_EPS = 0, 1
+ASTAR, ASTAR_EPS, SIPP = 0, 1, 2
 OK, NO_SOLUTION, CAP_EXPANSIONS, CAP_NODES, CAP_HORIZON, BAD_JOB, PATH_TRUNCATED, CAP_FOCAL = range(8)
 ACTION_NAMES = ["Up", "Down", "Left", "Right", "Wait"]  # example/ecbs.cpp:49-55
 
@@ -35,13 +35,16 @@ class mrp_ll_job(ctypes.Structure):
                 ("n_vertex_constraints", ctypes.c_int32), ("vertex_constraints", I32P),
                 ("n_edge_constraints", ctypes.c_int32), ("edge_constraints", I32P),
                 ("n_agents", ctypes.c_int32), ("path_len", I32P), ("path_xy", ctypes.POINTER(I32P)),
-                ("max_expansions", ctypes.c_int64)]
+                ("max_expansions", ctypes.c_int64),
+                ("n_collision_locations", ctypes.c_int32), ("collision_xy", I32P), ("collision_count", I32P),
+                ("collision_intervals", I32P)]
 
 
 class mrp_ll_result(ctypes.Structure):
     _fields_ = [("status", ctypes.c_int32), ("cost", ctypes.c_int32), ("fmin", ctypes.c_int32),
                 ("n_states", ctypes.c_int32), ("expanded", ctypes.c_int64), ("states_txy", I32P),
-                ("actions", I32P), ("states_cap", ctypes.c_int32), ("tier", ctypes.c_int32)]
+                ("actions", I32P), ("states_cap", ctypes.c_int32), ("tier", ctypes.c_int32),
+                ("action_costs", I32P)]
 
 
 class mrp_ll_stats(ctypes.Structure):
@@ -116,6 +119,7 @@ class LLJob:
     edge_constraints: Sequence[Sequence[int]] = ()     # (time, x1, y1, x2, y2)
     ctx_paths: Sequence[Sequence[Sequence[int]]] = ()  # per agent [[x, y], ...]; [] = empty path
     max_expansions: int = -1
+    collision_intervals: Sequence[Sequence[int]] = ()  # SIPP: [x, y, start, end] (grouped per location, in order)
 
 
 @dataclass
@@ -128,6 +132,7 @@ class LLResult:
     states: List[List[int]] = field(default_factory=list)   # [t, x, y]
     actions: List[int] = field(default_factory=list)
     tier: int = 0
+    action_costs: List[int] = field(default_factory=list)
 
 
 class LowLevelEngine:
@@ -172,6 +177,7 @@ class LowLevelEngine:
         keep = []
         states = np.zeros((max(n, 1), cap, 3), dtype=np.int32)
         actions = np.zeros((max(n, 1), cap), dtype=np.int32)
+        costs = np.zeros((max(n, 1), cap), dtype=np.int32)
         for i, j in enumerate(jobs):
             cj = cjobs[i]
             cj.map_id, cj.algo, cj.w, cj.agent_idx = j.map_id, j.algo, j.w, j.agent_idx
@@ -188,16 +194,33 @@ class LowLevelEngine:
             cj.path_len = plen.ctypes.data_as(I32P)
             cj.path_xy = ctypes.cast(pptr, ctypes.POINTER(I32P))
             cj.max_expansions = j.max_expansions
+            if j.collision_intervals:
+                locs, counts, ivs = [], [], []
+                for x, y, a, b in j.collision_intervals:  # consecutive entries of one location form one list
+                    if locs and locs[-1] == [x, y]:
+                        counts[-1] += 1
+                    else:
+                        locs.append([x, y])
+                        counts.append(1)
+                    ivs.append([a, b])
+                cxy = np.ascontiguousarray(np.asarray(locs, dtype=np.int32))
+                ccnt = np.ascontiguousarray(np.asarray(counts, dtype=np.int32))
+                civ = np.ascontiguousarray(np.asarray(ivs, dtype=np.int32))
+                cj.n_collision_locations = len(locs)
+                cj.collision_xy, cj.collision_count = cxy.ctypes.data_as(I32P), ccnt.ctypes.data_as(I32P)
+                cj.collision_intervals = civ.ctypes.data_as(I32P)
+                keep.append((cxy, ccnt, civ))
             keep.append((vc, ec, plen, parr, pptr))
             cres[i].states_txy = states[i].ctypes.data_as(I32P)
             cres[i].actions = actions[i].ctypes.data_as(I32P)
             cres[i].states_cap = cap
-        return cjobs, cres, (keep, states, actions)
+            cres[i].action_costs = costs[i].ctypes.data_as(I32P)
+        return cjobs, cres, (keep, states, actions, costs)
 
     def search_batch(self, jobs: Sequence[LLJob], states_cap: Optional[int] = None) -> List[LLResult]:
         n = len(jobs)
         cap = states_cap or self.max_horizon
-        cjobs, cres, (keep, states, actions) = self._marshal(jobs, cap)
+        cjobs, cres, (keep, states, actions, costs) = self._marshal(jobs, cap)
         self._check(self._lib.mrp_ll_search_batch(self._h, n, cjobs, cres), "mrp_ll_search_batch")
         out = []
         for i in range(n):
@@ -206,7 +229,8 @@ class LowLevelEngine:
             m = min(ns, cap)
             out.append(LLResult(status=r.status, success=r.status in (OK, PATH_TRUNCATED), cost=r.cost, fmin=r.fmin,
                                 expanded=r.expanded, states=states[i, :m].tolist(),
-                                actions=actions[i, :max(m - 1, 0)].tolist(), tier=r.tier))
+                                actions=actions[i, :max(m - 1, 0)].tolist(), tier=r.tier,
+                                action_costs=costs[i, :max(m - 1, 0)].tolist()))
         return out
 
     def session_begin(self, workgroups: int = 0):

@@ -204,6 +204,74 @@ def test_edge_cases(engine, oracle_mod):
     assert bad[0].status == ll.BAD_JOB
 
 
+def test_sipp_reference_case_and_random_jobs(engine, oracle_mod, ref_tests):
+    """MRP_LL_SIPP (sipp.hpp) against the oracle: test/sipp_1.yaml (test/test_sipp.py:16-21) and random single-agent
+    jobs with random collision intervals on a 16x16 grid (waits, blocked goals, several intervals per cell)."""
+    import random
+    from libmultirobotplanning_amd import ll
+    s = ref_tests["sipp_1"]
+    mid = engine.upload_map(s["dimx"], s["dimy"], s["obstacles"])
+    r = engine.search_batch([ll.LLJob(map_id=mid, algo=ll.SIPP, start=s["start"], goal=s["goal"],
+                                      collision_intervals=s["collision_intervals"])])[0]
+    assert r.success and len(r.states) == s["n_states"]
+    assert [r.states[-1][1], r.states[-1][2], r.states[-1][0]] == s["last"]
+    o_states, _ = oracle_mod.sipp_single(s["dimx"], s["dimy"], s["obstacles"], s["start"], s["goal"],
+                                         s["collision_intervals"])
+    assert [[x, y, t] for t, x, y in r.states] == o_states
+    assert ll.ACTION_NAMES[r.actions[3]] == "Wait" and r.action_costs[3] == 5
+
+    rng = random.Random(7)
+    dim = 16
+    obst = [[rng.randrange(dim), rng.randrange(dim)] for _ in range(40)]
+    obst = [list(c) for c in {tuple(c) for c in obst}]
+    mid2 = engine.upload_map(dim, dim, obst)
+    free = [[x, y] for x in range(dim) for y in range(dim) if [x, y] not in obst]
+    jobs, specs = [], []
+    for case in range(150):
+        st, go = rng.choice(free), rng.choice(free)
+        cis = []
+        for _ in range(rng.randrange(0, 60)):
+            c = rng.choice(free)
+            t0 = rng.randrange(0, 40)
+            n_iv = rng.randrange(1, 4)
+            t = t0
+            for _ in range(n_iv):                      # non-overlapping intervals of one location, in order
+                a = t + rng.randrange(0, 6)
+                b = a + rng.randrange(0, 5)
+                if rng.random() < 0.03:
+                    b = 2 ** 31 - 1
+                cis.append([c[0], c[1], a, b])
+                t = b + 2
+                if b == 2 ** 31 - 1:
+                    break
+        # one list per location, as the reference's setCollisionIntervals receives it
+        cis.sort(key=lambda v: (v[0], v[1]))
+        merged = []
+        for v in cis:
+            if merged and merged[-1][0][:2] == v[:2]:
+                if all(v[2] > w[3] for w in merged[-1]):
+                    merged[-1].append(v)
+            else:
+                merged.append([v])
+        cis = [v for grp in merged for v in grp]
+        specs.append((st, go, cis))
+        jobs.append(ll.LLJob(map_id=mid2, algo=ll.SIPP, start=st, goal=go, collision_intervals=cis,
+                             max_expansions=20000))
+    res = engine.search_batch(jobs)
+    n_ok = 0
+    for (st, go, cis), r in zip(specs, res):
+        o_states, o_exp = oracle_mod.sipp_single(dim, dim, obst, st, go, cis)
+        if r.status == ll.CAP_EXPANSIONS:
+            continue
+        assert r.success == (len(o_states) > 0), (st, go)
+        if r.success:
+            n_ok += 1
+            assert [[x, y, t] for t, x, y in r.states] == o_states, (st, go, cis)
+            assert r.expanded == o_exp
+            assert r.cost == o_states[-1][2]
+    assert n_ok > 60
+
+
 def test_stats_report_kernel_time(engine):
     st = engine.stats()
     assert st["launches"] > 0 and st["kernel_ms"] > 0 and st["expansions"] > 0
