@@ -89,6 +89,25 @@ int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* opt, int32_t n_i
 int mrp_hl_solver_ll_stats(mrp_hl_solver* s, mrp_ll_stats* out, int32_t reset); /* summed over its engines */
 const char* mrp_hl_solver_last_error(const mrp_hl_solver* s);
 
+/* Prioritized planning with SIPP (example/mapf_prioritized_sipp.cpp:214-270): agents are planned one after the other,
+ * each against the collision intervals left by the agents before it; an agent that cannot be planned is skipped.
+ * Every round plans the next agent of ALL instances in one MRP_LL_SIPP batch.
+ * Per instance: cost = statistics.cost (sum over planned agents); planned[a] in {0,1}; n_states[a];
+ * states_xyt [n_agents][state_cap][3] = x, y, t (the schedule the reference writes, :256-260). */
+typedef struct mrp_hl_sipp_solution {
+  int64_t cost;
+  int64_t low_level_expanded;
+  int32_t n_planned;
+  int32_t reserved;
+  int32_t* planned;     /* caller buffer [n_agents] */
+  int32_t* n_states;    /* caller buffer [n_agents] */
+  int32_t* states_xyt;  /* caller buffer [n_agents][state_cap][3] or NULL */
+  int32_t state_cap;
+  int32_t reserved2;
+} mrp_hl_sipp_solution;
+int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t n_instances, const mrp_hl_instance* instances,
+                                   mrp_hl_sipp_solution* solutions, mrp_hl_batch_stats* stats);
+
 /* Seeded synthetic "32x32_obst204-shaped" instance: obstacles uniform without replacement, agents with
  * distinct starts and distinct goals, every goal in the start's 4-connected free component. splitmix64(seed).
  * Buffers: obstacles_xy [n_obstacles][2], starts_xy / goals_xy [n_agents][2]. Returns 0, or -1 if impossible. */

@@ -5,7 +5,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <thread>
@@ -486,6 +488,135 @@ int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* optIn, int32_t n
   }
   for (int32_t k = 0; k < nInst; ++k) st.solved += solutions[k].status == MRP_HL_SOLVED ? 1 : 0;
   if (stats) *stats = st;
+  return MRP_LL_SUCCESS;
+}
+
+int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl_instance* instances,
+                                   mrp_hl_sipp_solution* sols, mrp_hl_batch_stats* stats) {
+  if (!s || nInst < 0 || (nInst > 0 && (!instances || !sols))) return MRP_LL_E_INVALID;
+  mrp_ll_ctx* ctx = s->engines[0];
+  const int32_t horizon = s->llOpt.max_horizon > 0 ? s->llOpt.max_horizon : 512;
+  struct Iv { int32_t s, e; };
+  struct Prio {
+    int32_t mapId = -1, agent = 0;
+    std::map<std::pair<int32_t, int32_t>, std::vector<Iv>> all;  // allCollisionIntervals (:215), ordered by (x, y)
+    std::vector<int32_t> xy, cnt, ivs;                            // flattened for the job of the current round
+  };
+  std::vector<Prio> st(nInst);
+  for (int32_t k = 0; k < nInst; ++k) {
+    const mrp_hl_instance& in = instances[k];
+    int rc = mrp_ll_upload_map(ctx, in.dimx, in.dimy, in.n_obstacles, in.obstacles_xy, &st[k].mapId);
+    if (rc != MRP_LL_SUCCESS) {
+      s->err = std::string("mrp_ll_upload_map: ") + mrp_ll_last_error(ctx);
+      return rc;
+    }
+    sols[k].cost = 0;
+    sols[k].low_level_expanded = 0;
+    sols[k].n_planned = 0;
+  }
+  mrp_hl_batch_stats bs;
+  std::memset(&bs, 0, sizeof(bs));
+  auto t0 = std::chrono::steady_clock::now();
+  const int32_t cap = std::max(horizon, 64);
+  std::vector<mrp_ll_job> jobs;
+  std::vector<mrp_ll_result> results;
+  std::vector<int32_t> owner, statesPool;
+  for (;;) {
+    jobs.clear();
+    owner.clear();
+    for (int32_t k = 0; k < nInst; ++k) {
+      Prio& p = st[k];
+      const mrp_hl_instance& in = instances[k];
+      if (p.agent >= in.n_agents) continue;
+      p.xy.clear();
+      p.cnt.clear();
+      p.ivs.clear();
+      for (const auto& kv : p.all) {  // sipp.setCollisionIntervals(location, intervals) for every location (:224-226)
+        p.xy.push_back(kv.first.first);
+        p.xy.push_back(kv.first.second);
+        p.cnt.push_back(static_cast<int32_t>(kv.second.size()));
+        for (const Iv& iv : kv.second) {
+          p.ivs.push_back(iv.s);
+          p.ivs.push_back(iv.e);
+        }
+      }
+      mrp_ll_job j;
+      std::memset(&j, 0, sizeof(j));
+      j.map_id = p.mapId;
+      j.algo = MRP_LL_SIPP;
+      j.w = 1.0f;
+      j.start_x = in.starts_xy[2 * p.agent];
+      j.start_y = in.starts_xy[2 * p.agent + 1];
+      j.goal_x = in.goals_xy[2 * p.agent];
+      j.goal_y = in.goals_xy[2 * p.agent + 1];
+      j.max_expansions = -1;
+      j.n_collision_locations = static_cast<int32_t>(p.cnt.size());
+      j.collision_xy = p.xy.data();
+      j.collision_count = p.cnt.data();
+      j.collision_intervals = p.ivs.data();
+      jobs.push_back(j);
+      owner.push_back(k);
+    }
+    if (jobs.empty()) break;
+    results.assign(jobs.size(), mrp_ll_result());
+    statesPool.resize(jobs.size() * static_cast<size_t>(cap) * 3);
+    for (size_t q = 0; q < jobs.size(); ++q) {
+      std::memset(&results[q], 0, sizeof(mrp_ll_result));
+      results[q].states_txy = statesPool.data() + q * static_cast<size_t>(cap) * 3;
+      results[q].states_cap = cap;
+    }
+    int rc = mrp_ll_search_batch(ctx, static_cast<int32_t>(jobs.size()), jobs.data(), results.data());
+    if (rc != MRP_LL_SUCCESS) {
+      s->err = std::string("mrp_ll_search_batch: ") + mrp_ll_last_error(ctx);
+      return rc;
+    }
+    bs.rounds += 1;
+    bs.ll_searches += static_cast<int64_t>(jobs.size());
+    for (size_t q = 0; q < jobs.size(); ++q) {
+      const int32_t k = owner[q];
+      Prio& p = st[k];
+      mrp_hl_sipp_solution& so = sols[k];
+      const mrp_ll_result& r = results[q];
+      const int32_t a = p.agent;
+      so.low_level_expanded += r.expanded;
+      bs.ll_expansions += r.expanded;
+      if (r.status != MRP_LL_OK && r.status != MRP_LL_NO_SOLUTION) {
+        s->err = "prioritized SIPP: low-level capacity status " + std::to_string(r.status);
+        return MRP_LL_E_DEVICE;
+      }
+      const bool ok = r.status == MRP_LL_OK;
+      if (so.planned) so.planned[a] = ok ? 1 : 0;
+      if (so.n_states) so.n_states[a] = ok ? r.n_states : 0;
+      if (ok) {
+        so.n_planned += 1;
+        so.cost += r.cost;
+        const int32_t* S = r.states_txy;  // [t, x, y]
+        // update collision intervals (:237-246): one interval per maximal stay on a cell
+        int32_t lx = S[1], ly = S[2], lt = S[0];
+        for (int32_t i = 1; i < r.n_states; ++i) {
+          if (S[3 * i + 1] != lx || S[3 * i + 2] != ly) {
+            p.all[{lx, ly}].push_back(Iv{lt, S[3 * i] - 1});
+            lx = S[3 * i + 1];
+            ly = S[3 * i + 2];
+            lt = S[3 * i];
+          }
+        }
+        const int32_t last = r.n_states - 1;
+        p.all[{S[3 * last + 1], S[3 * last + 2]}].push_back(Iv{S[3 * last], INT32_MAX});
+        if (so.states_xyt)
+          for (int32_t i = 0; i < r.n_states && i < so.state_cap; ++i) {
+            int32_t* dst = so.states_xyt + (static_cast<size_t>(a) * so.state_cap + i) * 3;
+            dst[0] = S[3 * i + 1];
+            dst[1] = S[3 * i + 2];
+            dst[2] = S[3 * i];
+          }
+      }
+      p.agent += 1;
+    }
+  }
+  bs.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int32_t k = 0; k < nInst; ++k) bs.solved += sols[k].n_planned == instances[k].n_agents ? 1 : 0;
+  if (stats) *stats = bs;
   return MRP_LL_SUCCESS;
 }
 

@@ -43,7 +43,13 @@ class mrp_hl_batch_stats(ctypes.Structure):
                 ("ll_call_seconds", ctypes.c_double), ("consume_seconds", ctypes.c_double)]
 
 
-EXPORTS = ["mrp_hl_solve_batch", "mrp_hl_solver_create", "mrp_hl_solver_destroy", "mrp_hl_solver_solve",
+class mrp_hl_sipp_solution(ctypes.Structure):
+    _fields_ = [("cost", ctypes.c_int64), ("low_level_expanded", ctypes.c_int64), ("n_planned", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("planned", I32P), ("n_states", I32P), ("states_xyt", I32P),
+                ("state_cap", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
+
+
+EXPORTS = ["mrp_hl_solver_prioritized_sipp", "mrp_hl_solve_batch", "mrp_hl_solver_create", "mrp_hl_solver_destroy", "mrp_hl_solver_solve",
            "mrp_hl_solver_ll_stats", "mrp_hl_solver_last_error", "mrp_hl_generate_instance"]
 
 _lib = None
@@ -75,6 +81,10 @@ def load_library(path: Optional[str] = None):
         lib.mrp_hl_solve_batch.argtypes = [ctypes.c_int32, ctypes.POINTER(mrp_hl_options), ctypes.c_int32,
                                            ctypes.POINTER(mrp_hl_instance), ctypes.POINTER(mrp_hl_solution),
                                            ctypes.POINTER(mrp_hl_batch_stats)]
+        lib.mrp_hl_solver_prioritized_sipp.restype = ctypes.c_int
+        lib.mrp_hl_solver_prioritized_sipp.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(mrp_hl_instance),
+                                                       ctypes.POINTER(mrp_hl_sipp_solution),
+                                                       ctypes.POINTER(mrp_hl_batch_stats)]
         lib.mrp_hl_generate_instance.restype = ctypes.c_int
         lib.mrp_hl_generate_instance.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int32, I32P, I32P, I32P]
@@ -164,6 +174,41 @@ class BatchSolver:
         stats = dict(wall_seconds=st.wall_seconds, rounds=st.rounds, ll_searches=st.ll_searches,
                      ll_expansions=st.ll_expansions, solved=st.solved, build_seconds=st.build_seconds,
                      ll_call_seconds=st.ll_call_seconds, consume_seconds=st.consume_seconds)
+        return out, stats
+
+    def prioritized_sipp(self, instances: Sequence[Dict], state_cap: int = 512):
+        """example/mapf_prioritized_sipp.cpp for a batch of instances: every round plans the next agent of all of them."""
+        n = len(instances)
+        cin = (mrp_hl_instance * max(n, 1))()
+        csol = (mrp_hl_sipp_solution * max(n, 1))()
+        keep, bufs = [], []
+        for i, inst in enumerate(instances):
+            ob = np.ascontiguousarray(np.asarray(inst["obstacles"], dtype=np.int32).reshape(-1, 2))
+            st = np.ascontiguousarray(np.asarray(inst["starts"], dtype=np.int32).reshape(-1, 2))
+            go = np.ascontiguousarray(np.asarray(inst["goals"], dtype=np.int32).reshape(-1, 2))
+            keep.append((ob, st, go))
+            c = cin[i]
+            c.dimx, c.dimy = inst["dimx"], inst["dimy"]
+            c.n_obstacles, c.obstacles_xy = len(ob), ob.ctypes.data_as(I32P)
+            c.n_agents, c.starts_xy, c.goals_xy = len(st), st.ctypes.data_as(I32P), go.ctypes.data_as(I32P)
+            pl = np.zeros(len(st), dtype=np.int32)
+            ns = np.zeros(len(st), dtype=np.int32)
+            sx = np.zeros((len(st), state_cap, 3), dtype=np.int32)
+            bufs.append((pl, ns, sx))
+            csol[i].planned, csol[i].n_states = pl.ctypes.data_as(I32P), ns.ctypes.data_as(I32P)
+            csol[i].states_xyt, csol[i].state_cap = sx.ctypes.data_as(I32P), state_cap
+        st = mrp_hl_batch_stats()
+        rc = self._lib.mrp_hl_solver_prioritized_sipp(self._h, n, cin, csol, ctypes.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"mrp_hl_solver_prioritized_sipp failed rc={rc}: "
+                               f"{self._lib.mrp_hl_solver_last_error(self._h).decode()}")
+        out = []
+        for i in range(n):
+            pl, ns, sx = bufs[i]
+            out.append(dict(cost=csol[i].cost, expanded=csol[i].low_level_expanded, n_planned=csol[i].n_planned,
+                            planned=pl.tolist(), schedules=[sx[a, :ns[a]].tolist() for a in range(len(pl))]))
+        stats = dict(wall_seconds=st.wall_seconds, rounds=st.rounds, ll_searches=st.ll_searches,
+                     ll_expansions=st.ll_expansions, solved=st.solved)
         return out, stats
 
     def ll_stats(self, reset: bool = False) -> dict:

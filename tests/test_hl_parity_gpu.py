@@ -113,3 +113,23 @@ def test_synthetic_bench_workload_matches_oracle(solver, oracle_mod):
             for i in range(len(paths)):
                 for j in range(i + 1, len(paths)):
                     assert not (cells[i] == nxt[j] and nxt[i] == cells[j])
+
+
+def test_prioritized_sipp_known_answers_and_64x64(solver, oracle_mod, ref_tests):
+    """example/mapf_prioritized_sipp.cpp on the GPU: the reference's own fixtures (test_mapf_prioritized_sipp.py:24-52)
+    and config 5's shape (64x64, 10 % obstacles) against the oracle — cost, planned flags and every schedule."""
+    from libmultirobotplanning_amd import hl
+    exp = ref_tests["prioritized_sipp"]
+    names = list(exp["cost"].keys())
+    res, _ = solver.prioritized_sipp([ref_tests["mapf"][n] for n in names])
+    assert [r["cost"] for r in res] == [exp["cost"][n] for n in names]
+    b = res[names.index("mapf_simple1b")]
+    assert len(b["schedules"][0]) == exp["simple1b_lens"]["agent0"] and len(b["schedules"][1]) == 0
+    insts = [hl.generate_instance(64000 + k, 64, 64, 410, 60) for k in range(6)]
+    insts += [hl.generate_instance(32000 + k, 32, 32, 204, 100) for k in range(4)]
+    res, stats = solver.prioritized_sipp(insts)
+    for inst, r in zip(insts, res):
+        o = oracle_mod.prioritized_sipp(inst)
+        assert (r["cost"], r["planned"], r["expanded"]) == (o["cost"], o["planned"], o["expanded"])
+        assert r["schedules"] == o["schedules"]
+    assert stats["rounds"] == 100
