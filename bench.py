@@ -41,12 +41,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=8192, help="instances per GPU per step")
+    ap.add_argument("--instances", type=int, default=16384, help="instances per GPU per step")
     ap.add_argument("--agents", type=int, default=10)
     ap.add_argument("--threads", type=int, default=0, help="host worker threads per GPU (0 = auto)")
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--lds-nodes", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=1536, help="instances of step 0 timed on the CPU oracle (rank 0)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="instances of step 0 timed on the CPU oracle (rank 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-ll-expansions", type=int, default=50000,
                     help="harness cap per instance (the reference has none and never returns on infeasible inputs); "

@@ -126,6 +126,7 @@ typedef struct mrp_ll_stats {
   int64_t migrated;          /* searches that left the LDS tier                                               */
   double kernel_ms;          /* sum of hipEvent-measured kernel durations (on the launching stream)           */
   double h2d_ms, d2h_ms;     /* hipEvent-measured copy durations                                              */
+  double session_busy_ms, session_idle_ms; /* session mode: sum over resident workgroups of time in jobs / waiting */
   double pack_ms, unpack_ms; /* host time spent packing jobs (mrp_ll_submit) / unpacking results (mrp_ll_wait)           */
   int64_t prof[8];           /* diagnostic (-DMRP_LL_TRACE library only, else 0): shader cycles in walk, pops,  */
                              /* pushes, successor generation, row init, whole job; #walks; nodes visited by walks */

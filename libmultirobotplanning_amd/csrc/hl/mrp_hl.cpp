@@ -195,6 +195,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   std::vector<const int32_t*> pathPtrPool;
   std::vector<size_t> poolOff;
 
+  const bool timing = std::getenv("MRP_HL_TIMING") != nullptr;
+  auto tg0 = std::chrono::steady_clock::now();
   if (mrp_ll_session_begin(ctx, workgroups) != MRP_LL_SUCCESS) {
     out.err = std::string("mrp_ll_session_begin: ") + mrp_ll_last_error(ctx);
     return;
@@ -255,6 +257,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     return 1;
   };
 
+  auto tg1 = std::chrono::steady_clock::now();
   std::vector<size_t> backlog;
   size_t nInflight = 0;
   std::vector<int32_t> doneTickets(4096);
@@ -266,6 +269,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   }
   bool failed = false;
   auto t0 = std::chrono::steady_clock::now();
+  auto tg2 = t0;
   uint64_t idleSpins = 0;
   auto nowS = []() { return std::chrono::steady_clock::now(); };
   auto secsS = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -341,8 +345,17 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       }
     }
   }
+  auto tg3 = std::chrono::steady_clock::now();
   if (mrp_ll_session_end(ctx) != MRP_LL_SUCCESS && out.err.empty())
     out.err = std::string("mrp_ll_session_end: ") + mrp_ll_last_error(ctx);
+  auto tg4 = std::chrono::steady_clock::now();
+  if (timing) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    std::fprintf(stderr, "[mrp_hl] group of %zu: session_begin %.2f ms, build instances %.2f ms, loop %.2f ms, session_end %.2f ms\n", n,
+                 ms(tg0, tg1), ms(tg1, tg2), ms(tg2, tg3), ms(tg3, tg4));
+  }
   if (failed) return;
   for (size_t k = 0; k < n; ++k) {
     const Instance& I = *live[k].inst;
@@ -424,6 +437,8 @@ int mrp_hl_solver_ll_stats(mrp_hl_solver* s, mrp_ll_stats* out, int32_t reset) {
     out->h2d_ms += st.h2d_ms;
     out->d2h_ms += st.d2h_ms;
     out->pack_ms += st.pack_ms;
+    out->session_busy_ms += st.session_busy_ms;
+    out->session_idle_ms += st.session_idle_ms;
     out->unpack_ms += st.unpack_ms;
     for (int q = 0; q < 8; ++q) out->prof[q] += st.prof[q];
     if (reset) mrp_ll_reset_stats(e);

@@ -84,6 +84,9 @@ struct LaunchParams {
   uint32_t* ring_done;        // [ring_size] device writes g when that job's result is in results[slot]
   uint32_t* ring_stop;        // host sets != 0 to end the session
   uint32_t* ring_head;        // host: number of tickets published so far (what waiting workgroups poll)
+  uint32_t* comp_ring;        // host [ring_size]: completion queue, entry = (generation << 11) | slot
+  uint32_t* comp_count;       // device: completions so far (index into comp_ring)
+  unsigned long long* sess_ticks; // device [2]: sum over workgroups of 100 MHz ticks spent in jobs / waiting for jobs
   uint32_t ring_size;
   uint32_t ring_idle_limit_s; // a workgroup that waited this long for a job exits (safety net if the host died)
 };

@@ -917,6 +917,7 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
   const uint32_t lane = threadIdx.x;
   uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
   const uint64_t idleLimit = (uint64_t)P.ring_idle_limit_s * 100000000ull;  // s_memrealtime ticks at 100 MHz
+  uint64_t busyTicks = 0, idleTicks = 0;
   for (;;) {
     uint32_t t = atomicAdd(P.queue_head, lane == 0 ? 1u : 0u);
     t = rfl(t);
@@ -942,12 +943,22 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
       if (naps > 48) naps = 48;
       for (uint32_t q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(64);
     }
+    const uint64_t t1 = __builtin_amdgcn_s_memrealtime();
+    idleTicks += t1 - t0;
     if (stop) break;
     processJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, smem, arenaSlot, jobS,
                resS);
     __threadfence_system();
     __hip_atomic_store(P.ring_done + slot, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring
+    uint32_t cidx = atomicAdd(P.comp_count, lane == 0 ? 1u : 0u);
+    cidx = rfl(cidx);
+    __hip_atomic_store(P.comp_ring + (cidx % P.ring_size), ((cidx / P.ring_size + 1) << 11) | slot, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    busyTicks += __builtin_amdgcn_s_memrealtime() - t1;
   }
+  atomicAdd(P.sess_ticks + 0, lane == 0 ? (unsigned long long)busyTicks : 0ull);
+  atomicAdd(P.sess_ticks + 1, lane == 0 ? (unsigned long long)idleTicks : 0ull);
 }
 
 }  // namespace mrp

@@ -103,7 +103,10 @@ struct Ring {
   static constexpr uint32_t kSlotConsWords = 1024;        // 4 KB of constraint words per job
   static constexpr uint32_t kSlotPathHalfs = 16 * 1024;   // 32 KB path table per job
   uint8_t* block = nullptr;        // one coherent allocation holding everything below
-  uint32_t *state = nullptr, *done = nullptr, *stop = nullptr, *headWord = nullptr;
+  uint32_t *state = nullptr, *done = nullptr, *stop = nullptr, *headWord = nullptr, *compRing = nullptr;
+  uint32_t* compCountDev = nullptr;  // device counter
+  unsigned long long* ticksDev = nullptr;  // device [2]: busy / idle ticks of the session's workgroups
+  uint64_t compCursor = 0;           // next completion-queue entry the host expects
   DevJob* jobs = nullptr;
   DevResult* results = nullptr;
   uint16_t* outPaths = nullptr;
@@ -630,6 +633,8 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
   if (ctx->ring.ev0) (void)hipEventDestroy(ctx->ring.ev0);
   if (ctx->ring.ev1) (void)hipEventDestroy(ctx->ring.ev1);
   if (ctx->ring.block) (void)hipHostFree(ctx->ring.block);
+  if (ctx->ring.compCountDev) (void)hipFree(ctx->ring.compCountDev);
+  if (ctx->ring.ticksDev) (void)hipFree(ctx->ring.ticksDev);
   for (auto& t : ctx->tickets) {
     if (t.inFlight && t.evK1) (void)hipEventSynchronize(t.evK1);
     if (t.stream) (void)hipStreamSynchronize(t.stream);
@@ -718,7 +723,7 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
       off += (bytes + 255) & ~size_t(255);
       return o;
     };
-    size_t oState = take(R * 4), oDone = take(R * 4), oStop = take(256), oHead = take(256), oJobs = take(R * sizeof(DevJob)),
+    size_t oState = take(R * 4), oDone = take(R * 4), oComp = take(R * 4), oStop = take(256), oHead = take(256), oJobs = take(R * sizeof(DevJob)),
            oRes = take(R * sizeof(DevResult)), oOut = take(static_cast<size_t>(R) * g.outStride * 2),
            oCons = take(static_cast<size_t>(R) * Ring::kSlotConsWords * 4),
            oPaths = take(static_cast<size_t>(R) * Ring::kSlotPathHalfs * 2);
@@ -728,6 +733,9 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
     g.done = reinterpret_cast<uint32_t*>(g.block + oDone);
     g.stop = reinterpret_cast<uint32_t*>(g.block + oStop);
     g.headWord = reinterpret_cast<uint32_t*>(g.block + oHead);
+    g.compRing = reinterpret_cast<uint32_t*>(g.block + oComp);
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&g.compCountDev), 256));
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&g.ticksDev), 256));
     g.jobs = reinterpret_cast<DevJob*>(g.block + oJobs);
     g.results = reinterpret_cast<DevResult*>(g.block + oRes);
     g.outPaths = reinterpret_cast<uint16_t*>(g.block + oOut);
@@ -738,6 +746,8 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   }
   std::memset(g.state, 0, R * 4);
   std::memset(g.done, 0, R * 4);
+  std::memset(g.compRing, 0, R * 4);
+  g.compCursor = 0;
   __atomic_store_n(g.stop, 0u, __ATOMIC_RELEASE);
   __atomic_store_n(g.headWord, 0u, __ATOMIC_RELEASE);
   g.head = 0;
@@ -763,6 +773,9 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   P.ring_done = static_cast<uint32_t*>(devPtr(g.done));
   P.ring_stop = static_cast<uint32_t*>(devPtr(g.stop));
   P.ring_head = static_cast<uint32_t*>(devPtr(g.headWord));
+  P.comp_ring = static_cast<uint32_t*>(devPtr(g.compRing));
+  P.comp_count = g.compCountDev;
+  P.sess_ticks = g.ticksDev;
   P.ring_size = R;
   P.ring_idle_limit_s = 20;
   uint32_t ldsBytes = 0;
@@ -771,6 +784,8 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   ctx->sessionRowWords = P.lds_row_words;
   g.grid = static_cast<uint32_t>(workgroups > 0 ? std::min(workgroups, ctx->opt.slots) : ctx->opt.slots);
   HIPCHK(ctx, hipMemsetAsync(t.queueHead, 0, 4, t.stream));  // session tickets count from 0
+  HIPCHK(ctx, hipMemsetAsync(g.compCountDev, 0, 4, t.stream));
+  HIPCHK(ctx, hipMemsetAsync(g.ticksDev, 0, 16, t.stream));
   t.queueBase = 0;
   HIPCHK(ctx, hipEventRecord(g.ev0, t.stream));
   HIPCHK(ctx, mrp_ll_launch_persistent(&P, g.grid, ldsBytes, t.stream));
@@ -789,6 +804,13 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
   HIPCHK(ctx, hipEventSynchronize(g.ev1));
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) ctx->stats.kernel_ms += ms;
+  {
+    unsigned long long tk[2] = {0, 0};
+    if (hipMemcpy(tk, g.ticksDev, 16, hipMemcpyDeviceToHost) == hipSuccess) {
+      ctx->stats.session_busy_ms += static_cast<double>(tk[0]) / 1e5;  // 100 MHz ticks
+      ctx->stats.session_idle_ms += static_cast<double>(tk[1]) / 1e5;
+    }
+  }
   g.active = false;
   // the device counter is past the published tickets: the next batch-mode launch starts from a clean base
   Ticket& t = ctx->tickets[0];
@@ -892,14 +914,15 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
   if (!g.active) return MRP_LL_E_INVALID;
   const uint32_t R = Ring::kSlots;
   int32_t n = 0;
-  // a slot may already be busy with ticket tk + R while the scan still passes the consumed ticket tk: compare numbers
-  auto occupies = [&](uint64_t tk) { return g.busy[tk % R] && g.slotTk[tk % R] == tk; };
-  while (g.tail < g.head && !occupies(g.tail)) g.tail += 1;
-  for (uint64_t tk = g.tail; tk < g.head && n < cap; ++tk) {
-    const uint32_t slot = static_cast<uint32_t>(tk % R);
-    if (!occupies(tk)) continue;
-    const uint32_t gen = static_cast<uint32_t>(tk / R) + 1;
-    if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != gen) continue;
+  // drain the completion queue: entry k holds (k / R + 1) << 11 | slot once the k-th finished job has been published
+  while (n < cap) {
+    const uint32_t e = __atomic_load_n(g.compRing + (g.compCursor % R), __ATOMIC_ACQUIRE);
+    if ((e >> 11) != static_cast<uint32_t>(g.compCursor / R) + 1) break;
+    g.compCursor += 1;
+    const uint32_t slot = e & 2047u;
+    if (!g.busy[slot]) continue;  // already consumed through mrp_ll_poll / mrp_ll_wait
+    // ... and if the slot has been re-used since, this entry is stale: only the occupant's own done word counts
+    if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != static_cast<uint32_t>(g.slotTk[slot] / R) + 1) continue;
     SessTicket& st = ctx->sess[g.slotTicket[slot]];
     const int32_t i = g.slotJob[slot];
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,

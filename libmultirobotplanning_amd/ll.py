@@ -50,7 +50,8 @@ class mrp_ll_result(ctypes.Structure):
 class mrp_ll_stats(ctypes.Structure):
     _fields_ = [("launches", ctypes.c_int64), ("jobs", ctypes.c_int64), ("expansions", ctypes.c_int64),
                 ("nodes_created", ctypes.c_int64), ("migrated", ctypes.c_int64), ("kernel_ms", ctypes.c_double),
-                ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("pack_ms", ctypes.c_double),
+                ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("session_busy_ms", ctypes.c_double),
+                ("session_idle_ms", ctypes.c_double), ("pack_ms", ctypes.c_double),
                 ("unpack_ms", ctypes.c_double), ("prof", ctypes.c_int64 * 8)]
 
 

@@ -1,0 +1,40 @@
+"""Secondary measurements for BASELINE.json configs 3 (CBS 8x8) and 5 (prioritized SIPP 64x64); not the contract bench."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import oracle
+from libmultirobotplanning_amd import hl
+s = hl.BatchSolver(device=0, n_threads=16, slots=512)
+out = {}
+# ---- config 3: CBS on 8x8_obst12-shaped synthetic instances, agents 4..10, cap 1e5 LL expansions per instance ----
+for agents, n in ((4, 4096), (6, 4096), (8, 2048)):
+    insts = [hl.generate_instance(800000 + 1000 * agents + k, 8, 8, 12, agents) for k in range(n)]
+    s.solve(insts[:256], algo=hl.CBS, max_ll_expansions=100000, want_paths=False)
+    res, st = s.solve(insts, algo=hl.CBS, max_ll_expansions=100000, want_paths=False)
+    m = min(n, 256)
+    t = e = 0; mism = 0
+    for inst, r in zip(insts[:m], res[:m]):
+        o = oracle.mapf_solve(oracle.CBS, inst, cap_total=100000)
+        t += o["elapsed_ns"] / 1e9; e += o["ll_expanded"]
+        if o["rc"] == 1 and (r["status"], r["cost"], r["hl_expanded"], r["ll_expanded"]) != (0, o["cost"], o["hl_expanded"], o["ll_expanded"]):
+            mism += 1
+    out["cbs_8x8_agents%d" % agents] = dict(instances=n, solved=st["solved"], gpu_exp_per_s=st["ll_expansions"] / st["wall_seconds"],
+                                            gpu_inst_per_s=n / st["wall_seconds"], cpu_exp_per_s=e / t, cpu_inst_per_s=m / t, mismatches=mism)
+    print(json.dumps({k: out[k] for k in list(out)[-1:]}), flush=True)
+# ---- config 5: prioritized SIPP 64x64, 10 % obstacles ----
+for agents, n in ((50, 256), (100, 128)):
+    insts = [hl.generate_instance(640000 + 1000 * agents + k, 64, 64, 410, agents) for k in range(n)]
+    s.prioritized_sipp(insts[:8])
+    res, st = s.prioritized_sipp(insts)
+    m = min(n, 16)
+    t0 = time.time(); e = 0; mism = 0
+    for inst, r in zip(insts[:m], res[:m]):
+        o = oracle.prioritized_sipp(inst)
+        e += o["expanded"]
+        mism += (o["cost"], o["planned"], o["expanded"]) != (r["cost"], r["planned"], r["expanded"])
+    t = time.time() - t0
+    out["psipp_64x64_agents%d" % agents] = dict(instances=n, gpu_exp_per_s=st["ll_expansions"] / st["wall_seconds"],
+                                                gpu_inst_per_s=n / st["wall_seconds"], cpu_exp_per_s=e / t, cpu_inst_per_s=m / t,
+                                                mismatches=mism, note="cpu time includes the oracle wrapper's python overhead")
+    print(json.dumps({k: out[k] for k in list(out)[-1:]}), flush=True)
