@@ -260,13 +260,16 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   auto tg1 = std::chrono::steady_clock::now();
   std::vector<size_t> backlog;
   size_t nInflight = 0;
-  std::vector<int32_t> doneTickets(4096);
+  std::vector<int32_t> doneTickets(64);  // small harvest chunks keep the latency of any one instance's chain low
   std::vector<size_t> ticketOwner;  // session ticket id -> local instance
-  for (size_t k = 0; k < n; ++k) {
-    live[k].inst.reset(new Instance(instIn[idx[k]], mapIds[k], opt));
-    live[k].inst->advance(live[k].ans, live[k].req);
-    if (!live[k].req.empty()) backlog.push_back(k);
-  }
+  std::vector<size_t> doneOwners;
+  // Optional admission control (MRP_HL_ACTIVE_LIMIT): at most that many instances are active at a time.  Measured on
+  // MI355X it does not pay — an instance with a long conflict-tree chain that is admitted late simply finishes late —
+  // so by default every instance of the group starts at once.
+  size_t nextToStart = 0;
+  size_t activeLimit = n;
+  if (const char* e = std::getenv("MRP_HL_ACTIVE_LIMIT")) activeLimit = std::max(1, std::atoi(e));
+  for (size_t k = 0; k < n; ++k) live[k].inst.reset(new Instance(instIn[idx[k]], mapIds[k], opt));
   bool failed = false;
   auto t0 = std::chrono::steady_clock::now();
   auto tg2 = t0;
@@ -275,9 +278,16 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   auto secsS = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double>(b - a).count();
   };
-  while (!failed && (nInflight != 0 || !backlog.empty())) {
+  while (!failed && (nInflight != 0 || !backlog.empty() || nextToStart < n)) {
     bool progress = false;
     auto tA = nowS();
+    while (nextToStart < n && nInflight + backlog.size() < activeLimit) {
+      Live& L = live[nextToStart];
+      L.inst->advance(L.ans, L.req);
+      if (!L.req.empty()) backlog.push_back(nextToStart);
+      nextToStart += 1;
+      progress = true;
+    }
     // publish as many waiting instances as the ring takes
     while (!backlog.empty()) {
       size_t k = backlog.back();
@@ -303,8 +313,11 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       break;
     }
     auto tC = nowS();
+    // resolve the owners first: a ticket id freed by this harvest can be handed out again by a resubmission below
+    doneOwners.resize(nDone);
+    for (int32_t d = 0; d < nDone; ++d) doneOwners[d] = ticketOwner[doneTickets[d]];
     for (int32_t d = 0; d < nDone; ++d) {
-      const size_t k = ticketOwner[doneTickets[d]];
+      const size_t k = doneOwners[d];
       Live& L = live[k];
       progress = true;
       nInflight -= 1;
@@ -330,8 +343,23 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
         L.ans.push_back(a);
       }
       L.inst->advance(L.ans, L.req);
-      if (!L.req.empty()) backlog.push_back(k);
+      if (!L.req.empty()) {
+        // publish the follow-up searches at once: a long conflict-tree chain must not wait for the rest of this pass
+        int r = backlog.empty() ? trySubmit(L) : 0;
+        if (r < 0) {
+          failed = true;
+          break;
+        }
+        if (r == 1) {
+          if (static_cast<size_t>(L.ticket) >= ticketOwner.size()) ticketOwner.resize(L.ticket + 1, 0);
+          ticketOwner[L.ticket] = k;
+          nInflight += 1;
+        } else {
+          backlog.push_back(k);
+        }
+      }
     }
+    if (failed) break;
     auto tD = nowS();
     out.buildS += secsS(tA, tB);
     out.llS += secsS(tB, tC);

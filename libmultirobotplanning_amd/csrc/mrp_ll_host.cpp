@@ -153,6 +153,7 @@ struct mrp_ll_ctx {
   uint32_t* debugHost = nullptr;  // MRP_LL_DEBUG: host-mapped trace buffer
   Ring ring;
   std::vector<SessTicket> sess;
+  std::vector<int32_t> sessFree;   // free session-ticket ids (stack)
 };
 
 namespace {
@@ -449,7 +450,9 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
     const uint32_t budget = 160 * 1024 - 512;
     uint32_t fixed = mrp_ll_lds_bytes(ldsNodes, 0, rowWords, ldsPaths);
     if (fixed + 16 * rowWords * 4 <= budget) {
-      rows = std::min<uint32_t>(64, (budget - fixed) / (rowWords * 4));
+      uint32_t rowsWanted = 64;
+      if (const char* e = std::getenv("MRP_LL_LDS_ROWS")) rowsWanted = std::max(8, std::atoi(e));  // tuning knob
+      rows = std::min<uint32_t>(rowsWanted, (budget - fixed) / (rowWords * 4));
       rows = std::min<uint32_t>(rows, static_cast<uint32_t>(ctx->opt.max_horizon));
       ldsBytes = mrp_ll_lds_bytes(ldsNodes, rows, rowWords, ldsPaths);
     } else {
@@ -757,6 +760,7 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   g.slotTk.assign(R, 0);
   g.tail = 0;
   ctx->sess.clear();
+  ctx->sessFree.clear();
   auto devPtr = [&](void* hostPtr) {
     void* d = nullptr;
     (void)hipHostGetDevicePointer(&d, hostPtr, 0);
@@ -831,12 +835,10 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs,
     if (g.busy[(g.head + i) % R]) return MRP_LL_E_BUSY;  // caller must consume finished tickets first
   auto packT0 = std::chrono::steady_clock::now();
   int ti = -1;
-  for (size_t i = 0; i < ctx->sess.size(); ++i)
-    if (!ctx->sess[i].used) {
-      ti = static_cast<int>(i);
-      break;
-    }
-  if (ti < 0) {
+  if (!ctx->sessFree.empty()) {
+    ti = ctx->sessFree.back();
+    ctx->sessFree.pop_back();
+  } else {
     ctx->sess.emplace_back();
     ti = static_cast<int>(ctx->sess.size()) - 1;
   }
@@ -904,7 +906,10 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
     g.busy[slot] = 0;
   }
   *doneOut = st.remaining == 0 ? 1 : 0;
-  if (st.remaining == 0) st.used = false;
+  if (st.remaining == 0) {
+    st.used = false;
+    ctx->sessFree.push_back(ticket);
+  }
   return MRP_LL_SUCCESS;
 }
 
@@ -932,6 +937,7 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
     g.busy[slot] = 0;
     if (st.remaining == 0) {
       st.used = false;
+      ctx->sessFree.push_back(g.slotTicket[slot]);
       tickets[n++] = g.slotTicket[slot];
     }
   }
