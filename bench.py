@@ -29,8 +29,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # One HIP stream per host worker thread: give each its own hardware queue (the ROCm default of 4 makes streams that
-# share a queue serialise their kernels).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# share a queue serialise their kernels — fatal for resident kernels, which only end when their host thread is done;
+# 24 > 16 worker streams + torch's own).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 ALGO_BYTES_PER_EXPANSION = 128
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s

@@ -127,6 +127,7 @@ typedef struct mrp_ll_stats {
   double kernel_ms;          /* sum of hipEvent-measured kernel durations (on the launching stream)           */
   double h2d_ms, d2h_ms;     /* hipEvent-measured copy durations                                              */
   double session_busy_ms, session_idle_ms; /* session mode: sum over resident workgroups of time in jobs / waiting */
+  int64_t session_active_wgs;              /* session mode: workgroups that ran at least one job (summed over sessions) */
   double pack_ms, unpack_ms; /* host time spent packing jobs (mrp_ll_submit) / unpacking results (mrp_ll_wait)           */
   int64_t prof[8];           /* diagnostic (-DMRP_LL_TRACE library only, else 0): shader cycles in walk, pops,  */
                              /* pushes, successor generation, row init, whole job; #walks; nodes visited by walks */
@@ -156,6 +157,10 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket);
  * search of a batch.  Results are identical to the batch mode's. */
 int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups /* 0 = mrp_ll_options.slots */);
 int mrp_ll_session_end(mrp_ll_ctx* ctx);
+/* Session mode: `lane` 0 = the bulk ring, 1 = the express ring, served by a few dedicated wavefronts and therefore
+ * never congested by lane 0 (use it for the searches of a long chain of dependent rounds).  mrp_ll_submit == lane 0. */
+int mrp_ll_submit_lane(mrp_ll_ctx* ctx, int32_t lane, int32_t n_jobs, const mrp_ll_job* jobs, mrp_ll_result* results,
+                       int32_t* ticket);
 int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* done);
 /* Session mode only: collect every ticket that has completed since the last call (its results are filled in and the
  * ticket is released, exactly as after mrp_ll_wait).  One pass over the ring's completion words, independent of how

@@ -123,11 +123,19 @@ class Instance {
       const LLAnswer& a = answers[k];
       const int32_t ag = childAgent_[k];
       if (a.status == MRP_LL_OK) {
+        const PathPtr oldPath = ch.solution[ag];  // the parent's path of this agent
+        const int32_t oldT = maxT(ch.solution);
         ch.solution[ag] = a.path;
         ch.cost += a.cost;
         if (algo_ == MRP_HL_ECBS) {
           ch.LB += a.fmin;
-          ch.focalHeuristic = countConflicts(ch.solution, scratch_);
+          // focalHeuristic(child) (ecbs.hpp:272): incremental while the scan horizon is unchanged (grid_mapf.hpp)
+          const int32_t newT = maxT(ch.solution);
+          if (newT == oldT)
+            ch.focalHeuristic += conflictsOfAgent(ch.solution, ag, *a.path, newT) -
+                                 conflictsOfAgent(ch.solution, ag, *oldPath, oldT);
+          else
+            ch.focalHeuristic = countConflicts(ch.solution, scratch_);
         }
         int32_t id = storeNode(children_[k]);
         open_.push(id);

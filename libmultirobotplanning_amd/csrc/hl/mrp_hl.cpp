@@ -28,6 +28,8 @@ struct mrp_hl_solver {
 
 namespace {
 
+constexpr int64_t kDeepHl = 24;  // conflict-tree expansions after which an instance counts as a long chain
+
 struct GroupResult {
   int64_t rounds = 0, searches = 0, expansions = 0;
   double buildS = 0, llS = 0, consumeS = 0;
@@ -246,7 +248,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       L.res[q].states_txy = L.states.data() + q * static_cast<size_t>(cap) * 3;
       L.res[q].states_cap = cap;
     }
-    int rc = mrp_ll_submit(ctx, static_cast<int32_t>(jobs.size()), jobs.data(), L.res.data(), &L.ticket);
+    // an instance deep in its conflict tree is a long chain of dependent rounds: its searches take the express lane,
+    // which the bulk never congests, so the chain advances alongside the bulk instead of after it
+    const int32_t lane = I.hlExpanded() >= kDeepHl ? 1 : 0;
+    int rc = mrp_ll_submit_lane(ctx, lane, static_cast<int32_t>(jobs.size()), jobs.data(), L.res.data(), &L.ticket);
     if (rc == MRP_LL_E_BUSY) return 0;
     if (rc != MRP_LL_SUCCESS) {
       out.err = std::string("mrp_ll_submit: ") + mrp_ll_last_error(ctx);
@@ -381,8 +386,12 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double, std::milli>(b - a).count();
     };
-    std::fprintf(stderr, "[mrp_hl] group of %zu: session_begin %.2f ms, build instances %.2f ms, loop %.2f ms, session_end %.2f ms\n", n,
-                 ms(tg0, tg1), ms(tg1, tg2), ms(tg2, tg3), ms(tg3, tg4));
+    mrp_ll_stats ls;
+    mrp_ll_get_stats(ctx, &ls);
+    std::fprintf(stderr, "[mrp_hl] group of %zu: session_begin %.2f ms, build instances %.2f ms, loop %.2f ms, session_end %.2f ms; "
+                 "cumulative: active wgs %lld, busy %.0f ms, idle %.0f ms, searches %lld, expansions %lld\n", n,
+                 ms(tg0, tg1), ms(tg1, tg2), ms(tg2, tg3), ms(tg3, tg4), (long long)ls.session_active_wgs,
+                 ls.session_busy_ms, ls.session_idle_ms, (long long)ls.jobs, (long long)ls.expansions);
   }
   if (failed) return;
   for (size_t k = 0; k < n; ++k) {
@@ -467,6 +476,7 @@ int mrp_hl_solver_ll_stats(mrp_hl_solver* s, mrp_ll_stats* out, int32_t reset) {
     out->pack_ms += st.pack_ms;
     out->session_busy_ms += st.session_busy_ms;
     out->session_idle_ms += st.session_idle_ms;
+    out->session_active_wgs += st.session_active_wgs;
     out->unpack_ms += st.unpack_ms;
     for (int q = 0; q < 8; ++q) out->prof[q] += st.prof[q];
     if (reset) mrp_ll_reset_stats(e);

@@ -87,7 +87,9 @@ struct LaunchParams {
   uint32_t* comp_ring;        // host [ring_size]: completion queue, entry = (generation << 11) | slot
   uint32_t* comp_count;       // device: completions so far (index into comp_ring)
   unsigned long long* sess_ticks; // device [2]: sum over workgroups of 100 MHz ticks spent in jobs / waiting for jobs
-  uint32_t ring_size;
+  uint32_t ring_size;         // slots of lane 0 (slots [0, ring_size)); completion ring has ring_size + ring_size1 entries
+  uint32_t ring_size1;        // slots of lane 1, the express lane (slots [ring_size, ring_size + ring_size1))
+  uint32_t express_first;     // workgroups with blockIdx.x >= express_first serve lane 1 only
   uint32_t ring_idle_limit_s; // a workgroup that waited this long for a job exits (safety net if the host died)
 };
 

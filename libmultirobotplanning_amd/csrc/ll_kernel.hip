@@ -918,18 +918,27 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
   uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
   const uint64_t idleLimit = (uint64_t)P.ring_idle_limit_s * 100000000ull;  // s_memrealtime ticks at 100 MHz
   uint64_t busyTicks = 0, idleTicks = 0;
+  // Two lanes share the slot arrays: lane 0 (the bulk) and lane 1 (express: a handful of workgroups that only serve
+  // searches of instances deep in their conflict tree, so a long chain of dependent rounds never queues behind the
+  // bulk).  Each lane has its own ticket counter (device) and published-count word (host), 64 bytes apart.
+  const uint32_t myLane = blockIdx.x >= P.express_first ? 1u : 0u;
+  const uint32_t laneSize = myLane ? P.ring_size1 : P.ring_size;
+  const uint32_t laneBase = myLane ? P.ring_size : 0u;
+  const uint32_t compSize = P.ring_size + P.ring_size1;
+  uint32_t* const laneTickets = P.queue_head + myLane * 16;
+  uint32_t* const laneHead = P.ring_head + myLane * 16;
   for (;;) {
-    uint32_t t = atomicAdd(P.queue_head, lane == 0 ? 1u : 0u);
+    uint32_t t = atomicAdd(laneTickets, lane == 0 ? 1u : 0u);
     t = rfl(t);
-    const uint32_t slot = t % P.ring_size;
-    const uint32_t gen = t / P.ring_size + 1;
+    const uint32_t slot = laneBase + t % laneSize;
+    const uint32_t gen = t / laneSize + 1;
     bool stop = false;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
       // Waiting workgroups poll ONE host word (the published-ticket count) and back off in proportion to how far
       // ahead of it their ticket is: the next in line looks every ~2 us, the k-th every ~2k us (<= ~100 us), so a
       // thousand idle wavefronts do not saturate PCIe with reads.
-      const uint32_t hd = rfl(__hip_atomic_load(P.ring_head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+      const uint32_t hd = rfl(__hip_atomic_load(laneHead, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
       if ((int32_t)(hd - t) > 0) {
         const uint32_t st = rfl(__hip_atomic_load(P.ring_state + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
         if (st == gen) break;
@@ -953,12 +962,13 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
     // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring
     uint32_t cidx = atomicAdd(P.comp_count, lane == 0 ? 1u : 0u);
     cidx = rfl(cidx);
-    __hip_atomic_store(P.comp_ring + (cidx % P.ring_size), ((cidx / P.ring_size + 1) << 11) | slot, __ATOMIC_RELEASE,
+    __hip_atomic_store(P.comp_ring + (cidx % compSize), ((cidx / compSize + 1) << 11) | slot, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
     busyTicks += __builtin_amdgcn_s_memrealtime() - t1;
   }
   atomicAdd(P.sess_ticks + 0, lane == 0 ? (unsigned long long)busyTicks : 0ull);
   atomicAdd(P.sess_ticks + 1, lane == 0 ? (unsigned long long)idleTicks : 0ull);
+  atomicAdd(P.sess_ticks + 2, (lane == 0 && busyTicks != 0) ? 1ull : 0ull);  // workgroups that ran at least one job
 }
 
 }  // namespace mrp

@@ -99,7 +99,9 @@ struct Ticket {
 
 // ---- session mode: job ring in coherent pinned host memory --------------------------------------------------
 struct Ring {
-  static constexpr uint32_t kSlots = 2048;
+  static constexpr uint32_t kSlots = 2048;                // all slots; lane 0 owns [0, kSlots0), lane 1 the rest
+  static constexpr uint32_t kSlots0 = 1792;
+  static constexpr uint32_t kSlots1 = kSlots - kSlots0;
   static constexpr uint32_t kSlotConsWords = 1024;        // 4 KB of constraint words per job
   static constexpr uint32_t kSlotPathHalfs = 16 * 1024;   // 32 KB path table per job
   uint8_t* block = nullptr;        // one coherent allocation holding everything below
@@ -113,19 +115,19 @@ struct Ring {
   uint32_t* cons = nullptr;
   uint16_t* paths = nullptr;
   uint32_t outStride = 0;
-  uint64_t head = 0;               // next ticket number to publish
+  uint64_t head[2] = {0, 0};       // per lane: next ticket number to publish
   std::vector<uint8_t> busy;       // slot holds a job whose result the host has not consumed yet
   std::vector<int32_t> slotTicket; // slot -> session ticket id / job index inside it
   std::vector<int32_t> slotJob;
-  std::vector<uint64_t> slotTk;    // ticket number currently occupying the slot (valid while busy)
-  uint64_t tail = 0;               // oldest ticket number whose slot may still be busy
+  std::vector<uint32_t> slotGen;   // generation the occupant's done word will show (valid while busy)
   bool active = false;
-  uint32_t grid = 0;
+  uint32_t grid = 0, expressWgs = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 struct SessTicket {
   bool used = false;
   uint64_t first = 0;
+  int32_t lane = 0;
   int32_t n = 0, remaining = 0;
   mrp_ll_result* res = nullptr;
   std::vector<uint8_t> state;      // per job: 0 pending, 1 consumed, 2 rejected on the host
@@ -753,12 +755,12 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   g.compCursor = 0;
   __atomic_store_n(g.stop, 0u, __ATOMIC_RELEASE);
   __atomic_store_n(g.headWord, 0u, __ATOMIC_RELEASE);
-  g.head = 0;
+  __atomic_store_n(g.headWord + 16, 0u, __ATOMIC_RELEASE);
+  g.head[0] = g.head[1] = 0;
   g.busy.assign(R, 0);
   g.slotTicket.assign(R, -1);
   g.slotJob.assign(R, 0);
-  g.slotTk.assign(R, 0);
-  g.tail = 0;
+  g.slotGen.assign(R, 0);
   ctx->sess.clear();
   ctx->sessFree.clear();
   auto devPtr = [&](void* hostPtr) {
@@ -780,16 +782,23 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   P.comp_ring = static_cast<uint32_t*>(devPtr(g.compRing));
   P.comp_count = g.compCountDev;
   P.sess_ticks = g.ticksDev;
-  P.ring_size = R;
+  P.ring_size = Ring::kSlots0;
+  P.ring_size1 = Ring::kSlots1;
   P.ring_idle_limit_s = 20;
   uint32_t ldsBytes = 0;
   rc = fillCommonParams(ctx, t, P, ldsBytes);
   if (rc != MRP_LL_SUCCESS) return rc;
   ctx->sessionRowWords = P.lds_row_words;
   g.grid = static_cast<uint32_t>(workgroups > 0 ? std::min(workgroups, ctx->opt.slots) : ctx->opt.slots);
-  HIPCHK(ctx, hipMemsetAsync(t.queueHead, 0, 4, t.stream));  // session tickets count from 0
+  {  // the last few workgroups serve the express lane only
+    uint32_t express = g.grid >= 32 ? 8u : (g.grid >= 4 ? g.grid / 4 : 0u);
+    if (const char* e = std::getenv("MRP_LL_EXPRESS_WGS")) express = std::min<uint32_t>(g.grid / 2, std::atoi(e));
+    g.expressWgs = express;
+    P.express_first = g.grid - express;
+  }
+  HIPCHK(ctx, hipMemsetAsync(t.queueHead, 0, 256, t.stream));  // session tickets of both lanes count from 0
   HIPCHK(ctx, hipMemsetAsync(g.compCountDev, 0, 4, t.stream));
-  HIPCHK(ctx, hipMemsetAsync(g.ticksDev, 0, 16, t.stream));
+  HIPCHK(ctx, hipMemsetAsync(g.ticksDev, 0, 32, t.stream));
   t.queueBase = 0;
   HIPCHK(ctx, hipEventRecord(g.ev0, t.stream));
   HIPCHK(ctx, mrp_ll_launch_persistent(&P, g.grid, ldsBytes, t.stream));
@@ -809,8 +818,9 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) ctx->stats.kernel_ms += ms;
   {
-    unsigned long long tk[2] = {0, 0};
-    if (hipMemcpy(tk, g.ticksDev, 16, hipMemcpyDeviceToHost) == hipSuccess) {
+    unsigned long long tk[3] = {0, 0, 0};
+    if (hipMemcpy(tk, g.ticksDev, 24, hipMemcpyDeviceToHost) == hipSuccess) {
+      ctx->stats.session_active_wgs += static_cast<int64_t>(tk[2]);
       ctx->stats.session_busy_ms += static_cast<double>(tk[0]) / 1e5;  // 100 MHz ticks
       ctx->stats.session_idle_ms += static_cast<double>(tk[1]) / 1e5;
     }
@@ -818,21 +828,23 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
   g.active = false;
   // the device counter is past the published tickets: the next batch-mode launch starts from a clean base
   Ticket& t = ctx->tickets[0];
-  HIPCHK(ctx, hipMemset(t.queueHead, 0, 4));
+  HIPCHK(ctx, hipMemset(t.queueHead, 0, 256));
   t.queueBase = 0;
   return MRP_LL_SUCCESS;
 }
 
-static int sessionSubmit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results,
+static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results,
                          int32_t* ticketOut) {
   Ring& g = ctx->ring;
-  const uint32_t R = Ring::kSlots;
+  if (lane == 1 && g.expressWgs == 0) lane = 0;  // no express workgroups in this session
+  const uint32_t R = lane ? Ring::kSlots1 : Ring::kSlots0;
+  const uint32_t base = lane ? Ring::kSlots0 : 0;
   if (nJobs > static_cast<int32_t>(R)) {
     ctx->err = "mrp_ll_submit (session): batch larger than the ring";
     return MRP_LL_E_INVALID;
   }
   for (int i = 0; i < nJobs; ++i)
-    if (g.busy[(g.head + i) % R]) return MRP_LL_E_BUSY;  // caller must consume finished tickets first
+    if (g.busy[base + (g.head[lane] + i) % R]) return MRP_LL_E_BUSY;  // caller must consume finished tickets first
   auto packT0 = std::chrono::steady_clock::now();
   int ti = -1;
   if (!ctx->sessFree.empty()) {
@@ -844,14 +856,15 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs,
   }
   SessTicket& st = ctx->sess[ti];
   st.used = true;
-  st.first = g.head;
+  st.first = g.head[lane];
+  st.lane = lane;
   st.n = nJobs;
   st.remaining = nJobs;
   st.res = results;
   st.state.assign(nJobs, 0);
   for (int i = 0; i < nJobs; ++i) {
-    const uint64_t tk = g.head + i;
-    const uint32_t slot = static_cast<uint32_t>(tk % R);
+    const uint64_t tk = g.head[lane] + i;
+    const uint32_t slot = base + static_cast<uint32_t>(tk % R);
     const uint32_t gen = static_cast<uint32_t>(tk / R) + 1;
     ConsSinkSlot cs{g.cons + static_cast<size_t>(slot) * Ring::kSlotConsWords, slot * Ring::kSlotConsWords,
                     Ring::kSlotConsWords};
@@ -867,11 +880,12 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs,
     g.busy[slot] = 1;
     g.slotTicket[slot] = ti;
     g.slotJob[slot] = i;
-    g.slotTk[slot] = tk;
+    g.slotGen[slot] = gen;
     __atomic_store_n(g.state + slot, gen, __ATOMIC_RELEASE);  // publish: the job data above is visible first
   }
-  g.head += static_cast<uint64_t>(nJobs);
-  __atomic_store_n(g.headWord, static_cast<uint32_t>(g.head), __ATOMIC_RELEASE);  // after every slot's state word
+  g.head[lane] += static_cast<uint64_t>(nJobs);
+  // after every slot's state word
+  __atomic_store_n(g.headWord + 16 * lane, static_cast<uint32_t>(g.head[lane]), __ATOMIC_RELEASE);
   ctx->stats.pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - packT0).count();
   *ticketOut = ti;
   return MRP_LL_SUCCESS;
@@ -892,11 +906,12 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
   }
   if (ticket < 0 || ticket >= static_cast<int32_t>(ctx->sess.size()) || !ctx->sess[ticket].used) return MRP_LL_E_INVALID;
   SessTicket& st = ctx->sess[ticket];
-  const uint32_t R = Ring::kSlots;
+  const uint32_t R = st.lane ? Ring::kSlots1 : Ring::kSlots0;
+  const uint32_t base = st.lane ? Ring::kSlots0 : 0;
   for (int i = 0; i < st.n && st.remaining > 0; ++i) {
     if (st.state[i] == 1) continue;
     const uint64_t tk = st.first + i;
-    const uint32_t slot = static_cast<uint32_t>(tk % R);
+    const uint32_t slot = base + static_cast<uint32_t>(tk % R);
     const uint32_t gen = static_cast<uint32_t>(tk / R) + 1;
     if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != gen) continue;
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
@@ -927,7 +942,7 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
     const uint32_t slot = e & 2047u;
     if (!g.busy[slot]) continue;  // already consumed through mrp_ll_poll / mrp_ll_wait
     // ... and if the slot has been re-used since, this entry is stale: only the occupant's own done word counts
-    if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != static_cast<uint32_t>(g.slotTk[slot] / R) + 1) continue;
+    if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != g.slotGen[slot]) continue;
     SessTicket& st = ctx->sess[g.slotTicket[slot]];
     const int32_t i = g.slotJob[slot];
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
@@ -967,7 +982,7 @@ static int sessionWait(mrp_ll_ctx* ctx, int32_t ticket) {
 
 int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results, int32_t* ticketOut) {
   if (!ctx || !ticketOut || nJobs < 0 || (nJobs > 0 && (!jobs || !results))) return MRP_LL_E_INVALID;
-  if (ctx->ring.active) return sessionSubmit(ctx, nJobs, jobs, results, ticketOut);
+  if (ctx->ring.active) return sessionSubmit(ctx, 0, nJobs, jobs, results, ticketOut);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int ti = -1;
   for (size_t i = 0; i < ctx->tickets.size(); ++i)
@@ -1056,6 +1071,13 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
   HIPCHK(ctx, hipEventRecord(t.evK1, t.stream));
   ctx->stats.launches += 1;
   return MRP_LL_SUCCESS;
+}
+
+int mrp_ll_submit_lane(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results,
+                       int32_t* ticketOut) {
+  if (!ctx || !ticketOut || nJobs < 0 || (nJobs > 0 && (!jobs || !results)) || lane < 0 || lane > 1) return MRP_LL_E_INVALID;
+  if (!ctx->ring.active) return mrp_ll_submit(ctx, nJobs, jobs, results, ticketOut);  // batch mode has one queue
+  return sessionSubmit(ctx, lane, nJobs, jobs, results, ticketOut);
 }
 
 int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {

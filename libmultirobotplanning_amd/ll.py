@@ -51,13 +51,13 @@ class mrp_ll_stats(ctypes.Structure):
     _fields_ = [("launches", ctypes.c_int64), ("jobs", ctypes.c_int64), ("expansions", ctypes.c_int64),
                 ("nodes_created", ctypes.c_int64), ("migrated", ctypes.c_int64), ("kernel_ms", ctypes.c_double),
                 ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("session_busy_ms", ctypes.c_double),
-                ("session_idle_ms", ctypes.c_double), ("pack_ms", ctypes.c_double),
+                ("session_idle_ms", ctypes.c_double), ("session_active_wgs", ctypes.c_int64), ("pack_ms", ctypes.c_double),
                 ("unpack_ms", ctypes.c_double), ("prof", ctypes.c_int64 * 8)]
 
 
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
            "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version",
-           "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any"]
+           "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any", "mrp_ll_submit_lane"]
 
 _lib = None
 
@@ -100,6 +100,9 @@ def load_library(path: Optional[str] = None):
     lib.mrp_ll_session_end.argtypes = [ctypes.c_void_p]
     lib.mrp_ll_poll.restype = ctypes.c_int
     lib.mrp_ll_poll.argtypes = [ctypes.c_void_p, ctypes.c_int32, I32P]
+    lib.mrp_ll_submit_lane.restype = ctypes.c_int
+    lib.mrp_ll_submit_lane.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(mrp_ll_job),
+                                       ctypes.POINTER(mrp_ll_result), I32P]
     lib.mrp_ll_poll_any.restype = ctypes.c_int
     lib.mrp_ll_poll_any.argtypes = [ctypes.c_void_p, I32P, ctypes.c_int32, I32P]
     if path is None:

@@ -2,7 +2,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 from libmultirobotplanning_amd import hl
 s = hl.BatchSolver(device=0, n_threads=1, slots=64)
 for seed in (10000 + 5169, 10000 + 9479, 10000 + 3493):

@@ -93,6 +93,9 @@ int mrp_ll_submit(mrp_ll_ctx* c, int32_t n, const mrp_ll_job* jobs, mrp_ll_resul
   c->doneTickets.push_back(*ticket);
   return mrp_ll_search_batch(c, n, jobs, res);
 }
+int mrp_ll_submit_lane(mrp_ll_ctx* c, int32_t, int32_t n, const mrp_ll_job* jobs, mrp_ll_result* res, int32_t* ticket) {
+  return mrp_ll_submit(c, n, jobs, res, ticket);
+}
 int mrp_ll_poll_any(mrp_ll_ctx* c, int32_t* tickets, int32_t cap, int32_t* n) {
   int32_t k = 0;
   while (!c->doneTickets.empty() && k < cap) {

@@ -46,4 +46,4 @@ def test_struct_layouts_match_header(built):
     assert ctypes.sizeof(ll.mrp_ll_options) == 32
     assert ctypes.sizeof(ll.mrp_ll_job) == 128
     assert ctypes.sizeof(ll.mrp_ll_result) == 56
-    assert ctypes.sizeof(ll.mrp_ll_stats) == 160
+    assert ctypes.sizeof(ll.mrp_ll_stats) == 168

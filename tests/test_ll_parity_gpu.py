@@ -148,7 +148,7 @@ def test_session_mode_matches_oracle(oracle_mod, bench_instances):
                                    edge_constraints=c["edge_constraints"], ctx_paths=c["ctx_paths"])
                     cj, cr, hold = eng._marshal([job], 512)
                     tk = ctypes.c_int32(-1)
-                    rc = lib.mrp_ll_submit(eng._h, 1, cj, cr, ctypes.byref(tk))
+                    rc = lib.mrp_ll_submit_lane(eng._h, submitted % 3 == 0, 1, cj, cr, ctypes.byref(tk))  # both lanes
                     if rc == -4:
                         break
                     assert rc == 0
