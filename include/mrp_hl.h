@@ -86,6 +86,15 @@ int mrp_hl_solver_create(int32_t device, int32_t n_threads, const mrp_ll_options
 void mrp_hl_solver_destroy(mrp_hl_solver* s);
 int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* opt, int32_t n_instances,
                         const mrp_hl_instance* instances, mrp_hl_solution* solutions, mrp_hl_batch_stats* stats);
+/* Two-step form: preload uploads the instances' static maps to HBM (the reference builds its Environment before it
+ * starts its Timer, example/ecbs.cpp:576-582) and fixes the instance -> worker assignment; solve_preloaded then runs the
+ * conflict-tree searches only.  The instance arrays must stay valid until mrp_hl_preloaded_free. */
+typedef struct mrp_hl_preloaded mrp_hl_preloaded;
+int mrp_hl_solver_preload(mrp_hl_solver* s, int32_t n_threads, int32_t n_instances, const mrp_hl_instance* instances,
+                          mrp_hl_preloaded** out);
+int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* opt, mrp_hl_preloaded* p,
+                                  mrp_hl_solution* solutions, mrp_hl_batch_stats* stats);
+void mrp_hl_preloaded_free(mrp_hl_preloaded* p);
 int mrp_hl_solver_ll_stats(mrp_hl_solver* s, mrp_ll_stats* out, int32_t reset); /* summed over its engines */
 const char* mrp_hl_solver_last_error(const mrp_hl_solver* s);
 

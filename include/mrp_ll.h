@@ -141,6 +141,9 @@ const char* mrp_ll_last_error(const mrp_ll_ctx* ctx);
 int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t n_obstacles, const int32_t* obstacles_xy,
                       int32_t* map_id);
 
+/* Copies every map uploaded so far to the device now (otherwise done lazily by the next submit / session_begin). */
+int mrp_ll_sync_maps(mrp_ll_ctx* ctx);
+
 /* Blocking: run n_jobs independent searches, fill results[i] for jobs[i]. */
 int mrp_ll_search_batch(mrp_ll_ctx* ctx, int32_t n_jobs, const mrp_ll_job* jobs, mrp_ll_result* results);
 

@@ -19,6 +19,12 @@
 
 using namespace mrp_hl;
 
+struct mrp_hl_preloaded {
+  int32_t nInst = 0;
+  const mrp_hl_instance* instances = nullptr;
+  std::vector<std::vector<int32_t>> idx, mapIds;  // per worker: instance indices and their map ids on that engine
+};
+
 struct mrp_hl_solver {
   int32_t device = 0;
   std::vector<mrp_ll_ctx*> engines;
@@ -484,29 +490,67 @@ int mrp_hl_solver_ll_stats(mrp_hl_solver* s, mrp_ll_stats* out, int32_t reset) {
   return MRP_LL_SUCCESS;
 }
 
-int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* optIn, int32_t nInst, const mrp_hl_instance* instances,
-                        mrp_hl_solution* solutions, mrp_hl_batch_stats* stats) {
-  if (!s || !optIn || nInst < 0 || (nInst > 0 && (!instances || !solutions))) return MRP_LL_E_INVALID;
-  mrp_hl_options opt = *optIn;
+int mrp_hl_solver_preload(mrp_hl_solver* s, int32_t nThreadsWanted, int32_t nInst, const mrp_hl_instance* instances,
+                          mrp_hl_preloaded** out) {
+  if (!s || !out || nInst < 0 || (nInst > 0 && !instances)) return MRP_LL_E_INVALID;
+  *out = nullptr;
   int32_t nThreads = static_cast<int32_t>(s->engines.size());
-  if (opt.n_threads > 0) nThreads = std::min(nThreads, opt.n_threads);
+  if (nThreadsWanted > 0) nThreads = std::min(nThreads, nThreadsWanted);
   nThreads = std::max(1, std::min(nThreads, std::max(nInst, 1)));
-  const int32_t horizon = s->llOpt.max_horizon > 0 ? s->llOpt.max_horizon : 512;
+  auto* p = new mrp_hl_preloaded();
+  p->nInst = nInst;
+  p->instances = instances;
+  p->idx.resize(nThreads);
+  p->mapIds.resize(nThreads);
   // instance k -> thread k % nThreads (interleaved, so easy and hard agent counts mix evenly)
-  std::vector<std::vector<int32_t>> idx(nThreads), mapIds(nThreads);
-  for (int32_t k = 0; k < nInst; ++k) idx[k % nThreads].push_back(k);
-  // Environment construction (ecbs.cpp:576) is outside the reference's timed region: upload the maps first
+  for (int32_t k = 0; k < nInst; ++k) p->idx[k % nThreads].push_back(k);
   for (int32_t t = 0; t < nThreads; ++t)
-    for (int32_t k : idx[t]) {
+    for (int32_t k : p->idx[t]) {
       const mrp_hl_instance& in = instances[k];
       int32_t mid = -1;
       int rc = mrp_ll_upload_map(s->engines[t], in.dimx, in.dimy, in.n_obstacles, in.obstacles_xy, &mid);
       if (rc != MRP_LL_SUCCESS) {
         s->err = std::string("mrp_ll_upload_map: ") + mrp_ll_last_error(s->engines[t]);
+        delete p;
         return rc;
       }
-      mapIds[t].push_back(mid);
+      p->mapIds[t].push_back(mid);
     }
+  for (int32_t t = 0; t < nThreads; ++t) {  // push the bitmaps to the device now, not at the first launch
+    int rc = mrp_ll_sync_maps(s->engines[t]);
+    if (rc != MRP_LL_SUCCESS) {
+      s->err = std::string("mrp_ll_sync_maps: ") + mrp_ll_last_error(s->engines[t]);
+      delete p;
+      return rc;
+    }
+  }
+  *out = p;
+  return MRP_LL_SUCCESS;
+}
+
+void mrp_hl_preloaded_free(mrp_hl_preloaded* p) { delete p; }
+
+int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* optIn, int32_t nInst, const mrp_hl_instance* instances,
+                        mrp_hl_solution* solutions, mrp_hl_batch_stats* stats) {
+  if (!s || !optIn || nInst < 0 || (nInst > 0 && (!instances || !solutions))) return MRP_LL_E_INVALID;
+  mrp_hl_preloaded* p = nullptr;
+  int rc = mrp_hl_solver_preload(s, optIn->n_threads, nInst, instances, &p);
+  if (rc != MRP_LL_SUCCESS) return rc;
+  rc = mrp_hl_solver_solve_preloaded(s, optIn, p, solutions, stats);
+  mrp_hl_preloaded_free(p);
+  return rc;
+}
+
+int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn, mrp_hl_preloaded* pre,
+                                  mrp_hl_solution* solutions, mrp_hl_batch_stats* stats) {
+  if (!s || !optIn || !pre || (pre->nInst > 0 && !solutions)) return MRP_LL_E_INVALID;
+  mrp_hl_options opt = *optIn;
+  const int32_t nInst = pre->nInst;
+  const mrp_hl_instance* instances = pre->instances;
+  const int32_t nThreads = static_cast<int32_t>(pre->idx.size());
+  const int32_t horizon = s->llOpt.max_horizon > 0 ? s->llOpt.max_horizon : 512;
+  std::vector<std::vector<int32_t>>& idx = pre->idx;
+  std::vector<std::vector<int32_t>>& mapIds = pre->mapIds;
   std::vector<GroupResult> gr(nThreads);
   // resident wavefronts per engine: the chip holds about 256 CUs x 4 workgroups of this kernel at once
   int32_t sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, 1024 / nThreads));

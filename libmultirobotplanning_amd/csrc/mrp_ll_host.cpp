@@ -1117,6 +1117,13 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
   return MRP_LL_SUCCESS;
 }
 
+int mrp_ll_sync_maps(mrp_ll_ctx* ctx) {
+  if (!ctx) return MRP_LL_E_INVALID;
+  if (ctx->ring.active) return MRP_LL_SUCCESS;  // in-session uploads are copied immediately
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return syncMaps(ctx);
+}
+
 int mrp_ll_search_batch(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results) {
   int32_t ticket = -1;
   int rc = mrp_ll_submit(ctx, nJobs, jobs, results, &ticket);

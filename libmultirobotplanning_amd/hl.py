@@ -49,7 +49,8 @@ class mrp_hl_sipp_solution(ctypes.Structure):
                 ("state_cap", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
 
 
-EXPORTS = ["mrp_hl_solver_prioritized_sipp", "mrp_hl_solve_batch", "mrp_hl_solver_create", "mrp_hl_solver_destroy", "mrp_hl_solver_solve",
+EXPORTS = ["mrp_hl_solver_prioritized_sipp", "mrp_hl_solver_preload", "mrp_hl_solver_solve_preloaded",
+           "mrp_hl_preloaded_free", "mrp_hl_solve_batch", "mrp_hl_solver_create", "mrp_hl_solver_destroy", "mrp_hl_solver_solve",
            "mrp_hl_solver_ll_stats", "mrp_hl_solver_last_error", "mrp_hl_generate_instance"]
 
 _lib = None
@@ -81,6 +82,14 @@ def load_library(path: Optional[str] = None):
         lib.mrp_hl_solve_batch.argtypes = [ctypes.c_int32, ctypes.POINTER(mrp_hl_options), ctypes.c_int32,
                                            ctypes.POINTER(mrp_hl_instance), ctypes.POINTER(mrp_hl_solution),
                                            ctypes.POINTER(mrp_hl_batch_stats)]
+        lib.mrp_hl_solver_preload.restype = ctypes.c_int
+        lib.mrp_hl_solver_preload.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.POINTER(mrp_hl_instance), ctypes.POINTER(ctypes.c_void_p)]
+        lib.mrp_hl_solver_solve_preloaded.restype = ctypes.c_int
+        lib.mrp_hl_solver_solve_preloaded.argtypes = [ctypes.c_void_p, ctypes.POINTER(mrp_hl_options), ctypes.c_void_p,
+                                                      ctypes.POINTER(mrp_hl_solution), ctypes.POINTER(mrp_hl_batch_stats)]
+        lib.mrp_hl_preloaded_free.restype = None
+        lib.mrp_hl_preloaded_free.argtypes = [ctypes.c_void_p]
         lib.mrp_hl_solver_prioritized_sipp.restype = ctypes.c_int
         lib.mrp_hl_solver_prioritized_sipp.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(mrp_hl_instance),
                                                        ctypes.POINTER(mrp_hl_sipp_solution),
@@ -131,9 +140,9 @@ class BatchSolver:
         except Exception:
             pass
 
-    def solve(self, instances: Sequence[Dict], algo: int = ECBS, w: float = 1.3, max_ll_expansions: int = -1,
-              max_hl_expansions: int = -1, n_threads: int = 0, want_paths: bool = True, path_cap: int = 512,
-              mode: int = 0):
+    def prepare(self, instances: Sequence[Dict], n_threads: int = 0, want_paths: bool = True, path_cap: int = 512):
+        """Marshal a batch and upload its static maps to HBM (outside any timed region: the reference constructs its
+        Environment before it starts its Timer, example/ecbs.cpp:576-582).  Returns an opaque prepared batch."""
         n = len(instances)
         cin = (mrp_hl_instance * max(n, 1))()
         csol = (mrp_hl_solution * max(n, 1))()
@@ -157,24 +166,56 @@ class BatchSolver:
                 csol[i].path_len = a.ctypes.data_as(I32P)
                 csol[i].paths_xy = b.ctypes.data_as(I32P)
                 csol[i].path_cap = path_cap
-        opt = mrp_hl_options(algo, w, max_ll_expansions, max_hl_expansions, n_threads, mode)
-        st = mrp_hl_batch_stats()
-        rc = self._lib.mrp_hl_solver_solve(self._h, ctypes.byref(opt), n, cin, csol, ctypes.byref(st))
+        h = ctypes.c_void_p()
+        rc = self._lib.mrp_hl_solver_preload(self._h, n_threads, n, cin, ctypes.byref(h))
         if rc != 0:
-            raise RuntimeError(f"mrp_hl_solver_solve failed rc={rc}: {self._lib.mrp_hl_solver_last_error(self._h).decode()}")
-        out = []
-        for i in range(n):
-            s = csol[i]
-            rec = dict(status=s.status, cost=s.cost, makespan=s.makespan, hl_expanded=s.high_level_expanded,
-                       ll_expanded=s.low_level_expanded, ll_searches=s.n_ll_searches)
-            if want_paths and s.status == SOLVED:
-                assert int(plen[i].max(initial=0)) <= path_cap
-                rec["paths"] = [pxy[i][a, :plen[i][a]].tolist() for a in range(len(plen[i]))]
-            out.append(rec)
+            raise RuntimeError(f"mrp_hl_solver_preload failed rc={rc}: "
+                               f"{self._lib.mrp_hl_solver_last_error(self._h).decode()}")
+        return dict(n=n, cin=cin, csol=csol, keep=keep, plen=plen, pxy=pxy, handle=h, want_paths=want_paths,
+                    path_cap=path_cap)
+
+    def release(self, prep) -> None:
+        if prep.get("handle"):
+            self._lib.mrp_hl_preloaded_free(prep["handle"])
+            prep["handle"] = None
+
+    def solve_prepared(self, prep, algo: int = ECBS, w: float = 1.3, max_ll_expansions: int = -1,
+                       max_hl_expansions: int = -1, mode: int = 0, raw: bool = False):
+        """Run the conflict-tree searches of a prepared batch.  raw=True skips building per-instance dicts."""
+        opt = mrp_hl_options(algo, w, max_ll_expansions, max_hl_expansions, 0, mode)
+        st = mrp_hl_batch_stats()
+        rc = self._lib.mrp_hl_solver_solve_preloaded(self._h, ctypes.byref(opt), prep["handle"], prep["csol"],
+                                                     ctypes.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"mrp_hl_solver_solve_preloaded failed rc={rc}: "
+                               f"{self._lib.mrp_hl_solver_last_error(self._h).decode()}")
         stats = dict(wall_seconds=st.wall_seconds, rounds=st.rounds, ll_searches=st.ll_searches,
                      ll_expansions=st.ll_expansions, solved=st.solved, build_seconds=st.build_seconds,
                      ll_call_seconds=st.ll_call_seconds, consume_seconds=st.consume_seconds)
-        return out, stats
+        return (None if raw else self.results_of(prep)), stats
+
+    def results_of(self, prep) -> List[Dict]:
+        out = []
+        csol, plen, pxy = prep["csol"], prep["plen"], prep["pxy"]
+        for i in range(prep["n"]):
+            s = csol[i]
+            rec = dict(status=s.status, cost=s.cost, makespan=s.makespan, hl_expanded=s.high_level_expanded,
+                       ll_expanded=s.low_level_expanded, ll_searches=s.n_ll_searches)
+            if prep["want_paths"] and s.status == SOLVED:
+                assert int(plen[i].max(initial=0)) <= prep["path_cap"]
+                rec["paths"] = [pxy[i][a, :plen[i][a]].tolist() for a in range(len(plen[i]))]
+            out.append(rec)
+        return out
+
+    def solve(self, instances: Sequence[Dict], algo: int = ECBS, w: float = 1.3, max_ll_expansions: int = -1,
+              max_hl_expansions: int = -1, n_threads: int = 0, want_paths: bool = True, path_cap: int = 512,
+              mode: int = 0):
+        prep = self.prepare(instances, n_threads=n_threads, want_paths=want_paths, path_cap=path_cap)
+        try:
+            return self.solve_prepared(prep, algo=algo, w=w, max_ll_expansions=max_ll_expansions,
+                                       max_hl_expansions=max_hl_expansions, mode=mode)
+        finally:
+            self.release(prep)
 
     def prioritized_sipp(self, instances: Sequence[Dict], state_cap: int = 512):
         """example/mapf_prioritized_sipp.cpp for a batch of instances: every round plans the next agent of all of them."""

@@ -57,7 +57,7 @@ class mrp_ll_stats(ctypes.Structure):
 
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
            "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version",
-           "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any", "mrp_ll_submit_lane"]
+           "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any", "mrp_ll_submit_lane", "mrp_ll_sync_maps"]
 
 _lib = None
 
@@ -103,6 +103,8 @@ def load_library(path: Optional[str] = None):
     lib.mrp_ll_submit_lane.restype = ctypes.c_int
     lib.mrp_ll_submit_lane.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(mrp_ll_job),
                                        ctypes.POINTER(mrp_ll_result), I32P]
+    lib.mrp_ll_sync_maps.restype = ctypes.c_int
+    lib.mrp_ll_sync_maps.argtypes = [ctypes.c_void_p]
     lib.mrp_ll_poll_any.restype = ctypes.c_int
     lib.mrp_ll_poll_any.argtypes = [ctypes.c_void_p, I32P, ctypes.c_int32, I32P]
     if path is None:
