@@ -151,6 +151,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
+                "achieved_all_launches_concurrently": ALGO_BYTES_PER_EXPANSION * (exp_all / elapsed_max) / 1e9,
                 "kernel": "mrp_ll_persistent_kernel",
                 "launches": lls["launches"],
                 "avg_launch_ms": lls["kernel_ms"] / max(lls["launches"], 1),
