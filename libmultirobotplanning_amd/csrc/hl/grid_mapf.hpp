@@ -13,6 +13,7 @@ struct Path {                 // PlanResult of one agent (planresult.hpp:18-27);
   std::vector<int32_t> xy;    // [len][2]
   int32_t cost = 0;
   int32_t fmin = 0;
+  bool fits8 = false;         // every coordinate is in 0..255 (set by whoever fills xy; enables the linear scans)
   int32_t len() const { return static_cast<int32_t>(xy.size() / 2); }
 };
 typedef std::shared_ptr<const Path> PathPtr;
@@ -53,9 +54,34 @@ inline int32_t maxT(const std::vector<PathPtr>& sol) {
   return m;
 }
 
+// Per-thread cell -> agent table for the linear-time scans below (coordinates fit 8 bits each: the engine's grids are
+// at most 256 x 256).  Entries are validated by a stamp, so starting a new time step costs nothing.
+struct CellTable {
+  std::vector<uint32_t> stamp;
+  std::vector<int32_t> who;
+  uint32_t now = 0;
+  CellTable() : stamp(65536, 0), who(65536, 0) {}
+  void nextStep() {
+    if (++now == 0) {
+      std::fill(stamp.begin(), stamp.end(), 0u);
+      now = 1;
+    }
+  }
+  static CellTable& local() {
+    static thread_local CellTable t;
+    return t;
+  }
+};
+inline bool fitsCellTable(const std::vector<PathPtr>& sol) {
+  for (const auto& p : sol)
+    if (!p->fits8) return false;
+  return true;
+}
+
 // getFirstConflict (ecbs.cpp:401-452): scan order is t ascending; at each t all vertex pairs (i<j) before all
-// swap pairs (i<j); the final time step is never checked (t < max_t).
-inline bool firstConflict(const std::vector<PathPtr>& sol, Conflict& out, std::vector<int32_t>& scratch) {
+// swap pairs (i<j); the final time step is never checked (t < max_t).  Quadratic restatement, kept for grids whose
+// coordinates do not fit the cell table and as the cross-check of the linear scan in the CPU tests.
+inline bool firstConflictQuadratic(const std::vector<PathPtr>& sol, Conflict& out, std::vector<int32_t>& scratch) {
   const int32_t n = static_cast<int32_t>(sol.size());
   const int32_t T = maxT(sol);
   scratch.resize(static_cast<size_t>(n) * 4);
@@ -82,8 +108,62 @@ inline bool firstConflict(const std::vector<PathPtr>& sol, Conflict& out, std::v
   return false;
 }
 
+// The same result in O(T * N): at each t the agents are entered into the cell table in index order.
+//  * vertex: the lexicographically first pair (i<j) on a common cell is (first occupant, second occupant) of some
+//    cell; the minimum over cells is kept while scanning j upwards.
+//  * swap: reached only when no two agents share a cell at t, so "the agent now standing on i's next cell" is unique;
+//    scanning i upwards, the first i whose partner moves onto i's cell is the first pair in (i<j) order (a partner
+//    j < i would have reported the pair when the scan was at j).
+inline bool firstConflict(const std::vector<PathPtr>& sol, Conflict& out, std::vector<int32_t>& scratch) {
+  if (!fitsCellTable(sol)) return firstConflictQuadratic(sol, out, scratch);
+  const int32_t n = static_cast<int32_t>(sol.size());
+  const int32_t T = maxT(sol);
+  CellTable& tab = CellTable::local();
+  scratch.resize(static_cast<size_t>(n) * 2);
+  int32_t* cur = scratch.data();        // y << 8 | x at t
+  int32_t* nxt = scratch.data() + n;    // at t + 1
+  auto keyAt = [](const Path& p, int32_t t) {
+    const int32_t k = t < p.len() ? t : p.len() - 1;
+    return (p.xy[2 * k + 1] << 8) | p.xy[2 * k];
+  };
+  for (int32_t i = 0; i < n; ++i) cur[i] = keyAt(*sol[i], 0);
+  for (int32_t t = 0; t < T; ++t) {
+    for (int32_t i = 0; i < n; ++i) nxt[i] = keyAt(*sol[i], t + 1);
+    tab.nextStep();
+    int32_t bi = n, bj = n;
+    for (int32_t j = 0; j < n; ++j) {
+      const int32_t key = cur[j];
+      if (tab.stamp[key] == tab.now) {
+        const int32_t i = tab.who[key];
+        if (i < bi || (i == bi && j < bj)) {
+          bi = i;
+          bj = j;
+        }
+      } else {
+        tab.stamp[key] = tab.now;
+        tab.who[key] = j;
+      }
+    }
+    if (bi < n) {
+      out = Conflict{t, bi, bj, Conflict::Vertex, cur[bi] & 255, cur[bi] >> 8, 0, 0};
+      return true;
+    }
+    for (int32_t i = 0; i < n; ++i) {
+      const int32_t key = nxt[i];
+      if (tab.stamp[key] != tab.now) continue;
+      const int32_t j = tab.who[key];
+      if (j != i && nxt[j] == cur[i]) {
+        out = Conflict{t, i, j, Conflict::Edge, cur[i] & 255, cur[i] >> 8, nxt[i] & 255, nxt[i] >> 8};
+        return true;
+      }
+    }
+    std::swap(cur, nxt);
+  }
+  return false;
+}
+
 // focalHeuristic (ecbs.cpp:315-350): number of vertex + swap conflicts over all pairs and t < max_t
-inline int32_t countConflicts(const std::vector<PathPtr>& sol, std::vector<int32_t>& scratch) {
+inline int32_t countConflictsQuadratic(const std::vector<PathPtr>& sol, std::vector<int32_t>& scratch) {
   const int32_t n = static_cast<int32_t>(sol.size());
   const int32_t T = maxT(sol);
   scratch.resize(static_cast<size_t>(n) * 4);
@@ -99,6 +179,51 @@ inline int32_t countConflicts(const std::vector<PathPtr>& sol, std::vector<int32
         total += (cx == cur[2 * j] && cy == cur[2 * j + 1]);
         total += (cx == nxt[2 * j] && cy == nxt[2 * j + 1] && nx == cur[2 * j] && ny == cur[2 * j + 1]);
       }
+    }
+    std::swap(cur, nxt);
+  }
+  return total;
+}
+
+// The same integer with the cell table: agents on one cell are chained (who = last entered, link[] = the one before),
+// an agent entering a cell that already holds c agents adds c vertex conflicts, and the swap partners of agent i are
+// the agents j > i now on i's next cell whose next cell is i's current one.
+inline int32_t countConflicts(const std::vector<PathPtr>& sol, std::vector<int32_t>& scratch) {
+  if (!fitsCellTable(sol)) return countConflictsQuadratic(sol, scratch);
+  const int32_t n = static_cast<int32_t>(sol.size());
+  const int32_t T = maxT(sol);
+  CellTable& tab = CellTable::local();
+  scratch.resize(static_cast<size_t>(n) * 4);
+  int32_t* cur = scratch.data();
+  int32_t* nxt = scratch.data() + n;
+  int32_t* link = scratch.data() + 2 * n;   // previous agent on the same cell, -1 = none
+  int32_t* depth = scratch.data() + 3 * n;  // agents entered before this one on the same cell
+  auto keyAt = [](const Path& p, int32_t t) {
+    const int32_t k = t < p.len() ? t : p.len() - 1;
+    return (p.xy[2 * k + 1] << 8) | p.xy[2 * k];
+  };
+  for (int32_t i = 0; i < n; ++i) cur[i] = keyAt(*sol[i], 0);
+  int32_t total = 0;
+  for (int32_t t = 0; t < T; ++t) {
+    for (int32_t i = 0; i < n; ++i) nxt[i] = keyAt(*sol[i], t + 1);
+    tab.nextStep();
+    for (int32_t j = 0; j < n; ++j) {
+      const int32_t key = cur[j];
+      if (tab.stamp[key] == tab.now) {
+        link[j] = tab.who[key];
+        depth[j] = depth[link[j]] + 1;
+        total += depth[j];
+      } else {
+        tab.stamp[key] = tab.now;
+        link[j] = -1;
+        depth[j] = 0;
+      }
+      tab.who[key] = j;
+    }
+    for (int32_t i = 0; i < n; ++i) {
+      const int32_t key = nxt[i];
+      if (tab.stamp[key] != tab.now) continue;
+      for (int32_t j = tab.who[key]; j > i; j = link[j]) total += (nxt[j] == cur[i]);  // chain is index-descending
     }
     std::swap(cur, nxt);
   }

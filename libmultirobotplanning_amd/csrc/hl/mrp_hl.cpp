@@ -138,10 +138,13 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
       if (r.status == MRP_LL_OK) {
         auto p = std::make_shared<Path>();
         p->xy.resize(static_cast<size_t>(r.n_states) * 2);
+        uint32_t orAll = 0;
         for (int32_t s = 0; s < r.n_states; ++s) {
           p->xy[2 * s] = r.states_txy[3 * s + 1];
           p->xy[2 * s + 1] = r.states_txy[3 * s + 2];
+          orAll |= static_cast<uint32_t>(p->xy[2 * s]) | static_cast<uint32_t>(p->xy[2 * s + 1]);
         }
+        p->fits8 = orAll < 256u;
         p->cost = r.cost;
         p->fmin = r.fmin;
         a.path = p;
@@ -285,6 +288,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   auto t0 = std::chrono::steady_clock::now();
   auto tg2 = t0;
   uint64_t idleSpins = 0;
+  double tmSubmitOk = 0, tmSubmitBusy = 0, tmPollEmpty = 0, tmPollHit = 0, tmUnpack = 0, tmAdvance = 0;
+  uint64_t nSubmitBusy = 0, nPollEmpty = 0, nPollHit = 0;
   auto nowS = []() { return std::chrono::steady_clock::now(); };
   auto secsS = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double>(b - a).count();
@@ -302,12 +307,18 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     // publish as many waiting instances as the ring takes
     while (!backlog.empty()) {
       size_t k = backlog.back();
+      auto ts0 = nowS();
       int r = trySubmit(live[k]);
       if (r < 0) {
         failed = true;
         break;
       }
-      if (r == 0) break;
+      if (r == 0) {
+        tmSubmitBusy += secsS(ts0, nowS());
+        nSubmitBusy += 1;
+        break;
+      }
+      tmSubmitOk += secsS(ts0, nowS());
       backlog.pop_back();
       if (static_cast<size_t>(live[k].ticket) >= ticketOwner.size()) ticketOwner.resize(live[k].ticket + 1, 0);
       ticketOwner[live[k].ticket] = k;
@@ -324,6 +335,13 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       break;
     }
     auto tC = nowS();
+    if (nDone) {
+      tmPollHit += secsS(tB, tC);
+      nPollHit += 1;
+    } else {
+      tmPollEmpty += secsS(tB, tC);
+      nPollEmpty += 1;
+    }
     // resolve the owners first: a ticket id freed by this harvest can be handed out again by a resubmission below
     doneOwners.resize(nDone);
     for (int32_t d = 0; d < nDone; ++d) doneOwners[d] = ticketOwner[doneTickets[d]];
@@ -333,6 +351,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       progress = true;
       nInflight -= 1;
       L.ans.clear();
+      auto tu0 = nowS();
       for (const mrp_ll_result& r : L.res) {
         LLAnswer a;
         a.status = r.status;
@@ -343,20 +362,28 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
         if (r.status == MRP_LL_OK) {
           auto p = std::make_shared<Path>();
           p->xy.resize(static_cast<size_t>(r.n_states) * 2);
+          uint32_t orAll = 0;
           for (int32_t s = 0; s < r.n_states; ++s) {
             p->xy[2 * s] = r.states_txy[3 * s + 1];
             p->xy[2 * s + 1] = r.states_txy[3 * s + 2];
+            orAll |= static_cast<uint32_t>(p->xy[2 * s]) | static_cast<uint32_t>(p->xy[2 * s + 1]);
           }
+          p->fits8 = orAll < 256u;
           p->cost = r.cost;
           p->fmin = r.fmin;
           a.path = p;
         }
         L.ans.push_back(a);
       }
+      auto tu1 = nowS();
       L.inst->advance(L.ans, L.req);
+      auto tu2 = nowS();
+      tmUnpack += secsS(tu0, tu1);
+      tmAdvance += secsS(tu1, tu2);
       if (!L.req.empty()) {
         // publish the follow-up searches at once: a long conflict-tree chain must not wait for the rest of this pass
         int r = backlog.empty() ? trySubmit(L) : 0;
+        if (r == 1) tmSubmitOk += secsS(tu2, nowS());
         if (r < 0) {
           failed = true;
           break;
@@ -398,6 +425,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
                  "cumulative: active wgs %lld, busy %.0f ms, idle %.0f ms, searches %lld, expansions %lld\n", n,
                  ms(tg0, tg1), ms(tg1, tg2), ms(tg2, tg3), ms(tg3, tg4), (long long)ls.session_active_wgs,
                  ls.session_busy_ms, ls.session_idle_ms, (long long)ls.jobs, (long long)ls.expansions);
+    std::fprintf(stderr, "[mrp_hl]   host ms: submit ok %.1f, submit busy %.1f (%llu), poll empty %.1f (%llu), poll hit %.1f (%llu), "
+                 "unpack %.1f, advance %.1f; rounds %lld searches %lld\n", tmSubmitOk * 1e3, tmSubmitBusy * 1e3,
+                 (unsigned long long)nSubmitBusy, tmPollEmpty * 1e3, (unsigned long long)nPollEmpty, tmPollHit * 1e3,
+                 (unsigned long long)nPollHit, tmUnpack * 1e3, tmAdvance * 1e3, (long long)out.rounds, (long long)out.searches);
   }
   if (failed) return;
   for (size_t k = 0; k < n; ++k) {

@@ -80,15 +80,17 @@ struct LaunchParams {
   uint32_t lds_row_words;     // words per row the LDS layout was sized for
   volatile uint32_t* debug;   // host-mapped trace words (MRP_LL_DEBUG only; nullptr otherwise)
   // ---- session mode (mrp_ll_persistent_kernel): host-fed job ring in coherent pinned host memory ----
-  uint32_t* ring_state;       // [ring_size] host writes generation g when slot holds the job of ticket (g-1)*ring_size+slot
-  uint32_t* ring_done;        // [ring_size] device writes g when that job's result is in results[slot]
+  uint32_t* ring_state;       // ticket rings, lane 0 then lane 1: host writes (generation << 11) | job slot for ticket
+                              // (generation-1)*ring_size + index once the job in that slot is ready
+  uint32_t* ring_done;        // [n_slots] device writes ticket+1 when that job's result is in results[slot]
   uint32_t* ring_stop;        // host sets != 0 to end the session
   uint32_t* ring_head;        // host: number of tickets published so far (what waiting workgroups poll)
-  uint32_t* comp_ring;        // host [ring_size]: completion queue, entry = (generation << 11) | slot
+  uint32_t* comp_ring;        // host [n_slots]: completion queue, entry = (generation << 11) | slot
   uint32_t* comp_count;       // device: completions so far (index into comp_ring)
   unsigned long long* sess_ticks; // device [2]: sum over workgroups of 100 MHz ticks spent in jobs / waiting for jobs
-  uint32_t ring_size;         // slots of lane 0 (slots [0, ring_size)); completion ring has ring_size + ring_size1 entries
-  uint32_t ring_size1;        // slots of lane 1, the express lane (slots [ring_size, ring_size + ring_size1))
+  uint32_t ring_size;         // ticket-ring entries of lane 0
+  uint32_t ring_size1;        // ticket-ring entries of lane 1, the express lane (stored after lane 0's)
+  uint32_t n_slots;           // job slots (both lanes); at most 2048 (11-bit slot field)
   uint32_t express_first;     // workgroups with blockIdx.x >= express_first serve lane 1 only
   uint32_t ring_idle_limit_s; // a workgroup that waited this long for a job exits (safety net if the host died)
 };

@@ -907,8 +907,9 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams
 }
 
 // Session mode.  The same workgroups stay resident for a whole solve and are fed through a ring in coherent pinned
-// host memory: workgroup takes ticket t (device atomic), waits until the host has published generation t/R+1 in
-// ring_state[t%R], runs the job, writes the result to host memory and publishes the generation in ring_done.
+// host memory: workgroup takes ticket t (device atomic), waits until the host has published (generation t/R+1, job
+// slot) in ring_state[t%R], runs the job of that slot, writes the result to host memory and publishes t+1 in
+// ring_done[slot].  Job slots come from a host-side free list, so a slow search holds one slot, not the ring.
 // Exit conditions every wave reaches: *ring_stop != 0, or no job for ring_idle_limit_s seconds.
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(LaunchParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -923,15 +924,15 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
   // bulk).  Each lane has its own ticket counter (device) and published-count word (host), 64 bytes apart.
   const uint32_t myLane = blockIdx.x >= P.express_first ? 1u : 0u;
   const uint32_t laneSize = myLane ? P.ring_size1 : P.ring_size;
-  const uint32_t laneBase = myLane ? P.ring_size : 0u;
-  const uint32_t compSize = P.ring_size + P.ring_size1;
+  uint32_t* const laneRing = P.ring_state + (myLane ? P.ring_size : 0u);
+  const uint32_t compSize = P.n_slots;
   uint32_t* const laneTickets = P.queue_head + myLane * 16;
   uint32_t* const laneHead = P.ring_head + myLane * 16;
   for (;;) {
     uint32_t t = atomicAdd(laneTickets, lane == 0 ? 1u : 0u);
     t = rfl(t);
-    const uint32_t slot = laneBase + t % laneSize;
-    const uint32_t gen = t / laneSize + 1;
+    const uint32_t gen = (t / laneSize + 1) & 0x1FFFFFu;
+    uint32_t slot = 0;
     bool stop = false;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
@@ -940,8 +941,11 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
       // thousand idle wavefronts do not saturate PCIe with reads.
       const uint32_t hd = rfl(__hip_atomic_load(laneHead, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
       if ((int32_t)(hd - t) > 0) {
-        const uint32_t st = rfl(__hip_atomic_load(P.ring_state + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
-        if (st == gen) break;
+        const uint32_t e = rfl(__hip_atomic_load(laneRing + t % laneSize, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+        if ((e >> 11) == gen) {
+          slot = e & 2047u;
+          break;
+        }
       }
       const uint32_t sp = rfl(__hip_atomic_load(P.ring_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
       if (sp != 0 || __builtin_amdgcn_s_memrealtime() - t0 > idleLimit) {
@@ -958,7 +962,7 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
     processJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, smem, arenaSlot, jobS,
                resS);
     __threadfence_system();
-    __hip_atomic_store(P.ring_done + slot, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(P.ring_done + slot, t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring
     uint32_t cidx = atomicAdd(P.comp_count, lane == 0 ? 1u : 0u);
     cidx = rfl(cidx);

@@ -98,10 +98,17 @@ struct Ticket {
 };
 
 // ---- session mode: job ring in coherent pinned host memory --------------------------------------------------
+// Two levels: a TICKET ring per lane, consumed strictly in order by the workgroups (entry = generation << 11 | job
+// slot), and a pool of job SLOTS (descriptor, constraint words, path table, result, path) handed out from a free
+// list.  A slot is tied up until its result has been consumed, a ticket entry only until a workgroup has started the
+// job, so one long search never blocks the publication of the searches behind it.
 struct Ring {
-  static constexpr uint32_t kSlots = 2048;                // all slots; lane 0 owns [0, kSlots0), lane 1 the rest
+  static constexpr uint32_t kSlots = 2048;                // all job slots; lane 0 owns [0, kSlots0), lane 1 the rest
   static constexpr uint32_t kSlots0 = 1792;
   static constexpr uint32_t kSlots1 = kSlots - kSlots0;
+  static constexpr uint32_t kTickets0 = 1u << 17;         // ticket-ring entries of lane 0 / lane 1
+  static constexpr uint32_t kTickets1 = 1u << 14;
+  static constexpr uint32_t kTickets = kTickets0 + kTickets1;
   static constexpr uint32_t kSlotConsWords = 1024;        // 4 KB of constraint words per job
   static constexpr uint32_t kSlotPathHalfs = 16 * 1024;   // 32 KB path table per job
   uint8_t* block = nullptr;        // one coherent allocation holding everything below
@@ -119,18 +126,22 @@ struct Ring {
   std::vector<uint8_t> busy;       // slot holds a job whose result the host has not consumed yet
   std::vector<int32_t> slotTicket; // slot -> session ticket id / job index inside it
   std::vector<int32_t> slotJob;
-  std::vector<uint32_t> slotGen;   // generation the occupant's done word will show (valid while busy)
+  std::vector<uint32_t> slotGen;   // value the occupant's done word will show: its ticket number + 1 (valid while busy)
+  std::vector<uint32_t> freeSlots[2];  // per lane: job slots not in use (stack)
+  std::vector<uint32_t> tkSlot, tkSeq; // per ticket-ring entry: the slot / done value of the job last published there
+  uint32_t Q[2] = {kTickets0, kTickets1};  // ticket-ring entries in use (MRP_LL_TICKET_RING shrinks them: wrap tests)
   bool active = false;
   uint32_t grid = 0, expressWgs = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 struct SessTicket {
   bool used = false;
-  uint64_t first = 0;
   int32_t lane = 0;
   int32_t n = 0, remaining = 0;
   mrp_ll_result* res = nullptr;
   std::vector<uint8_t> state;      // per job: 0 pending, 1 consumed, 2 rejected on the host
+  std::vector<uint32_t> slots;     // per job: its job slot
+  std::vector<uint32_t> seq;       // per job: the done value that marks it finished
 };
 
 }  // namespace
@@ -728,7 +739,7 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
       off += (bytes + 255) & ~size_t(255);
       return o;
     };
-    size_t oState = take(R * 4), oDone = take(R * 4), oComp = take(R * 4), oStop = take(256), oHead = take(256), oJobs = take(R * sizeof(DevJob)),
+    size_t oState = take(Ring::kTickets * 4), oDone = take(R * 4), oComp = take(R * 4), oStop = take(256), oHead = take(256), oJobs = take(R * sizeof(DevJob)),
            oRes = take(R * sizeof(DevResult)), oOut = take(static_cast<size_t>(R) * g.outStride * 2),
            oCons = take(static_cast<size_t>(R) * Ring::kSlotConsWords * 4),
            oPaths = take(static_cast<size_t>(R) * Ring::kSlotPathHalfs * 2);
@@ -749,7 +760,7 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
     HIPCHK(ctx, hipEventCreate(&g.ev0));
     HIPCHK(ctx, hipEventCreate(&g.ev1));
   }
-  std::memset(g.state, 0, R * 4);
+  std::memset(g.state, 0, Ring::kTickets * 4);
   std::memset(g.done, 0, R * 4);
   std::memset(g.compRing, 0, R * 4);
   g.compCursor = 0;
@@ -761,6 +772,12 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   g.slotTicket.assign(R, -1);
   g.slotJob.assign(R, 0);
   g.slotGen.assign(R, 0);
+  g.tkSlot.assign(Ring::kTickets, 0xFFFFFFFFu);
+  g.tkSeq.assign(Ring::kTickets, 0);
+  g.freeSlots[0].clear();
+  g.freeSlots[1].clear();
+  for (uint32_t sl = Ring::kSlots0; sl-- > 0;) g.freeSlots[0].push_back(sl);
+  for (uint32_t sl = Ring::kSlots; sl-- > Ring::kSlots0;) g.freeSlots[1].push_back(sl);
   ctx->sess.clear();
   ctx->sessFree.clear();
   auto devPtr = [&](void* hostPtr) {
@@ -782,8 +799,16 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   P.comp_ring = static_cast<uint32_t*>(devPtr(g.compRing));
   P.comp_count = g.compCountDev;
   P.sess_ticks = g.ticksDev;
-  P.ring_size = Ring::kSlots0;
-  P.ring_size1 = Ring::kSlots1;
+  g.Q[0] = Ring::kTickets0;
+  g.Q[1] = Ring::kTickets1;
+  if (const char* e = std::getenv("MRP_LL_TICKET_RING")) {  // test knob: small rings wrap often
+    const uint32_t q = static_cast<uint32_t>(std::atoi(e));
+    g.Q[0] = std::min(Ring::kTickets0, std::max(q, Ring::kSlots0));
+    g.Q[1] = std::min(Ring::kTickets1, std::max(q, Ring::kSlots1));
+  }
+  P.ring_size = g.Q[0];
+  P.ring_size1 = g.Q[1];
+  P.n_slots = Ring::kSlots;
   P.ring_idle_limit_s = 20;
   uint32_t ldsBytes = 0;
   rc = fillCommonParams(ctx, t, P, ldsBytes);
@@ -837,14 +862,20 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
                          int32_t* ticketOut) {
   Ring& g = ctx->ring;
   if (lane == 1 && g.expressWgs == 0) lane = 0;  // no express workgroups in this session
-  const uint32_t R = lane ? Ring::kSlots1 : Ring::kSlots0;
-  const uint32_t base = lane ? Ring::kSlots0 : 0;
-  if (nJobs > static_cast<int32_t>(R)) {
+  const uint32_t nSlotsLane = lane ? Ring::kSlots1 : Ring::kSlots0;
+  const uint32_t Q = g.Q[lane];
+  const uint32_t qBase = lane ? g.Q[0] : 0;
+  if (nJobs > static_cast<int32_t>(nSlotsLane)) {
     ctx->err = "mrp_ll_submit (session): batch larger than the ring";
     return MRP_LL_E_INVALID;
   }
-  for (int i = 0; i < nJobs; ++i)
-    if (g.busy[base + (g.head[lane] + i) % R]) return MRP_LL_E_BUSY;  // caller must consume finished tickets first
+  if (g.freeSlots[lane].size() < static_cast<size_t>(nJobs)) return MRP_LL_E_BUSY;  // consume finished tickets first
+  for (int i = 0; i < nJobs; ++i) {
+    // a ticket entry may be overwritten once the job published there a whole ring ago has been consumed
+    const uint32_t qi = qBase + static_cast<uint32_t>((g.head[lane] + i) % Q);
+    const uint32_t prev = g.tkSlot[qi];
+    if (prev != 0xFFFFFFFFu && g.busy[prev] && g.slotGen[prev] == g.tkSeq[qi]) return MRP_LL_E_BUSY;
+  }
   auto packT0 = std::chrono::steady_clock::now();
   int ti = -1;
   if (!ctx->sessFree.empty()) {
@@ -856,16 +887,19 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
   }
   SessTicket& st = ctx->sess[ti];
   st.used = true;
-  st.first = g.head[lane];
   st.lane = lane;
   st.n = nJobs;
   st.remaining = nJobs;
   st.res = results;
   st.state.assign(nJobs, 0);
+  st.slots.resize(nJobs);
+  st.seq.resize(nJobs);
   for (int i = 0; i < nJobs; ++i) {
     const uint64_t tk = g.head[lane] + i;
-    const uint32_t slot = base + static_cast<uint32_t>(tk % R);
-    const uint32_t gen = static_cast<uint32_t>(tk / R) + 1;
+    const uint32_t qi = qBase + static_cast<uint32_t>(tk % Q);
+    const uint32_t gen = (static_cast<uint32_t>(tk / Q) + 1) & 0x1FFFFFu;
+    const uint32_t slot = g.freeSlots[lane].back();
+    g.freeSlots[lane].pop_back();
     ConsSinkSlot cs{g.cons + static_cast<size_t>(slot) * Ring::kSlotConsWords, slot * Ring::kSlotConsWords,
                     Ring::kSlotConsWords};
     PathSinkSlot ps{g.paths + static_cast<size_t>(slot) * Ring::kSlotPathHalfs, slot * Ring::kSlotPathHalfs,
@@ -880,11 +914,15 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
     g.busy[slot] = 1;
     g.slotTicket[slot] = ti;
     g.slotJob[slot] = i;
-    g.slotGen[slot] = gen;
-    __atomic_store_n(g.state + slot, gen, __ATOMIC_RELEASE);  // publish: the job data above is visible first
+    g.slotGen[slot] = static_cast<uint32_t>(tk) + 1u;
+    g.tkSlot[qi] = slot;
+    g.tkSeq[qi] = g.slotGen[slot];
+    st.slots[i] = slot;
+    st.seq[i] = g.slotGen[slot];
+    __atomic_store_n(g.state + qi, (gen << 11) | slot, __ATOMIC_RELEASE);  // publish: the job data above is visible first
   }
   g.head[lane] += static_cast<uint64_t>(nJobs);
-  // after every slot's state word
+  // after every ticket entry
   __atomic_store_n(g.headWord + 16 * lane, static_cast<uint32_t>(g.head[lane]), __ATOMIC_RELEASE);
   ctx->stats.pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - packT0).count();
   *ticketOut = ti;
@@ -906,19 +944,16 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
   }
   if (ticket < 0 || ticket >= static_cast<int32_t>(ctx->sess.size()) || !ctx->sess[ticket].used) return MRP_LL_E_INVALID;
   SessTicket& st = ctx->sess[ticket];
-  const uint32_t R = st.lane ? Ring::kSlots1 : Ring::kSlots0;
-  const uint32_t base = st.lane ? Ring::kSlots0 : 0;
   for (int i = 0; i < st.n && st.remaining > 0; ++i) {
     if (st.state[i] == 1) continue;
-    const uint64_t tk = st.first + i;
-    const uint32_t slot = base + static_cast<uint32_t>(tk % R);
-    const uint32_t gen = static_cast<uint32_t>(tk / R) + 1;
-    if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != gen) continue;
+    const uint32_t slot = st.slots[i];
+    if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != st.seq[i]) continue;
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
                  st.res[i]);
     st.state[i] = 1;
     st.remaining -= 1;
     g.busy[slot] = 0;
+    g.freeSlots[st.lane].push_back(slot);
   }
   *doneOut = st.remaining == 0 ? 1 : 0;
   if (st.remaining == 0) {
@@ -950,6 +985,7 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
     st.state[i] = 1;
     st.remaining -= 1;
     g.busy[slot] = 0;
+    g.freeSlots[st.lane].push_back(slot);
     if (st.remaining == 0) {
       st.used = false;
       ctx->sessFree.push_back(g.slotTicket[slot]);

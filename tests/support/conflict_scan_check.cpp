@@ -1,0 +1,48 @@
+// TEST INFRASTRUCTURE ONLY.  Cross-checks the linear-time conflict scans of csrc/hl/grid_mapf.hpp against their
+// quadratic restatements of ecbs.cpp:401-452 / :315-350 on random, collision-rich path sets.  Prints "ok <cases>".
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../libmultirobotplanning_amd/csrc/hl/grid_mapf.hpp"
+
+using namespace mrp_hl;
+
+int main(int argc, char** argv) {
+  const int cases = argc > 1 ? std::atoi(argv[1]) : 20000;
+  std::mt19937 rng(12345);
+  std::vector<int32_t> s1, s2;
+  for (int c = 0; c < cases; ++c) {
+    const int n = 1 + rng() % 12;
+    const int side = 2 + rng() % 5;  // tiny grids: plenty of vertex and swap conflicts
+    std::vector<PathPtr> sol;
+    for (int a = 0; a < n; ++a) {
+      auto p = std::make_shared<Path>();
+      const int len = 1 + rng() % 9;
+      int x = rng() % side, y = rng() % side;
+      for (int k = 0; k < len; ++k) {
+        p->xy.push_back(x);
+        p->xy.push_back(y);
+        const int m = rng() % 5;
+        if (m == 1 && x > 0) --x;
+        if (m == 2 && x + 1 < side) ++x;
+        if (m == 3 && y > 0) --y;
+        if (m == 4 && y + 1 < side) ++y;
+      }
+      p->cost = len - 1;
+      p->fits8 = true;
+      sol.push_back(p);
+    }
+    Conflict a{}, b{};
+    const bool fa = firstConflict(sol, a, s1), fb = firstConflictQuadratic(sol, b, s2);
+    if (fa != fb) return std::printf("case %d: found %d vs %d\n", c, fa, fb), 1;
+    if (fa && (a.time != b.time || a.agent1 != b.agent1 || a.agent2 != b.agent2 || a.type != b.type || a.x1 != b.x1 ||
+               a.y1 != b.y1 || (a.type == Conflict::Edge && (a.x2 != b.x2 || a.y2 != b.y2))))
+      return std::printf("case %d: conflict differs (t %d/%d agents %d,%d / %d,%d type %d/%d)\n", c, a.time, b.time,
+                         a.agent1, a.agent2, b.agent1, b.agent2, a.type, b.type), 1;
+    const int ca = countConflicts(sol, s1), cb = countConflictsQuadratic(sol, s2);
+    if (ca != cb) return std::printf("case %d: count %d vs %d\n", c, ca, cb), 1;
+  }
+  std::printf("ok %d\n", cases);
+  return 0;
+}

@@ -102,3 +102,14 @@ def test_generator_is_deterministic_and_well_formed():
                     seen.add(c)
                     todo.append(c)
         assert tuple(g) in seen
+
+
+def test_linear_conflict_scans_match_quadratic_restatement():
+    """grid_mapf.hpp's O(T*N) getFirstConflict / focalHeuristic scans vs the quadratic restatements of
+    ecbs.cpp:401-452 / :315-350 on 100k random collision-rich path sets (tests/support/conflict_scan_check.cpp)."""
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "conflict_scan_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe,
+                           os.path.join(ROOT, "tests", "support", "conflict_scan_check.cpp")])
+    out = subprocess.check_output([exe, "100000"], timeout=300).decode()
+    assert out.strip() == "ok 100000", out

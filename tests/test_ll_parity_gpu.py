@@ -6,6 +6,8 @@ success, cost, fmin, the onExpandNode count and the full path.  Calls are harves
 oracle on shipped benchmark inputs (tests/golden/bench_instances.json), so constraint sets and focal contexts are the
 ones the conflict tree really produces.
 """
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -129,10 +131,14 @@ def test_session_mode_matches_oracle(oracle_mod, bench_instances):
         import ctypes
         import numpy as np
         lib = ll.load_library()
-        eng.session_begin(64)
+        os.environ["MRP_LL_TICKET_RING"] = "256"  # smallest ticket rings (1792 / 256 entries): they wrap 2x / 7x below
+        try:
+            eng.session_begin(64)
+        finally:
+            del os.environ["MRP_LL_TICKET_RING"]
         try:
             small = cases[:40]
-            total = 6000  # ring has 2048 slots
+            total = 6000  # 2048 job slots, re-used from the free list in completion order
             inflight = {}
             done_buf = (ctypes.c_int32 * 256)()
             n_done = ctypes.c_int32(0)
