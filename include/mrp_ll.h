@@ -160,8 +160,9 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket);
  * search of a batch.  Results are identical to the batch mode's. */
 int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups /* 0 = mrp_ll_options.slots */);
 int mrp_ll_session_end(mrp_ll_ctx* ctx);
-/* Session mode: `lane` 0 = the bulk ring, 1 = the express ring, served by a few dedicated wavefronts and therefore
- * never congested by lane 0 (use it for the searches of a long chain of dependent rounds).  mrp_ll_submit == lane 0. */
+/* Session mode: `lane` 0 = the bulk ring (first in, first out), 1 = the priority ring: every resident wavefront looks
+ * there before it takes its next bulk job, so a lane-1 search starts within one job time however long the bulk queue is
+ * (use it for the searches of a long chain of dependent rounds).  mrp_ll_submit == lane 0. */
 int mrp_ll_submit_lane(mrp_ll_ctx* ctx, int32_t lane, int32_t n_jobs, const mrp_ll_job* jobs, mrp_ll_result* results,
                        int32_t* ticket);
 int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* done);

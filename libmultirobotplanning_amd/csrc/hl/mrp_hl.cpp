@@ -34,7 +34,7 @@ struct mrp_hl_solver {
 
 namespace {
 
-constexpr int64_t kDeepHl = 24;  // conflict-tree expansions after which an instance counts as a long chain
+constexpr int64_t kDeepHl = 4;  // conflict-tree expansions after which an instance counts as a long chain
 
 struct GroupResult {
   int64_t rounds = 0, searches = 0, expansions = 0;
@@ -207,6 +207,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   std::vector<size_t> poolOff;
 
   const bool timing = std::getenv("MRP_HL_TIMING") != nullptr;
+  int64_t deepHl = kDeepHl;
+  if (const char* e = std::getenv("MRP_HL_DEEP")) deepHl = std::atoll(e);  // tuning knob
   auto tg0 = std::chrono::steady_clock::now();
   if (mrp_ll_session_begin(ctx, workgroups) != MRP_LL_SUCCESS) {
     out.err = std::string("mrp_ll_session_begin: ") + mrp_ll_last_error(ctx);
@@ -257,9 +259,9 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       L.res[q].states_txy = L.states.data() + q * static_cast<size_t>(cap) * 3;
       L.res[q].states_cap = cap;
     }
-    // an instance deep in its conflict tree is a long chain of dependent rounds: its searches take the express lane,
-    // which the bulk never congests, so the chain advances alongside the bulk instead of after it
-    const int32_t lane = I.hlExpanded() >= kDeepHl ? 1 : 0;
+    // an instance deep in its conflict tree is a long chain of dependent rounds: its searches take the priority lane,
+    // which every workgroup serves before the bulk, so the chain advances alongside the bulk instead of after it
+    const int32_t lane = I.hlExpanded() >= deepHl ? 1 : 0;
     int rc = mrp_ll_submit_lane(ctx, lane, static_cast<int32_t>(jobs.size()), jobs.data(), L.res.data(), &L.ticket);
     if (rc == MRP_LL_E_BUSY) return 0;
     if (rc != MRP_LL_SUCCESS) {

@@ -89,9 +89,8 @@ struct LaunchParams {
   uint32_t* comp_count;       // device: completions so far (index into comp_ring)
   unsigned long long* sess_ticks; // device [2]: sum over workgroups of 100 MHz ticks spent in jobs / waiting for jobs
   uint32_t ring_size;         // ticket-ring entries of lane 0
-  uint32_t ring_size1;        // ticket-ring entries of lane 1, the express lane (stored after lane 0's)
+  uint32_t ring_size1;        // ticket-ring entries of lane 1, the priority lane (stored after lane 0's)
   uint32_t n_slots;           // job slots (both lanes); at most 2048 (11-bit slot field)
-  uint32_t express_first;     // workgroups with blockIdx.x >= express_first serve lane 1 only
   uint32_t ring_idle_limit_s; // a workgroup that waited this long for a job exits (safety net if the host died)
 };
 

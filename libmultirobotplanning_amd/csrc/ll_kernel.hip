@@ -245,6 +245,171 @@ DEVI void openErase(Mem<AS>& m, uint32_t& n, uint32_t idx) {
   heapPop<AS, 0, true>(m, m.open, n);
 }
 
+// ---- batched operations of one expansion ------------------------------------------------------------------------
+// An expansion pops one element and pushes up to five.  Done one heap operation at a time that is a chain of ~25
+// dependent memory round trips; the results of the operations, however, depend on each other only through a handful
+// of heap entries, so the loads of ALL of them are issued first and the sequential semantics are then resolved in
+// registers:
+//   * pushes: the sift-up chain of the k-th new element is held LEVEL-MAJOR — lane L owns the chain's node at tree
+//     level L (root = level 0), for every k.  Two chains that pass through the same heap position do so at the same
+//     level, i.e. in the same lane, so "what did an earlier push of this expansion leave at this position" is a
+//     per-lane select; the one-level move of the ancestors that a sift-up performs is a one-lane shift of the wave
+//     (DPP wave_shr:1).  Five pushes into two heaps cost one round trip.
+//   * pops: the loads of the focal and the open sift-down (which child is the larger one does not depend on the
+//     element being sifted) are issued together, and the moved "last" elements are fetched with them.
+DEVI uint32_t waveShr1(uint32_t v) {  // lane i receives lane i-1's value (lane 0 keeps its own)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);
+}
+DEVI uint64_t waveShr1_64(uint64_t v) {
+  return ((uint64_t)waveShr1((uint32_t)(v >> 32)) << 32) | waveShr1((uint32_t)v);
+}
+
+constexpr uint32_t kNoPos = 0xFFFFFFFFu;
+
+template <int AS>
+struct PushChains {          // sift-up chains of the (up to five) pushes of one expansion into one heap
+  uint32_t pos[5];           // lane L: heap position of the chain's node at level L (kNoPos: none)
+  uint64_t val[5];           // lane L: the entry there before any of these pushes
+  // `mask` bit k: successor k is pushed; pushed elements take positions n0, n0+1, ... in ascending k
+  DEVI void load(typename Mem<AS>::P64 heap, uint32_t n0, uint32_t mask) {
+    const uint32_t lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      pos[k] = kNoPos;
+      val[k] = 0;
+      if ((mask >> k) & 1u) {
+        const uint32_t p = n0 + (uint32_t)__builtin_popcount(mask & ((1u << k) - 1u));
+        const uint32_t d = 31u - (uint32_t)__builtin_clz(p + 1);  // level of p == number of ancestors
+        if (lane <= d) pos[k] = ((p + 1) >> (d - lane)) - 1;
+        if (lane < d) val[k] = heap[pos[k]];
+      }
+    }
+  }
+  // boost siftup / libstdc++ __push_heap of e[k] at its position, for k ascending — the same stores a one-at-a-time
+  // replay ends with (positions written twice are written in push order).
+  template <int KEY, bool POS>
+  DEVI void resolve(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t n0, uint32_t mask, const uint64_t (&e)[5]) {
+    const uint32_t lane = threadIdx.x;
+    uint64_t nv[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      nv[k] = 0;
+      if ((mask >> k) & 1u) {
+        const uint32_t p = n0 + (uint32_t)__builtin_popcount(mask & ((1u << k) - 1u));
+        const uint32_t d = 31u - (uint32_t)__builtin_clz(p + 1);
+        uint64_t v = val[k];
+#pragma unroll
+        for (int j = 0; j < k; ++j)  // what earlier pushes of this expansion left on this chain
+          if (((mask >> j) & 1u) && pos[j] == pos[k] && pos[k] != kNoPos) v = nv[j];
+        const uint64_t worse = __ballot(lane < d && kLess<KEY>(v, e[k]));
+        const uint64_t notWorse = ~worse & ((1ull << d) - 1ull);
+        const int32_t sLvl = notWorse ? 63 - (int32_t)__builtin_clzll(notWorse) : -1;  // deepest ancestor that stays
+        const uint64_t sh = waveShr1_64(v);
+        const uint64_t nk = (int32_t)lane <= sLvl ? v : ((int32_t)lane == sLvl + 1 ? e[k] : sh);
+        if ((int32_t)lane > sLvl && lane <= d) {
+          heap[pos[k]] = nk;
+          if (POS) ((typename Mem<AS>::P32)m.nodes)[entryId(nk) * 4 + 3] = pos[k];
+        }
+        nv[k] = nk;
+      }
+    }
+  }
+};
+
+// One 6-level block of a sift-down whose child pairs have been loaded (see descend): follows the path, pulls the
+// chosen children up, returns the new hole; `more` = the block was left through its bottom.
+template <int AS, int KEY, bool POS>
+DEVI uint32_t descendBlock(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx, uint32_t xk, u64x2 pr, uint32_t node,
+                           bool has, bool hasR, bool& more) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t kl = KEY == 0 ? openKey(pr.x) : entryKey(pr.x);
+  const uint32_t kr = KEY == 0 ? openKey(pr.y) : entryKey(pr.y);
+  const bool right = hasR && (kl < kr);
+  const uint64_t pe = right ? pr.y : pr.x;
+  const uint32_t pk = right ? kr : kl;
+  const bool go = has && !(pk < xk);
+  const uint64_t goMask = __ballot(go);
+  const uint64_t rightMask = __ballot(right);
+  uint64_t pathMask = 0;
+  uint32_t rel = 0, steps = 0;
+#pragma unroll 1
+  while (steps < 6 && ((goMask >> rel) & 1ull)) {
+    pathMask |= 1ull << rel;
+    rel = 2 * rel + 1 + (uint32_t)((rightMask >> rel) & 1ull);
+    steps += 1;
+  }
+  if ((pathMask >> lane) & 1ull) {
+    heap[node] = pe;
+    if (POS) ((typename Mem<AS>::P32)m.nodes)[entryId(pe) * 4 + 3] = node;
+  }
+  more = steps == 6;
+  return ((idx + 1) << steps) - 1 + (rel + 1 - (1u << steps));
+}
+
+// a_star_epsilon.hpp:191-192 of one expansion: focalSet.pop() and openSet.erase(handle of the same node), with the
+// memory traffic of the two heaps overlapped.  curPos = position of the popped node in the open array.
+template <int AS>
+DEVI void popFocalEraseOpen(Mem<AS>& m, uint32_t& nFocal, uint32_t& nOpen, uint32_t curPos) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lv = 31u - (uint32_t)__builtin_clz(lane + 1);
+  const uint32_t off = (lane + 1) - (1u << lv);
+  // ---- loads that depend on nothing but the sizes
+  nFocal -= 1;
+  const uint32_t nOld = nOpen;
+  nOpen -= 1;
+  uint64_t lastFv = 0, lastOv = 0;
+  if (nFocal > 0) lastFv = m.focal[nFocal];
+  if (nOpen > 0) lastOv = m.open[nOld - 1];
+  const uint32_t depth = 31u - (uint32_t)__builtin_clz(curPos + 1);
+  const bool act = lane < depth;
+  const uint32_t anc = act ? ((curPos + 1) >> (lane + 1)) - 1 : 0;
+  uint64_t ae = 0;
+  if (depth != 0) ae = m.open[anc];
+  // first block of the focal sift-down: does not depend on the element being sifted
+  uint32_t idxF = 0, idxO = 0;
+  bool moreF = nFocal > 0, moreO = nOpen > 0;
+  u64x2 prF;
+  prF.x = 0; prF.y = 0;
+  const uint32_t nodeF0 = (1u << lv) - 1 + off;
+  const bool hasF0 = moreF && lane < 63 && (2 * nodeF0 + 1 < nFocal);
+  if (hasF0) prF = *(typename Mem<AS>::PPair)(m.focal + 2 * nodeF0 + 1);
+  // ---- open: every ancestor of curPos moves down one level (boost erase = bubble to the root, then pop)
+  if (act) {
+    const uint32_t dest = ((curPos + 1) >> lane) - 1;
+    m.open[dest] = ae;
+    ((typename Mem<AS>::P32)m.nodes)[entryId(ae) * 4 + 3] = dest;
+  }
+  // the element that pop() moves to the root: the last one — which the shift above has just overwritten if the erased
+  // node WAS the last one (then it is the erased node's parent)
+  uint64_t lastO = rfl64(lastOv);
+  if (curPos == nOld - 1 && depth != 0) lastO = readlane64(ae, 0);
+  const uint64_t lastF = rfl64(lastFv);
+  const uint32_t xkF = entryKey(lastF), xkO = openKey(lastO);
+  // ---- sift-downs, block by block, both heaps per round trip
+  bool firstF = true;
+  for (;;) {
+    u64x2 prO;
+    prO.x = 0; prO.y = 0;
+    const uint32_t nodeO = ((idxO + 1) << lv) - 1 + off;
+    const bool hasO = moreO && lane < 63 && (2 * nodeO + 1 < nOpen);
+    if (hasO) prO = *(typename Mem<AS>::PPair)(m.open + 2 * nodeO + 1);
+    uint32_t nodeF = nodeF0;
+    bool hasF = hasF0;
+    if (!firstF) {
+      nodeF = ((idxF + 1) << lv) - 1 + off;
+      hasF = moreF && lane < 63 && (2 * nodeF + 1 < nFocal);
+      prF.x = 0; prF.y = 0;
+      if (hasF) prF = *(typename Mem<AS>::PPair)(m.focal + 2 * nodeF + 1);
+    }
+    firstF = false;
+    if (moreF) idxF = descendBlock<AS, 1, false>(m, m.focal, idxF, xkF, prF, nodeF, hasF, hasF && (2 * nodeF + 2 < nFocal), moreF);
+    if (moreO) idxO = descendBlock<AS, 0, true>(m, m.open, idxO, xkO, prO, nodeO, hasO, hasO && (2 * nodeO + 2 < nOpen), moreO);
+    if (!moreF && !moreO) break;
+  }
+  if (nFocal > 0) m.focal[idxF] = lastF;
+  if (nOpen > 0) heapStore<AS, true>(m, m.open, idxO, lastO);
+}
+
 // ---- ordered walk (open.ordered_begin(), a_star_epsilon.hpp:141-152) ----------------------------------------
 // libstdc++ std::priority_queue<…> restated: push = __push_heap, pop = __pop_heap/__adjust_heap (bits/stl_heap.h).
 template <int AS>
@@ -343,6 +508,8 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
                    typename Mem<AS>::P32 ecLocal, bool useLocal, DevResult& res, uint16_t* outPath) {
   const uint32_t lane = threadIdx.x;
   uint32_t dbgIter = 0;
+  // edge-constraint keys, one per lane (lists longer than a wave keep their tail in memory)
+  const uint32_t ecReg = lane < c.nEc ? c.ec[lane] : 0xFFFFFFFFu;
   for (;;) {
     DBG(c, 5, ++dbgIter);
     if (s.nOpen == 0) return ST_NO_SOLUTION;
@@ -408,92 +575,120 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
       return ST_OK;
     }
 
-    {
-      PROF_T0();
-      if (EPS) {
-        heapPop<AS, 1, false>(m, m.focal, s.nFocal);
-        openErase<AS>(m, s.nOpen, curPos);
-      } else {
-        heapPop<AS, 0, true>(m, m.open, s.nOpen);
-      }
-      PROF_ADD(res, 1);
-    }
-
     const uint32_t t1 = t + 1;
     {
       PROF_T0();
       ensureRows<AS>(m, s, c, t1, c.obst, obstLocal, useLocal);
       PROF_ADD(res, 4);
     }
-    PROF_T0();
-
-    // successors in the reference's order Wait, Left, Right, Up, Down (ecbs.cpp:365-398) on lanes 0..4
+    // successors in the reference's order Wait, Left, Right, Up, Down (ecbs.cpp:365-398) on lanes 0..4; the bitmap
+    // words are requested before the pops below so that their latency is hidden behind them
     const int32_t dx = (lane == 2) - (lane == 1);
     const int32_t dy = (lane == 3) - (lane == 4);
     const uint32_t nx = x + (uint32_t)dx, ny = y + (uint32_t)dy;
     const bool inb = (lane < 5) && (nx < c.dimx) && (ny < c.dimy);
     const uint32_t ncell = inb ? ny * c.dimx + nx : 0;
     const uint32_t curCell = y * c.dimx + x;
-    uint32_t word = m.bits[t1 * m.rowWords + (ncell >> 5)];
+    const uint32_t bitIdx = t1 * m.rowWords + (ncell >> 5);
+    const uint32_t word = m.bits[bitIdx];
+
+    {
+      PROF_T0();
+      if (EPS) {
+        popFocalEraseOpen<AS>(m, s.nFocal, s.nOpen, curPos);
+      } else {
+        heapPop<AS, 0, true>(m, m.open, s.nOpen);
+      }
+      PROF_ADD(res, 1);
+    }
+    PROF_T0();
     bool ok = inb && !((word >> (ncell & 31)) & 1u);
-    if (c.nEc) {  // transitionValid (ecbs.cpp:505-510)
-      const uint32_t key = (t << 19) | (curCell << 3) | lane;
-      for (uint32_t j = 0; j < c.nEc; ++j) {
-        uint32_t e = (j < 64) ? ecLocal[j] : c.ec[j];
-        ok = ok && (e != key);
+    uint32_t mask = (uint32_t)(__ballot(ok) & 0x1Full);
+    if (c.nEc) {  // transitionValid (ecbs.cpp:505-510): lane j holds edge-constraint key j = t << 19 | cell << 3 | action
+      const uint32_t base = (t << 19) | (curCell << 3);
+      const uint32_t d = ecReg - base;
+      uint32_t blocked = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 5; ++k) blocked |= __ballot(d == k) ? (1u << k) : 0u;
+      for (uint32_t j = 64; j < c.nEc; ++j) {  // lists longer than a wave: the rest one by one
+        const uint32_t dd = rfl(c.ec[j]) - base;
+        if (dd < 5) blocked |= 1u << dd;
+      }
+      mask &= ~blocked;
+    }
+    PROF_ADD(res, 3);
+    if (mask == 0) continue;
+
+    // ---- the successors' entries (order-independent part: heuristics, node records, discovered marks)
+    uint64_t e[5];
+    uint32_t maskF = 0;
+    const float bound = __fmul_rn((float)s.bestF, c.w);  // a_star_epsilon.hpp:240, binary32
+    const uint32_t nBase = s.nNodes;
+#pragma unroll
+    for (uint32_t k = 0; k < 5; ++k) {
+      e[k] = 0;
+      if ((mask >> k) & 1u) {
+        const uint32_t cx = __builtin_amdgcn_readlane(nx, k);
+        const uint32_t cy = __builtin_amdgcn_readlane(ny, k);
+        const uint32_t cc = __builtin_amdgcn_readlane(ncell, k);
+        uint32_t fh = curFh;
+        if (EPS && c.nAgentsPad) {
+          // focalStateHeuristic (ecbs.cpp:282-295) + focalTransitionHeuristic (ecbs.cpp:298-312)
+          uint32_t cnt = __popcll(__ballot(b0 == cc)) + __popcll(__ballot(a0 == cc && b0 == curCell));
+          if (c.nAgentsPad > 64) {
+            cnt += __popcll(__ballot(b1 == cc)) + __popcll(__ballot(a1 == cc && b1 == curCell));
+            for (uint32_t base = 128; base < c.nAgentsPad; base += 64) {
+              uint32_t av = kEmptyCell, bv = kEmptyCell;
+              if (base + lane < c.nAgentsPad) {
+                av = rowA[base + lane];
+                bv = rowB[base + lane];
+              }
+              cnt += __popcll(__ballot(bv == cc)) + __popcll(__ballot(av == cc && bv == curCell));
+            }
+          }
+          fh += cnt;
+          if (fh > kFhMax) return ST_CAP_FOCAL;
+        }
+        const uint32_t h = (cx > c.gx ? cx - c.gx : c.gx - cx) + (cy > c.gy ? cy - c.gy : c.gy - cy);
+        const uint32_t f = t1 + h;
+        const uint32_t nid = nBase + (uint32_t)__builtin_popcount(mask & ((1u << k) - 1u));
+        u32x4 nn;
+        nn.x = cx | (cy << 8) | (t1 << 16) | (k << 27);
+        nn.y = curId;
+        nn.z = fh;
+        nn.w = 0;
+        m.nodes[nid] = nn;
+        e[k] = packEntry(fh, f, t1, nid);
+        if (EPS && (float)(int32_t)f <= bound) maskF |= 1u << k;
       }
     }
-    uint64_t mask = __ballot(ok) & 0x1Full;
-    PROF_ADD(res, 3);
+    s.nNodes = nBase + (uint32_t)__builtin_popcount(mask);
+    // mark (t1, cell) discovered: stands for stateToHeap / closedSet membership (a_star_epsilon.hpp:224-227); the
+    // successors of one expansion are distinct cells, so marking them together changes nothing
+    {
+      const bool mine = lane < 5 && ((mask >> lane) & 1u);
+      const uint32_t myBit = mine ? 1u << (ncell & 31) : 0u;
+      uint32_t merged = word;  // successors that share a bitmap word all store the same merged word
+#pragma unroll
+      for (uint32_t k = 0; k < 5; ++k) {
+        const uint32_t oi = __builtin_amdgcn_readlane(bitIdx, k);
+        const uint32_t ob = __builtin_amdgcn_readlane(myBit, k);
+        merged |= oi == bitIdx ? ob : 0u;
+      }
+      if (mine) m.bits[bitIdx] = merged;
+    }
 
-    while (mask) {
-      const uint32_t k = (uint32_t)__builtin_ctzll(mask);
-      mask &= mask - 1;
-      const uint32_t cx = __builtin_amdgcn_readlane(nx, k);
-      const uint32_t cy = __builtin_amdgcn_readlane(ny, k);
-      const uint32_t cc = __builtin_amdgcn_readlane(ncell, k);
-      uint32_t fh = curFh;
-      if (EPS && c.nAgentsPad) {
-        // focalStateHeuristic (ecbs.cpp:282-295) + focalTransitionHeuristic (ecbs.cpp:298-312)
-        uint32_t cnt = __popcll(__ballot(b0 == cc)) + __popcll(__ballot(a0 == cc && b0 == curCell));
-        if (c.nAgentsPad > 64) {
-          cnt += __popcll(__ballot(b1 == cc)) + __popcll(__ballot(a1 == cc && b1 == curCell));
-          for (uint32_t base = 128; base < c.nAgentsPad; base += 64) {
-            uint32_t av = kEmptyCell, bv = kEmptyCell;
-            if (base + lane < c.nAgentsPad) {
-              av = rowA[base + lane];
-              bv = rowB[base + lane];
-            }
-            cnt += __popcll(__ballot(bv == cc)) + __popcll(__ballot(av == cc && bv == curCell));
-          }
-        }
-        fh += cnt;
-        if (fh > kFhMax) return ST_CAP_FOCAL;
-      }
-      const uint32_t h = (cx > c.gx ? cx - c.gx : c.gx - cx) + (cy > c.gy ? cy - c.gy : c.gy - cy);
-      const uint32_t f = t1 + h;
-      const uint32_t nid = s.nNodes;
-      s.nNodes += 1;
-      u32x4 nn;
-      nn.x = cx | (cy << 8) | (t1 << 16) | (k << 27);
-      nn.y = curId;
-      nn.z = fh;
-      nn.w = 0;
-      m.nodes[nid] = nn;
-      {  // mark (t1, cell) discovered: stands for stateToHeap / closedSet membership (a_star_epsilon.hpp:224-227)
-        uint32_t wi = t1 * m.rowWords + (cc >> 5);
-        uint32_t wv = rfl(m.bits[wi]);
-        m.bits[wi] = wv | (1u << (cc & 31));
-      }
-      const uint64_t e = packEntry(fh, f, t1, nid);
+    // ---- pushes: openSet.push for every successor, focalSet.push for those within the bound, in successor order
+    {
       PROF_T0();
-      siftUp<AS, 0, true>(m, m.open, s.nOpen, e);
-      s.nOpen += 1;
+      PushChains<AS> po, pf;
+      po.load(m.open, s.nOpen, mask);
+      if (EPS) pf.load(m.focal, s.nFocal, maskF);
+      po.template resolve<0, true>(m, m.open, s.nOpen, mask, e);
+      s.nOpen += (uint32_t)__builtin_popcount(mask);
       if (EPS) {
-        if ((float)(int32_t)f <= __fmul_rn((float)s.bestF, c.w)) {  // a_star_epsilon.hpp:240
-          siftUp<AS, 1, false>(m, m.focal, s.nFocal, e);
-          s.nFocal += 1;
-        }
+        pf.template resolve<1, false>(m, m.focal, s.nFocal, maskF, e);
+        s.nFocal += (uint32_t)__builtin_popcount(maskF);
       }
       PROF_ADD(res, 2);
     }
@@ -906,10 +1101,15 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams
   }
 }
 
-// Session mode.  The same workgroups stay resident for a whole solve and are fed through a ring in coherent pinned
-// host memory: workgroup takes ticket t (device atomic), waits until the host has published (generation t/R+1, job
-// slot) in ring_state[t%R], runs the job of that slot, writes the result to host memory and publishes t+1 in
-// ring_done[slot].  Job slots come from a host-side free list, so a slow search holds one slot, not the ring.
+// Session mode.  The same workgroups stay resident for a whole solve and are fed through two ticket rings in coherent
+// pinned host memory.  An entry is (generation << 11) | job slot; job slots (descriptor, constraint words, path table,
+// result) come from a host-side free list, so a slow search holds one slot, not the ring.
+//   lane 0 (bulk)     : a workgroup takes ticket t with a device fetch-add and waits until the host has published it.
+//   lane 1 (priority) : EVERY workgroup looks here first — before taking a bulk ticket and on every poll while it
+//                       waits for one — and claims a ticket only if it is already published (compare-and-swap), so
+//                       the searches of an instance deep in its conflict tree never queue behind the bulk.
+// The finished job's slot gets ring_done[slot] = (ticket + 1) & 0x3FFFFFFF | 1 << 30 | lane << 31 (never 0) and an
+// entry in the completion queue.
 // Exit conditions every wave reaches: *ring_stop != 0, or no job for ring_idle_limit_s seconds.
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(LaunchParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -919,31 +1119,55 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
   uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
   const uint64_t idleLimit = (uint64_t)P.ring_idle_limit_s * 100000000ull;  // s_memrealtime ticks at 100 MHz
   uint64_t busyTicks = 0, idleTicks = 0;
-  // Two lanes share the slot arrays: lane 0 (the bulk) and lane 1 (express: a handful of workgroups that only serve
-  // searches of instances deep in their conflict tree, so a long chain of dependent rounds never queues behind the
-  // bulk).  Each lane has its own ticket counter (device) and published-count word (host), 64 bytes apart.
-  const uint32_t myLane = blockIdx.x >= P.express_first ? 1u : 0u;
-  const uint32_t laneSize = myLane ? P.ring_size1 : P.ring_size;
-  uint32_t* const laneRing = P.ring_state + (myLane ? P.ring_size : 0u);
+  const uint32_t q0 = P.ring_size, q1 = P.ring_size1;
+  uint32_t* const ring0 = P.ring_state;
+  uint32_t* const ring1 = P.ring_state + q0;
+  uint32_t* const tickets0 = P.queue_head;        // device counters, 64 bytes apart
+  uint32_t* const tickets1 = P.queue_head + 16;
+  uint32_t* const head0 = P.ring_head;            // host words, 64 bytes apart
+  uint32_t* const head1 = P.ring_head + 16;
   const uint32_t compSize = P.n_slots;
-  uint32_t* const laneTickets = P.queue_head + myLane * 16;
-  uint32_t* const laneHead = P.ring_head + myLane * 16;
+  bool haveBulk = false;                          // a bulk ticket is held and not yet served
+  uint32_t bulkT = 0;
   for (;;) {
-    uint32_t t = atomicAdd(laneTickets, lane == 0 ? 1u : 0u);
-    t = rfl(t);
-    const uint32_t gen = (t / laneSize + 1) & 0x1FFFFFu;
-    uint32_t slot = 0;
+    uint32_t slot = 0, doneVal = 0;
     bool stop = false;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-      // Waiting workgroups poll ONE host word (the published-ticket count) and back off in proportion to how far
-      // ahead of it their ticket is: the next in line looks every ~2 us, the k-th every ~2k us (<= ~100 us), so a
-      // thousand idle wavefronts do not saturate PCIe with reads.
-      const uint32_t hd = rfl(__hip_atomic_load(laneHead, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
-      if ((int32_t)(hd - t) > 0) {
-        const uint32_t e = rfl(__hip_atomic_load(laneRing + t % laneSize, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+      // priority lane: claim only what is already published
+      const uint32_t hd1 = rfl(__hip_atomic_load(head1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+      const uint32_t t1 = rfl(__hip_atomic_load(tickets1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if ((int32_t)(hd1 - t1) > 0) {
+        // lane 0 carries the real compare value; the others compare against a value the counter cannot hold now
+        const uint32_t old = atomicCAS(tickets1, lane == 0 ? t1 : (t1 ^ 0x80000000u), t1 + 1u);
+        if (rfl(old) == t1) {
+          const uint32_t gen = (t1 / q1 + 1) & 0x1FFFFFu;
+          uint32_t e;
+          do {  // published before head1 was advanced: visible on the first look in practice
+            e = rfl(__hip_atomic_load(ring1 + t1 % q1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+          } while ((e >> 11) != gen);
+          slot = e & 2047u;
+          doneVal = ((t1 + 1u) & 0x3FFFFFFFu) | 0xC0000000u;
+          break;
+        }
+        continue;  // another workgroup was faster: look again at once
+      }
+      // bulk lane
+      if (!haveBulk) {
+        bulkT = rfl(atomicAdd(tickets0, lane == 0 ? 1u : 0u));
+        haveBulk = true;
+      }
+      // Waiting workgroups poll the published-ticket counts and back off in proportion to how far ahead of the bulk
+      // count their ticket is: the next in line looks every ~2 us, the k-th every ~2k us (<= ~100 us), so a thousand
+      // idle wavefronts do not saturate PCIe with reads.
+      const uint32_t hd = rfl(__hip_atomic_load(head0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+      if ((int32_t)(hd - bulkT) > 0) {
+        const uint32_t gen = (bulkT / q0 + 1) & 0x1FFFFFu;
+        const uint32_t e = rfl(__hip_atomic_load(ring0 + bulkT % q0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
         if ((e >> 11) == gen) {
           slot = e & 2047u;
+          doneVal = ((bulkT + 1u) & 0x3FFFFFFFu) | 0x40000000u;
+          haveBulk = false;
           break;
         }
       }
@@ -952,23 +1176,23 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
         stop = true;
         break;
       }
-      uint32_t naps = (int32_t)(t - hd) > 0 ? 1 + (t - hd) : 1;
+      uint32_t naps = (int32_t)(bulkT - hd) > 0 ? 1 + (bulkT - hd) : 1;
       if (naps > 48) naps = 48;
       for (uint32_t q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(64);
     }
-    const uint64_t t1 = __builtin_amdgcn_s_memrealtime();
-    idleTicks += t1 - t0;
+    const uint64_t t1c = __builtin_amdgcn_s_memrealtime();
+    idleTicks += t1c - t0;
     if (stop) break;
     processJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, smem, arenaSlot, jobS,
                resS);
     __threadfence_system();
-    __hip_atomic_store(P.ring_done + slot, t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(P.ring_done + slot, doneVal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring
     uint32_t cidx = atomicAdd(P.comp_count, lane == 0 ? 1u : 0u);
     cidx = rfl(cidx);
     __hip_atomic_store(P.comp_ring + (cidx % compSize), ((cidx / compSize + 1) << 11) | slot, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
-    busyTicks += __builtin_amdgcn_s_memrealtime() - t1;
+    busyTicks += __builtin_amdgcn_s_memrealtime() - t1c;
   }
   atomicAdd(P.sess_ticks + 0, lane == 0 ? (unsigned long long)busyTicks : 0ull);
   atomicAdd(P.sess_ticks + 1, lane == 0 ? (unsigned long long)idleTicks : 0ull);

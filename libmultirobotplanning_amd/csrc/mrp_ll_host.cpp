@@ -103,9 +103,8 @@ struct Ticket {
 // list.  A slot is tied up until its result has been consumed, a ticket entry only until a workgroup has started the
 // job, so one long search never blocks the publication of the searches behind it.
 struct Ring {
-  static constexpr uint32_t kSlots = 2048;                // all job slots; lane 0 owns [0, kSlots0), lane 1 the rest
-  static constexpr uint32_t kSlots0 = 1792;
-  static constexpr uint32_t kSlots1 = kSlots - kSlots0;
+  static constexpr uint32_t kSlots = 2048;                // job slots, shared by both lanes
+  static constexpr uint32_t kReserve1 = 256;              // slots the bulk lane leaves free for the priority lane
   static constexpr uint32_t kTickets0 = 1u << 17;         // ticket-ring entries of lane 0 / lane 1
   static constexpr uint32_t kTickets1 = 1u << 14;
   static constexpr uint32_t kTickets = kTickets0 + kTickets1;
@@ -127,11 +126,11 @@ struct Ring {
   std::vector<int32_t> slotTicket; // slot -> session ticket id / job index inside it
   std::vector<int32_t> slotJob;
   std::vector<uint32_t> slotGen;   // value the occupant's done word will show: its ticket number + 1 (valid while busy)
-  std::vector<uint32_t> freeSlots[2];  // per lane: job slots not in use (stack)
+  std::vector<uint32_t> freeSlots;     // job slots not in use (stack)
   std::vector<uint32_t> tkSlot, tkSeq; // per ticket-ring entry: the slot / done value of the job last published there
   uint32_t Q[2] = {kTickets0, kTickets1};  // ticket-ring entries in use (MRP_LL_TICKET_RING shrinks them: wrap tests)
   bool active = false;
-  uint32_t grid = 0, expressWgs = 0;
+  uint32_t grid = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 struct SessTicket {
@@ -774,10 +773,8 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   g.slotGen.assign(R, 0);
   g.tkSlot.assign(Ring::kTickets, 0xFFFFFFFFu);
   g.tkSeq.assign(Ring::kTickets, 0);
-  g.freeSlots[0].clear();
-  g.freeSlots[1].clear();
-  for (uint32_t sl = Ring::kSlots0; sl-- > 0;) g.freeSlots[0].push_back(sl);
-  for (uint32_t sl = Ring::kSlots; sl-- > Ring::kSlots0;) g.freeSlots[1].push_back(sl);
+  g.freeSlots.clear();
+  for (uint32_t sl = Ring::kSlots; sl-- > 0;) g.freeSlots.push_back(sl);
   ctx->sess.clear();
   ctx->sessFree.clear();
   auto devPtr = [&](void* hostPtr) {
@@ -803,8 +800,8 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   g.Q[1] = Ring::kTickets1;
   if (const char* e = std::getenv("MRP_LL_TICKET_RING")) {  // test knob: small rings wrap often
     const uint32_t q = static_cast<uint32_t>(std::atoi(e));
-    g.Q[0] = std::min(Ring::kTickets0, std::max(q, Ring::kSlots0));
-    g.Q[1] = std::min(Ring::kTickets1, std::max(q, Ring::kSlots1));
+    g.Q[0] = std::min(Ring::kTickets0, std::max(q, Ring::kSlots));  // a batch never laps its own entries
+    g.Q[1] = std::min(Ring::kTickets1, std::max(q, Ring::kSlots));
   }
   P.ring_size = g.Q[0];
   P.ring_size1 = g.Q[1];
@@ -815,12 +812,6 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   if (rc != MRP_LL_SUCCESS) return rc;
   ctx->sessionRowWords = P.lds_row_words;
   g.grid = static_cast<uint32_t>(workgroups > 0 ? std::min(workgroups, ctx->opt.slots) : ctx->opt.slots);
-  {  // the last few workgroups serve the express lane only
-    uint32_t express = g.grid >= 32 ? 8u : (g.grid >= 4 ? g.grid / 4 : 0u);
-    if (const char* e = std::getenv("MRP_LL_EXPRESS_WGS")) express = std::min<uint32_t>(g.grid / 2, std::atoi(e));
-    g.expressWgs = express;
-    P.express_first = g.grid - express;
-  }
   HIPCHK(ctx, hipMemsetAsync(t.queueHead, 0, 256, t.stream));  // session tickets of both lanes count from 0
   HIPCHK(ctx, hipMemsetAsync(g.compCountDev, 0, 4, t.stream));
   HIPCHK(ctx, hipMemsetAsync(g.ticksDev, 0, 32, t.stream));
@@ -861,15 +852,15 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
 static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results,
                          int32_t* ticketOut) {
   Ring& g = ctx->ring;
-  if (lane == 1 && g.expressWgs == 0) lane = 0;  // no express workgroups in this session
-  const uint32_t nSlotsLane = lane ? Ring::kSlots1 : Ring::kSlots0;
+  const uint32_t nSlotsLane = lane ? Ring::kSlots : Ring::kSlots - Ring::kReserve1;
   const uint32_t Q = g.Q[lane];
   const uint32_t qBase = lane ? g.Q[0] : 0;
   if (nJobs > static_cast<int32_t>(nSlotsLane)) {
     ctx->err = "mrp_ll_submit (session): batch larger than the ring";
     return MRP_LL_E_INVALID;
   }
-  if (g.freeSlots[lane].size() < static_cast<size_t>(nJobs)) return MRP_LL_E_BUSY;  // consume finished tickets first
+  // consume finished tickets first; the bulk lane leaves kReserve1 slots to the priority lane
+  if (g.freeSlots.size() < static_cast<size_t>(nJobs) + (lane ? 0u : Ring::kReserve1)) return MRP_LL_E_BUSY;
   for (int i = 0; i < nJobs; ++i) {
     // a ticket entry may be overwritten once the job published there a whole ring ago has been consumed
     const uint32_t qi = qBase + static_cast<uint32_t>((g.head[lane] + i) % Q);
@@ -898,8 +889,8 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
     const uint64_t tk = g.head[lane] + i;
     const uint32_t qi = qBase + static_cast<uint32_t>(tk % Q);
     const uint32_t gen = (static_cast<uint32_t>(tk / Q) + 1) & 0x1FFFFFu;
-    const uint32_t slot = g.freeSlots[lane].back();
-    g.freeSlots[lane].pop_back();
+    const uint32_t slot = g.freeSlots.back();
+    g.freeSlots.pop_back();
     ConsSinkSlot cs{g.cons + static_cast<size_t>(slot) * Ring::kSlotConsWords, slot * Ring::kSlotConsWords,
                     Ring::kSlotConsWords};
     PathSinkSlot ps{g.paths + static_cast<size_t>(slot) * Ring::kSlotPathHalfs, slot * Ring::kSlotPathHalfs,
@@ -914,7 +905,8 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
     g.busy[slot] = 1;
     g.slotTicket[slot] = ti;
     g.slotJob[slot] = i;
-    g.slotGen[slot] = static_cast<uint32_t>(tk) + 1u;
+    g.slotGen[slot] = ((static_cast<uint32_t>(tk) + 1u) & 0x3FFFFFFFu) | 0x40000000u | (lane ? 0x80000000u : 0u);  // never 0
+    __atomic_store_n(g.done + slot, 0u, __ATOMIC_RELAXED);  // the previous occupant's done word must not be mistaken
     g.tkSlot[qi] = slot;
     g.tkSeq[qi] = g.slotGen[slot];
     st.slots[i] = slot;
@@ -953,7 +945,7 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
     st.state[i] = 1;
     st.remaining -= 1;
     g.busy[slot] = 0;
-    g.freeSlots[st.lane].push_back(slot);
+    g.freeSlots.push_back(slot);
   }
   *doneOut = st.remaining == 0 ? 1 : 0;
   if (st.remaining == 0) {
@@ -985,7 +977,7 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
     st.state[i] = 1;
     st.remaining -= 1;
     g.busy[slot] = 0;
-    g.freeSlots[st.lane].push_back(slot);
+    g.freeSlots.push_back(slot);
     if (st.remaining == 0) {
       st.used = false;
       ctx->sessFree.push_back(g.slotTicket[slot]);
