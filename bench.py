@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=16384, help="instances per GPU per step")
+    ap.add_argument("--instances", type=int, default=65536, help="instances per GPU per step")
     ap.add_argument("--agents", type=int, default=10)
     ap.add_argument("--threads", type=int, default=0, help="host worker threads per GPU (0 = auto)")
     ap.add_argument("--slots", type=int, default=0)

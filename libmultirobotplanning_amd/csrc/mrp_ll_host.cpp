@@ -457,7 +457,8 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
   uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
   uint32_t rows = 0;
   uint32_t ldsBytes = 0;
-  const uint32_t ldsPaths = 4096;
+  uint32_t ldsPaths = 4096;
+  if (const char* e = std::getenv("MRP_LL_LDS_PATHS")) ldsPaths = static_cast<uint32_t>(std::max(0, std::atoi(e))) & ~31u;  // tuning knob
   if (ldsNodes) {
     const uint32_t budget = 160 * 1024 - 512;
     uint32_t fixed = mrp_ll_lds_bytes(ldsNodes, 0, rowWords, ldsPaths);
