@@ -144,6 +144,14 @@ int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t n_obs
 /* Copies every map uploaded so far to the device now (otherwise done lazily by the next submit / session_begin). */
 int mrp_ll_sync_maps(mrp_ll_ctx* ctx);
 
+/* Geometry of the LDS-resident fast tier for the launches / sessions that follow: node capacity, (time, cell) bitmap
+ * rows and bytes of the focal path table kept in LDS per resident search (0 = keep the current value; lds_nodes < 0
+ * disables the tier).  Smaller tiers let more searches share a CU (occupancy = 160 KiB / tier bytes) at the price of
+ * more searches overflowing into the HBM tier; results never depend on it.  *occupancy_out (may be NULL) receives the
+ * resulting resident searches per CU.  MRP_LL_E_BUSY while a batch or a session is in flight. */
+int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t lds_nodes, int32_t lds_rows, int32_t lds_path_bytes,
+                           int32_t* occupancy_out);
+
 /* Blocking: run n_jobs independent searches, fill results[i] for jobs[i]. */
 int mrp_ll_search_batch(mrp_ll_ctx* ctx, int32_t n_jobs, const mrp_ll_job* jobs, mrp_ll_result* results);
 

@@ -585,8 +585,24 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   std::vector<std::vector<int32_t>>& idx = pre->idx;
   std::vector<std::vector<int32_t>>& mapIds = pre->mapIds;
   std::vector<GroupResult> gr(nThreads);
-  // resident wavefronts per engine: the chip holds about 256 CUs x 4 workgroups of this kernel at once
-  int32_t sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, 1024 / nThreads));
+  // LDS tier sized for two resident searches per SIMD (8 per CU): one wavefront alone leaves about half of its SIMD's
+  // issue slots idle (waiting on LDS / memory), a second one fills them.  The focal path table of a search is
+  // [time][agents rounded up to 16] halfwords; 64 time steps of it are kept in LDS, the rest of a longer table lives in
+  // the search's arena slot.
+  int32_t maxAgents = 1;
+  for (int32_t k = 0; k < nInst; ++k) maxAgents = std::max(maxAgents, instances[k].n_agents);
+  const int32_t agentsPad = (maxAgents + 15) & ~15;
+  int32_t occupancy = 4;
+  if (s->llOpt.lds_nodes == 0 && opt.mode != 1) {  // the caller did not choose a geometry: pick one for this batch
+    const int32_t pathBytes = opt.algo == MRP_HL_ECBS ? std::min(16384, std::max(2048, agentsPad * 2 * 64)) : 32;
+    for (int32_t t = 0; t < nThreads; ++t)
+      if (mrp_ll_configure_tiers(s->engines[t], 256, 48, pathBytes, &occupancy) != MRP_LL_SUCCESS) {
+        s->err = std::string("mrp_ll_configure_tiers: ") + mrp_ll_last_error(s->engines[t]);
+        return MRP_LL_E_DEVICE;
+      }
+  }
+  // resident wavefronts per engine: the chip holds 256 CUs x `occupancy` workgroups of this kernel at once
+  int32_t sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, (256 * occupancy) / nThreads));
   if (const char* e = std::getenv("MRP_HL_SESSION_WGS")) sessionWgs = std::max(1, std::atoi(e));  // tuning knob
   auto t0 = std::chrono::steady_clock::now();
   {

@@ -50,6 +50,7 @@ typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 #define PROF_INC(res, k, v) do { } while (0)
 #endif
 
+DEVI uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // no bool -> int -> bool round trip
 DEVI uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 DEVI int32_t rfli(int32_t v) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)v); }
 DEVI uint64_t rfl64(uint64_t v) {
@@ -158,7 +159,7 @@ DEVI void siftUp(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx, uint64_t 
     const bool act = lane < depth;
     const uint32_t anc = act ? ((idx + 1) >> (lane + 1)) - 1 : 0;     // lane k: k-th ancestor
     const uint64_t ae = heap[anc];
-    const uint64_t worse = __ballot(act && kLess<KEY>(ae, e));
+    const uint64_t worse = ballot64(act && kLess<KEY>(ae, e));
     stop = (uint32_t)__builtin_ctzll(~worse);                          // first ancestor that is not worse than e
     if (lane < stop) {                                                 // ancestors 0..stop-1 move down one level
       const uint32_t dest = ((idx + 1) >> lane) - 1;
@@ -197,8 +198,8 @@ DEVI uint32_t descend(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t n, uint32
     const uint64_t pe = right ? pr.y : pr.x;
     const uint32_t pk = right ? kr : kl;
     const bool go = has && (STL || !(pk < xk));                 // the hole moves below this node
-    const uint64_t goMask = __ballot(go);
-    const uint64_t rightMask = __ballot(right);
+    const uint64_t goMask = ballot64(go);
+    const uint64_t rightMask = ballot64(right);
     uint64_t pathMask = 0;
     uint32_t rel = 0, steps = 0;
 #pragma unroll 1
@@ -301,7 +302,7 @@ struct PushChains {          // sift-up chains of the (up to five) pushes of one
 #pragma unroll
         for (int j = 0; j < k; ++j)  // what earlier pushes of this expansion left on this chain
           if (((mask >> j) & 1u) && pos[j] == pos[k] && pos[k] != kNoPos) v = nv[j];
-        const uint64_t worse = __ballot(lane < d && kLess<KEY>(v, e[k]));
+        const uint64_t worse = ballot64(lane < d && kLess<KEY>(v, e[k]));
         const uint64_t notWorse = ~worse & ((1ull << d) - 1ull);
         const int32_t sLvl = notWorse ? 63 - (int32_t)__builtin_clzll(notWorse) : -1;  // deepest ancestor that stays
         const uint64_t sh = waveShr1_64(v);
@@ -328,8 +329,8 @@ DEVI uint32_t descendBlock(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx,
   const uint64_t pe = right ? pr.y : pr.x;
   const uint32_t pk = right ? kr : kl;
   const bool go = has && !(pk < xk);
-  const uint64_t goMask = __ballot(go);
-  const uint64_t rightMask = __ballot(right);
+  const uint64_t goMask = ballot64(go);
+  const uint64_t rightMask = ballot64(right);
   uint64_t pathMask = 0;
   uint32_t rel = 0, steps = 0;
 #pragma unroll 1
@@ -603,13 +604,13 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
     }
     PROF_T0();
     bool ok = inb && !((word >> (ncell & 31)) & 1u);
-    uint32_t mask = (uint32_t)(__ballot(ok) & 0x1Full);
+    uint32_t mask = (uint32_t)(ballot64(ok) & 0x1Full);
     if (c.nEc) {  // transitionValid (ecbs.cpp:505-510): lane j holds edge-constraint key j = t << 19 | cell << 3 | action
       const uint32_t base = (t << 19) | (curCell << 3);
       const uint32_t d = ecReg - base;
       uint32_t blocked = 0;
 #pragma unroll
-      for (uint32_t k = 0; k < 5; ++k) blocked |= __ballot(d == k) ? (1u << k) : 0u;
+      for (uint32_t k = 0; k < 5; ++k) blocked |= ballot64(d == k) ? (1u << k) : 0u;
       for (uint32_t j = 64; j < c.nEc; ++j) {  // lists longer than a wave: the rest one by one
         const uint32_t dd = rfl(c.ec[j]) - base;
         if (dd < 5) blocked |= 1u << dd;
@@ -634,16 +635,16 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
         uint32_t fh = curFh;
         if (EPS && c.nAgentsPad) {
           // focalStateHeuristic (ecbs.cpp:282-295) + focalTransitionHeuristic (ecbs.cpp:298-312)
-          uint32_t cnt = __popcll(__ballot(b0 == cc)) + __popcll(__ballot(a0 == cc && b0 == curCell));
+          uint32_t cnt = __popcll(ballot64(b0 == cc)) + __popcll(ballot64(a0 == cc && b0 == curCell));
           if (c.nAgentsPad > 64) {
-            cnt += __popcll(__ballot(b1 == cc)) + __popcll(__ballot(a1 == cc && b1 == curCell));
+            cnt += __popcll(ballot64(b1 == cc)) + __popcll(ballot64(a1 == cc && b1 == curCell));
             for (uint32_t base = 128; base < c.nAgentsPad; base += 64) {
               uint32_t av = kEmptyCell, bv = kEmptyCell;
               if (base + lane < c.nAgentsPad) {
                 av = rowA[base + lane];
                 bv = rowB[base + lane];
               }
-              cnt += __popcll(__ballot(bv == cc)) + __popcll(__ballot(av == cc && bv == curCell));
+              cnt += __popcll(ballot64(bv == cc)) + __popcll(ballot64(av == cc && bv == curCell));
             }
           }
           fh += cnt;
@@ -958,7 +959,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
         // sipp.hpp:209: skip if si.start - m_time > end_t || si.end < start_t
         const bool cand = (i < cnt) && !((int64_t)siS - 1 > (int64_t)endT || siE < (int32_t)startT);
         const uint32_t tArr = (uint32_t)(siS > (int32_t)startT ? siS : (int32_t)startT);
-        uint64_t mask = __ballot(cand);
+        uint64_t mask = ballot64(cand);
         while (mask) {
           const uint32_t l = (uint32_t)__builtin_ctzll(mask);
           mask &= mask - 1;

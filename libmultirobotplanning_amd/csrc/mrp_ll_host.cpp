@@ -155,6 +155,7 @@ struct mrp_ll_ctx {
   size_t mapsDevCap = 0;
   bool mapsDirty = false;
   uint32_t maxWpr = 1;
+  uint32_t tierRows = 64, tierPathBytes = 4096;  // LDS tier geometry (mrp_ll_configure_tiers); nodes live in opt.lds_nodes
   uint32_t sessionRowWords = 0;   // LDS bitmap row width the resident kernel was launched with
   uint32_t arenaRowWords = 0;
   uint64_t arenaStride = 0;
@@ -457,13 +458,13 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
   uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
   uint32_t rows = 0;
   uint32_t ldsBytes = 0;
-  uint32_t ldsPaths = 4096;
+  uint32_t ldsPaths = ctx->tierPathBytes;
   if (const char* e = std::getenv("MRP_LL_LDS_PATHS")) ldsPaths = static_cast<uint32_t>(std::max(0, std::atoi(e))) & ~31u;  // tuning knob
   if (ldsNodes) {
     const uint32_t budget = 160 * 1024 - 512;
     uint32_t fixed = mrp_ll_lds_bytes(ldsNodes, 0, rowWords, ldsPaths);
     if (fixed + 16 * rowWords * 4 <= budget) {
-      uint32_t rowsWanted = 64;
+      uint32_t rowsWanted = ctx->tierRows;
       if (const char* e = std::getenv("MRP_LL_LDS_ROWS")) rowsWanted = std::max(8, std::atoi(e));  // tuning knob
       rows = std::min<uint32_t>(rowsWanted, (budget - fixed) / (rowWords * 4));
       rows = std::min<uint32_t>(rows, static_cast<uint32_t>(ctx->opt.max_horizon));
@@ -716,6 +717,25 @@ int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t nObst
   return MRP_LL_SUCCESS;
 }
 
+
+int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t ldsNodes, int32_t ldsRows, int32_t ldsPathBytes, int32_t* occOut) {
+  if (!ctx) return MRP_LL_E_INVALID;
+  if (ctx->ring.active) return MRP_LL_E_BUSY;
+  for (const Ticket& t : ctx->tickets)
+    if (t.inFlight) return MRP_LL_E_BUSY;
+  if (ldsNodes < 0) ctx->opt.lds_nodes = 0;
+  if (ldsNodes > 0) ctx->opt.lds_nodes = std::min(ldsNodes, 8192) & ~1;
+  if (ldsRows > 0) ctx->tierRows = static_cast<uint32_t>(std::min(std::max(ldsRows, 8), 1024));
+  if (ldsPathBytes > 0) ctx->tierPathBytes = static_cast<uint32_t>(std::min(ldsPathBytes, 65536)) & ~31u;
+  if (occOut) {
+    const uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
+    const uint32_t bytes = ctx->opt.lds_nodes
+                               ? mrp_ll_lds_bytes(static_cast<uint32_t>(ctx->opt.lds_nodes), ctx->tierRows, rowWords, ctx->tierPathBytes) + 256
+                               : 0;
+    *occOut = bytes ? static_cast<int32_t>(std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / bytes))) : 8;
+  }
+  return MRP_LL_SUCCESS;
+}
 
 // ---- session mode ---------------------------------------------------------------------------------------------
 int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
