@@ -83,7 +83,7 @@ struct Mem {
   P64 focal;
   P64 aux;       // std::priority_queue of the ordered walk: (openKey << 32) | open index
   P32 bits;      // (time, cell) bitmap: 1 = obstacle | vertex constraint | already discovered
-  uint32_t capNodes, capRows, rowWords;
+  uint32_t capNodes, capHeap, capRows, rowWords;  // capHeap: entries per heap array (open / focal / walk queue)
 };
 
 struct Ctx {  // wave-uniform job context
@@ -537,7 +537,7 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
     DBG(c, 6, xyt);
     DBG(c, 7, isGoal ? 1 : 2);
     if (!isGoal) {
-      if (s.nNodes + 5 > m.capNodes) return RUN_MIGRATE_NODES;
+      if (s.nNodes + 5 > m.capNodes || s.nOpen + 5 > m.capHeap) return RUN_MIGRATE_NODES;
       if (t + 1 >= m.capRows) return RUN_MIGRATE_ROWS;
     }
     // other agents' positions at t and t+1 (issued early; consumed after the heap pops)
@@ -699,8 +699,10 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
 // ---- LDS layout ------------------------------------------------------------------------------------------------
 constexpr uint32_t kEcLocal = 64;
 __host__ __device__ inline uint32_t ldsBytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes) {
-  // nodes 16 B, three biased heaps 8 B (+16 B bias pad each), bitmap rows, obstacle row, edge constraints, path table
-  return capNodes * 16 + 3 * (capNodes * 8 + 16) + rows * rowWords * 4 + rowWords * 4 + kEcLocal * 4 + pathBytes;
+  // nodes 16 B; three biased heaps of capNodes / 2 entries of 8 B (+16 B bias pad each) — most nodes of a search are
+  // closed, so the open list outgrowing half the node capacity is rare and simply migrates like a full node array;
+  // bitmap rows, obstacle row, edge constraints, path table
+  return capNodes * 16 + 3 * ((capNodes / 2) * 8 + 16) + rows * rowWords * 4 + rowWords * 4 + kEcLocal * 4 + pathBytes;
 }
 
 template <bool EPS>
@@ -765,7 +767,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     g.focal = (Mem<1>::P64)(p + 8);              p += (size_t)P.arena_nodes * 8 + 16;
     g.aux = (Mem<1>::P64)(p + 8);                p += (size_t)P.arena_nodes * 8 + 16;
     g.bits = (Mem<1>::P32)p;
-    g.capNodes = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
+    g.capNodes = P.arena_nodes; g.capHeap = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
   }
 
   const bool ldsOk = P.lds_nodes != 0 && c.wpr <= P.lds_row_words;
@@ -773,13 +775,14 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     Mem<3> m;
     uint8_t* p = smem;
     m.nodes = (Mem<3>::PNode)p;                  p += P.lds_nodes * 16;
-    m.open = (Mem<3>::P64)(p + 8);               p += P.lds_nodes * 8 + 16;
-    m.focal = (Mem<3>::P64)(p + 8);              p += P.lds_nodes * 8 + 16;
-    m.aux = (Mem<3>::P64)(p + 8);                p += P.lds_nodes * 8 + 16;
+    const uint32_t heapBytes = (P.lds_nodes / 2) * 8 + 16;
+    m.open = (Mem<3>::P64)(p + 8);               p += heapBytes;
+    m.focal = (Mem<3>::P64)(p + 8);              p += heapBytes;
+    m.aux = (Mem<3>::P64)(p + 8);                p += heapBytes;
     m.bits = (Mem<3>::P32)p;                     p += P.lds_rows * P.lds_row_words * 4;
     Mem<3>::P32 obstLocal = (Mem<3>::P32)p;      p += P.lds_row_words * 4;
     Mem<3>::P32 ecLocal = (Mem<3>::P32)p;
-    m.capNodes = P.lds_nodes; m.capRows = P.lds_rows; m.rowWords = P.lds_row_words;
+    m.capNodes = P.lds_nodes; m.capHeap = P.lds_nodes / 2; m.capRows = P.lds_rows; m.rowWords = P.lds_row_words;
 
     __syncthreads();  // previous job's LDS reads are done
     for (uint32_t wd = lane; wd < c.wpr; wd += 64) obstLocal[wd] = c.obst[wd];
@@ -841,7 +844,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
     g.focal = (Mem<1>::P64)(p + 8);              p += (size_t)P.arena_nodes * 8 + 16;
     g.aux = (Mem<1>::P64)(p + 8);                p += (size_t)P.arena_nodes * 8 + 16;
     g.bits = (Mem<1>::P32)p;
-    g.capNodes = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
+    g.capNodes = P.arena_nodes; g.capHeap = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
   }
   uint8_t* scratch = arenaSlot + P.arena_scratch_off;
   uint32_t* tab = (uint32_t*)((uint32_t*)(scratch + (size_t)P.out_stride * 2) + kConsLocalWords);  // path-table area

@@ -601,7 +601,7 @@ int mrp_ll_create(const mrp_ll_options* optIn, mrp_ll_ctx** out) {
   if (o.max_cells > 255 * 255) o.max_cells = 255 * 255;
   if (o.lds_nodes == 0) o.lds_nodes = 512;
   if (o.lds_nodes < 0) o.lds_nodes = 0;
-  o.lds_nodes &= ~1;
+  o.lds_nodes &= ~3;  // heap arrays hold lds_nodes / 2 entries and stay 16-byte aligned
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || o.device < 0 || o.device >= ndev) {
@@ -724,7 +724,7 @@ int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t ldsNodes, int32_t ldsRows, i
   for (const Ticket& t : ctx->tickets)
     if (t.inFlight) return MRP_LL_E_BUSY;
   if (ldsNodes < 0) ctx->opt.lds_nodes = 0;
-  if (ldsNodes > 0) ctx->opt.lds_nodes = std::min(ldsNodes, 8192) & ~1;
+  if (ldsNodes > 0) ctx->opt.lds_nodes = std::max(8, std::min(ldsNodes, 8192) & ~3);
   if (ldsRows > 0) ctx->tierRows = static_cast<uint32_t>(std::min(std::max(ldsRows, 8), 1024));
   if (ldsPathBytes > 0) ctx->tierPathBytes = static_cast<uint32_t>(std::min(ldsPathBytes, 65536)) & ~31u;
   if (occOut) {
