@@ -44,7 +44,11 @@ typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 #define PROF_T0() uint64_t prof_t0__ = __builtin_amdgcn_s_memtime()
 #define PROF_ADD(res, k) (res).prof[k] += (uint32_t)(__builtin_amdgcn_s_memtime() - prof_t0__)
 #define PROF_INC(res, k, v) (res).prof[k] += (uint32_t)(v)
+#define PROF_MARK(var) uint64_t var = __builtin_amdgcn_s_memtime()
+#define PROF_SINCE(res, k, var) (res).prof[k] += (uint32_t)(__builtin_amdgcn_s_memtime() - var)
 #else
+#define PROF_MARK(var) do { } while (0)
+#define PROF_SINCE(res, k, var) do { } while (0)
 #define PROF_T0() do { } while (0)
 #define PROF_ADD(res, k) do { } while (0)
 #define PROF_INC(res, k, v) do { } while (0)
@@ -95,6 +99,7 @@ struct Ctx {  // wave-uniform job context
   const uint32_t* ec;
   const uint32_t* obst;     // global obstacle bitmap
   const uint16_t* paths;    // generic: LDS copy, arena copy, or host memory
+  __attribute__((address_space(3))) const uint16_t* pathsLds;  // the same table when it is the LDS copy (ds_read), else null
   uint32_t nAgentsPad, tPad;
   int64_t maxExp;
   volatile uint32_t* debug;
@@ -321,7 +326,7 @@ struct PushChains {          // sift-up chains of the (up to five) pushes of one
 // chosen children up, returns the new hole; `more` = the block was left through its bottom.
 template <int AS, int KEY, bool POS>
 DEVI uint32_t descendBlock(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx, uint32_t xk, u64x2 pr, uint32_t node,
-                           bool has, bool hasR, bool& more) {
+                           bool has, bool hasR, bool full, bool& more) {
   const uint32_t lane = threadIdx.x;
   const uint32_t kl = KEY == 0 ? openKey(pr.x) : entryKey(pr.x);
   const uint32_t kr = KEY == 0 ? openKey(pr.y) : entryKey(pr.y);
@@ -333,11 +338,24 @@ DEVI uint32_t descendBlock(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx,
   const uint64_t rightMask = ballot64(right);
   uint64_t pathMask = 0;
   uint32_t rel = 0, steps = 0;
+  if (full) {
+    // all six levels exist below the hole: six branch-free steps (a taken scalar branch costs about as much as six
+    // instructions; measured 504 vs 876 cycles per block, scripts/micro/descend_micro.hip)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const uint32_t g = (uint32_t)((goMask >> rel) & 1ull);
+      const uint32_t r = (uint32_t)((rightMask >> rel) & 1ull);
+      pathMask |= (uint64_t)g << rel;
+      rel = g ? 2 * rel + 1 + r : rel;
+      steps += g;
+    }
+  } else {
 #pragma unroll 1
-  while (steps < 6 && ((goMask >> rel) & 1ull)) {
-    pathMask |= 1ull << rel;
-    rel = 2 * rel + 1 + (uint32_t)((rightMask >> rel) & 1ull);
-    steps += 1;
+    while (steps < 6 && ((goMask >> rel) & 1ull)) {
+      pathMask |= 1ull << rel;
+      rel = 2 * rel + 1 + (uint32_t)((rightMask >> rel) & 1ull);
+      steps += 1;
+    }
   }
   if ((pathMask >> lane) & 1ull) {
     heap[node] = pe;
@@ -389,6 +407,7 @@ DEVI void popFocalEraseOpen(Mem<AS>& m, uint32_t& nFocal, uint32_t& nOpen, uint3
   // ---- sift-downs, block by block, both heaps per round trip
   bool firstF = true;
   for (;;) {
+
     u64x2 prO;
     prO.x = 0; prO.y = 0;
     const uint32_t nodeO = ((idxO + 1) << lv) - 1 + off;
@@ -403,8 +422,13 @@ DEVI void popFocalEraseOpen(Mem<AS>& m, uint32_t& nFocal, uint32_t& nOpen, uint3
       if (hasF) prF = *(typename Mem<AS>::PPair)(m.focal + 2 * nodeF + 1);
     }
     firstF = false;
-    if (moreF) idxF = descendBlock<AS, 1, false>(m, m.focal, idxF, xkF, prF, nodeF, hasF, hasF && (2 * nodeF + 2 < nFocal), moreF);
-    if (moreO) idxO = descendBlock<AS, 0, true>(m, m.open, idxO, xkO, prO, nodeO, hasO, hasO && (2 * nodeO + 2 < nOpen), moreO);
+    // "full": the leftmost descendant six levels below the hole exists
+    if (moreF)
+      idxF = descendBlock<AS, 1, false>(m, m.focal, idxF, xkF, prF, nodeF, hasF, hasF && (2 * nodeF + 2 < nFocal),
+                                        ((idxF + 1) << 6) - 1 < nFocal, moreF);
+    if (moreO)
+      idxO = descendBlock<AS, 0, true>(m, m.open, idxO, xkO, prO, nodeO, hasO, hasO && (2 * nodeO + 2 < nOpen),
+                                       ((idxO + 1) << 6) - 1 < nOpen, moreO);
     if (!moreF && !moreO) break;
   }
   if (nFocal > 0) m.focal[idxF] = lastF;
@@ -445,6 +469,7 @@ DEVI void orderedWalk(Mem<AS>& m, SState& s, const Ctx& c, int32_t oldBest, DevR
       if (first + 1 < s.nOpen) auxPush<AS>(m, npq, ((uint64_t)openKey(e2) << 32) | (first + 1));
     }
     PROF_INC(res, 7, 1);
+
     uint64_t e = ld64<AS>(m.open, cur);
     float fv = (float)entryF(e);
     if (fv > lo && fv <= hi) {
@@ -513,6 +538,7 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
   const uint32_t ecReg = lane < c.nEc ? c.ec[lane] : 0xFFFFFFFFu;
   for (;;) {
     DBG(c, 5, ++dbgIter);
+    PROF_MARK(profTop);
     if (s.nOpen == 0) return ST_NO_SOLUTION;
     uint64_t topE = ld64<AS>(m.open, 0);
     uint64_t curE = topE;
@@ -524,6 +550,7 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
         orderedWalk<AS>(m, s, c, oldBest, res);
         PROF_ADD(res, 0);
         PROF_INC(res, 6, 1);
+
       }
       curE = ld64<AS>(m.focal, 0);
     }
@@ -549,13 +576,24 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
       uint32_t rb = (t + 1) < c.tPad ? (t + 1) : c.tPad - 1;
       rowA = c.paths + (size_t)ra * c.nAgentsPad;
       rowB = c.paths + (size_t)rb * c.nAgentsPad;
-      if (lane < c.nAgentsPad) {  // rows are n_agents_pad (multiple of 16) entries long
-        a0 = rowA[lane];
-        b0 = rowB[lane];
-      }
-      if (64 + lane < c.nAgentsPad) {
-        a1 = rowA[64 + lane];
-        b1 = rowB[64 + lane];
+      if (c.pathsLds) {  // the usual case: LDS reads proper, not flat loads through the LDS aperture
+        if (lane < c.nAgentsPad) {  // rows are n_agents_pad (multiple of 16) entries long
+          a0 = c.pathsLds[ra * c.nAgentsPad + lane];
+          b0 = c.pathsLds[rb * c.nAgentsPad + lane];
+        }
+        if (64 + lane < c.nAgentsPad) {
+          a1 = c.pathsLds[ra * c.nAgentsPad + 64 + lane];
+          b1 = c.pathsLds[rb * c.nAgentsPad + 64 + lane];
+        }
+      } else {
+        if (lane < c.nAgentsPad) {
+          a0 = rowA[lane];
+          b0 = rowB[lane];
+        }
+        if (64 + lane < c.nAgentsPad) {
+          a1 = rowA[64 + lane];
+          b1 = rowB[64 + lane];
+        }
       }
     }
 
@@ -577,11 +615,8 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
     }
 
     const uint32_t t1 = t + 1;
-    {
-      PROF_T0();
-      ensureRows<AS>(m, s, c, t1, c.obst, obstLocal, useLocal);
-      PROF_ADD(res, 4);
-    }
+    ensureRows<AS>(m, s, c, t1, c.obst, obstLocal, useLocal);
+    PROF_SINCE(res, 4, profTop);  // loop top -> pops, minus the ordered walk (slot 0)
     // successors in the reference's order Wait, Left, Right, Up, Down (ecbs.cpp:365-398) on lanes 0..4; the bitmap
     // words are requested before the pops below so that their latency is hidden behind them
     const int32_t dx = (lane == 2) - (lane == 1);
@@ -602,7 +637,6 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
       }
       PROF_ADD(res, 1);
     }
-    PROF_T0();
     bool ok = inb && !((word >> (ncell & 31)) & 1u);
     uint32_t mask = (uint32_t)(ballot64(ok) & 0x1Full);
     if (c.nEc) {  // transitionValid (ecbs.cpp:505-510): lane j holds edge-constraint key j = t << 19 | cell << 3 | action
@@ -617,8 +651,8 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
       }
       mask &= ~blocked;
     }
-    PROF_ADD(res, 3);
     if (mask == 0) continue;
+    PROF_MARK(profEnt);
 
     // ---- the successors' entries (order-independent part: heuristics, node records, discovered marks)
     uint64_t e[5];
@@ -679,6 +713,7 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
       if (mine) m.bits[bitIdx] = merged;
     }
 
+    PROF_SINCE(res, 3, profEnt);  // successors' entries: heuristics, node records, discovered marks
     // ---- pushes: openSet.push for every successor, focalSet.push for those within the bound, in successor order
     {
       PROF_T0();
@@ -738,12 +773,14 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     const uint32_t pathBytes = c.tPad * c.nAgentsPad * 2;  // multiple of 32
     const uint32_t* psrc = (const uint32_t*)(P.paths + J.path_off);
     uint8_t* ldsPaths = smem + ldsBytes(P.lds_nodes, P.lds_rows, P.lds_row_words, 0);
+    c.pathsLds = nullptr;
     if (pathBytes == 0) {
       c.paths = nullptr;
     } else if (P.lds_nodes != 0 && pathBytes <= P.lds_paths_bytes) {
       uint32_t* dst = (uint32_t*)ldsPaths;
       for (uint32_t i = lane; i < pathBytes / 4; i += 64) dst[i] = psrc[i];
       c.paths = (const uint16_t*)ldsPaths;
+      c.pathsLds = (__attribute__((address_space(3))) const uint16_t*)ldsPaths;
     } else if (pathBytes <= P.arena_paths_bytes) {
       uint32_t* dst = (uint32_t*)pathsArena;
       for (uint32_t i = lane; i < pathBytes / 4; i += 64) dst[i] = psrc[i];

@@ -29,7 +29,7 @@ for rep in range(2):
     p = st["prof"]
     tot = max(p[5], 1)
     print("rep %d wall %.1f ms kernel %.2f ms; migrated %d; cycles/expansion %.0f" % (rep, dt * 1e3, st["kernel_ms"], st["migrated"], p[5] / sum(exp)))
-    names = ["walk", "pop+erase", "push", "successors", "rows", "total", "#walks", "walk-visited"]
+    names = ["walk", "pop+erase", "push", "entries", "top(incl walk)", "total", "#walks", "walk-visited"]
     print("  " + "  ".join("%s=%.1f%%" % (names[i], 100.0 * p[i] / tot) for i in range(5)))
     print("  walks %d, visited %d (%.1f per walk), cycles per visited %.0f; per-expansion: pop+erase %.0f push %.0f succ %.0f" % (
         p[6], p[7], p[7] / max(p[6], 1), p[0] / max(p[7], 1), p[1] / sum(exp), p[2] / sum(exp), p[3] / sum(exp)))
