@@ -637,32 +637,32 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   return MRP_LL_SUCCESS;
 }
 
-int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl_instance* instances,
-                                   mrp_hl_sipp_solution* sols, mrp_hl_batch_stats* stats) {
-  if (!s || nInst < 0 || (nInst > 0 && (!instances || !sols))) return MRP_LL_E_INVALID;
-  mrp_ll_ctx* ctx = s->engines[0];
-  const int32_t horizon = s->llOpt.max_horizon > 0 ? s->llOpt.max_horizon : 512;
+namespace {
+
+// The loop of mapf_prioritized_sipp.cpp:214-270 for instances idx[...] on one engine: round r plans agent r of every
+// instance that still has one (agents of one instance are a chain — each plans against the intervals the earlier ones
+// occupy — instances are independent).
+void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, const mrp_hl_instance* instances, mrp_hl_sipp_solution* sols,
+                  const std::vector<int32_t>& idx, GroupResult& out) {
   struct Iv { int32_t s, e; };
   struct Prio {
     int32_t mapId = -1, agent = 0;
     std::map<std::pair<int32_t, int32_t>, std::vector<Iv>> all;  // allCollisionIntervals (:215), ordered by (x, y)
     std::vector<int32_t> xy, cnt, ivs;                            // flattened for the job of the current round
   };
-  std::vector<Prio> st(nInst);
-  for (int32_t k = 0; k < nInst; ++k) {
-    const mrp_hl_instance& in = instances[k];
-    int rc = mrp_ll_upload_map(ctx, in.dimx, in.dimy, in.n_obstacles, in.obstacles_xy, &st[k].mapId);
+  const size_t n = idx.size();
+  std::vector<Prio> st(n);
+  for (size_t q = 0; q < n; ++q) {
+    const mrp_hl_instance& in = instances[idx[q]];
+    int rc = mrp_ll_upload_map(ctx, in.dimx, in.dimy, in.n_obstacles, in.obstacles_xy, &st[q].mapId);
     if (rc != MRP_LL_SUCCESS) {
-      s->err = std::string("mrp_ll_upload_map: ") + mrp_ll_last_error(ctx);
-      return rc;
+      out.err = std::string("mrp_ll_upload_map: ") + mrp_ll_last_error(ctx);
+      return;
     }
-    sols[k].cost = 0;
-    sols[k].low_level_expanded = 0;
-    sols[k].n_planned = 0;
+    sols[idx[q]].cost = 0;
+    sols[idx[q]].low_level_expanded = 0;
+    sols[idx[q]].n_planned = 0;
   }
-  mrp_hl_batch_stats bs;
-  std::memset(&bs, 0, sizeof(bs));
-  auto t0 = std::chrono::steady_clock::now();
   const int32_t cap = std::max(horizon, 64);
   std::vector<mrp_ll_job> jobs;
   std::vector<mrp_ll_result> results;
@@ -670,9 +670,9 @@ int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl
   for (;;) {
     jobs.clear();
     owner.clear();
-    for (int32_t k = 0; k < nInst; ++k) {
-      Prio& p = st[k];
-      const mrp_hl_instance& in = instances[k];
+    for (size_t q = 0; q < n; ++q) {
+      Prio& p = st[q];
+      const mrp_hl_instance& in = instances[idx[q]];
       if (p.agent >= in.n_agents) continue;
       p.xy.clear();
       p.cnt.clear();
@@ -701,7 +701,7 @@ int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl
       j.collision_count = p.cnt.data();
       j.collision_intervals = p.ivs.data();
       jobs.push_back(j);
-      owner.push_back(k);
+      owner.push_back(static_cast<int32_t>(q));
     }
     if (jobs.empty()) break;
     results.assign(jobs.size(), mrp_ll_result());
@@ -713,22 +713,21 @@ int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl
     }
     int rc = mrp_ll_search_batch(ctx, static_cast<int32_t>(jobs.size()), jobs.data(), results.data());
     if (rc != MRP_LL_SUCCESS) {
-      s->err = std::string("mrp_ll_search_batch: ") + mrp_ll_last_error(ctx);
-      return rc;
+      out.err = std::string("mrp_ll_search_batch: ") + mrp_ll_last_error(ctx);
+      return;
     }
-    bs.rounds += 1;
-    bs.ll_searches += static_cast<int64_t>(jobs.size());
-    for (size_t q = 0; q < jobs.size(); ++q) {
-      const int32_t k = owner[q];
-      Prio& p = st[k];
-      mrp_hl_sipp_solution& so = sols[k];
-      const mrp_ll_result& r = results[q];
+    out.rounds += 1;
+    out.searches += static_cast<int64_t>(jobs.size());
+    for (size_t jq = 0; jq < jobs.size(); ++jq) {
+      Prio& p = st[owner[jq]];
+      mrp_hl_sipp_solution& so = sols[idx[owner[jq]]];
+      const mrp_ll_result& r = results[jq];
       const int32_t a = p.agent;
       so.low_level_expanded += r.expanded;
-      bs.ll_expansions += r.expanded;
+      out.expansions += r.expanded;
       if (r.status != MRP_LL_OK && r.status != MRP_LL_NO_SOLUTION) {
-        s->err = "prioritized SIPP: low-level capacity status " + std::to_string(r.status);
-        return MRP_LL_E_DEVICE;
+        out.err = "prioritized SIPP: low-level capacity status " + std::to_string(r.status);
+        return;
       }
       const bool ok = r.status == MRP_LL_OK;
       if (so.planned) so.planned[a] = ok ? 1 : 0;
@@ -760,7 +759,38 @@ int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl
       p.agent += 1;
     }
   }
+}
+
+}  // namespace
+
+int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl_instance* instances,
+                                   mrp_hl_sipp_solution* sols, mrp_hl_batch_stats* stats) {
+  if (!s || nInst < 0 || (nInst > 0 && (!instances || !sols))) return MRP_LL_E_INVALID;
+  const int32_t horizon = s->llOpt.max_horizon > 0 ? s->llOpt.max_horizon : 512;
+  // instances are independent: one share per worker thread / engine, as for CBS and ECBS
+  const int32_t nThreads = std::max(1, std::min<int32_t>(static_cast<int32_t>(s->engines.size()), std::max(nInst, 1)));
+  std::vector<std::vector<int32_t>> idx(nThreads);
+  for (int32_t k = 0; k < nInst; ++k) idx[k % nThreads].push_back(k);
+  std::vector<GroupResult> gr(nThreads);
+  auto t0 = std::chrono::steady_clock::now();
+  {
+    std::vector<std::thread> th;
+    for (int32_t t = 0; t < nThreads; ++t)
+      th.emplace_back([&, t]() { runSippGroup(s->engines[t], horizon, instances, sols, idx[t], gr[t]); });
+    for (auto& x : th) x.join();
+  }
+  mrp_hl_batch_stats bs;
+  std::memset(&bs, 0, sizeof(bs));
   bs.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (auto& g : gr) {
+    if (!g.err.empty()) {
+      s->err = g.err;
+      return MRP_LL_E_DEVICE;
+    }
+    bs.rounds += g.rounds;
+    bs.ll_searches += g.searches;
+    bs.ll_expansions += g.expansions;
+  }
   for (int32_t k = 0; k < nInst; ++k) bs.solved += sols[k].n_planned == instances[k].n_agents ? 1 : 0;
   if (stats) *stats = bs;
   return MRP_LL_SUCCESS;

@@ -23,7 +23,7 @@ for agents, n in ((4, 4096), (6, 4096), (8, 2048)):
                                             gpu_inst_per_s=n / st["wall_seconds"], cpu_exp_per_s=e / t, cpu_inst_per_s=m / t, mismatches=mism)
     print(json.dumps({k: out[k] for k in list(out)[-1:]}), flush=True)
 # ---- config 5: prioritized SIPP 64x64, 10 % obstacles ----
-for agents, n in ((50, 256), (100, 128)):
+for agents, n in ():  # prioritized SIPP: see scripts/sipp_bench.py
     insts = [hl.generate_instance(640000 + 1000 * agents + k, 64, 64, 410, agents) for k in range(n)]
     s.prioritized_sipp(insts[:8])
     res, st = s.prioritized_sipp(insts)
