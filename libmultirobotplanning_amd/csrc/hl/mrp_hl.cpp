@@ -787,7 +787,7 @@ int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl
       s->err = g.err;
       return MRP_LL_E_DEVICE;
     }
-    bs.rounds += g.rounds;
+    bs.rounds = std::max(bs.rounds, g.rounds);  // rounds run concurrently on the worker threads: the longest chain
     bs.ll_searches += g.searches;
     bs.ll_expansions += g.expansions;
   }
