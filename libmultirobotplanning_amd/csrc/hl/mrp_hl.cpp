@@ -34,7 +34,10 @@ struct mrp_hl_solver {
 
 namespace {
 
-constexpr int64_t kDeepHl = 4;  // conflict-tree expansions after which an instance counts as a long chain
+// Conflict-tree expansions after which an instance's searches take the engine's priority lane (MRP_HL_DEEP).  Off by
+// default: with the job slots recycled in completion order the bulk lane no longer starves long chains (measured
+// neutral for ECBS at the bench shape), and for CBS — where nearly every instance is deep — it only adds contention.
+constexpr int64_t kDeepHl = INT64_MAX;
 
 struct GroupResult {
   int64_t rounds = 0, searches = 0, expansions = 0;

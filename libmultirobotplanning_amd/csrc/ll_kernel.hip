@@ -1179,19 +1179,30 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
       const uint32_t hd1 = rfl(__hip_atomic_load(head1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
       const uint32_t t1 = rfl(__hip_atomic_load(tickets1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       if ((int32_t)(hd1 - t1) > 0) {
-        // lane 0 carries the real compare value; the others compare against a value the counter cannot hold now
-        const uint32_t old = atomicCAS(tickets1, lane == 0 ? t1 : (t1 ^ 0x80000000u), t1 + 1u);
-        if (rfl(old) == t1) {
-          const uint32_t gen = (t1 / q1 + 1) & 0x1FFFFFu;
+        // Claim by compare-and-swap; a lost race retries on the device counter alone (the value the failed swap returned)
+        // while it is still below the published count read above — going back to the host word for every attempt would
+        // serialise the claims of all workgroups at one PCIe round trip each.  Lane 0 carries the real compare value;
+        // the other lanes compare against a value the counter cannot hold now.
+        uint32_t cur = t1;
+        bool got = false;
+        while ((int32_t)(hd1 - cur) > 0) {
+          const uint32_t old = rfl(atomicCAS(tickets1, lane == 0 ? cur : (cur ^ 0x80000000u), cur + 1u));
+          if (old == cur) {
+            got = true;
+            break;
+          }
+          cur = old;
+        }
+        if (got) {
+          const uint32_t gen = (cur / q1 + 1) & 0x1FFFFFu;
           uint32_t e;
           do {  // published before head1 was advanced: visible on the first look in practice
-            e = rfl(__hip_atomic_load(ring1 + t1 % q1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+            e = rfl(__hip_atomic_load(ring1 + cur % q1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
           } while ((e >> 11) != gen);
           slot = e & 2047u;
-          doneVal = ((t1 + 1u) & 0x3FFFFFFFu) | 0xC0000000u;
+          doneVal = ((cur + 1u) & 0x3FFFFFFFu) | 0xC0000000u;
           break;
         }
-        continue;  // another workgroup was faster: look again at once
       }
       // bulk lane
       if (!haveBulk) {
