@@ -12,11 +12,17 @@ along.  Instances are generated (splitmix64, seeds 1000*agents + k) before the t
 to HBM before it starts, as the reference constructs its Environment before its Timer (example/ecbs.cpp:576-582).
 
 Extra objects:
-  roofline     — dominant kernel mrp_ll_search_kernel: achieved = 128 B/expansion x expansions of the
-                 timed launches / sum of their hipEvent durations; bound = HBM (8 TB/s).  See DESIGN.md for why this
-                 fraction is tiny by construction (the path is latency-bound heap replay in LDS, not streaming).
+  roofline     — dominant kernel mrp_ll_persistent_kernel (session mode: one resident launch per host thread per step):
+                 achieved = 128 B/expansion x expansions of the timed launches / sum of their hipEvent
+                 durations; bound = HBM (8 TB/s); traffic = HBM bytes per launch scaled from the committed PMC passes.
+                 The fraction is tiny by construction — the path is an issue-bound replay of sequential heaps whose
+                 working set sits in LDS / L2 — so `issue_bound` rides along: the chip-wide ceiling of
+                 the kernel's measured instruction stream (instructions per expansion from the committed PMC passes x 4
+                 cycles per issue slot, 256 CUs x 4 SIMDs) and the fraction of it this run reached.
   cpu_baseline — the oracle's CPU restatement (kind "port"; the reference needs Boost/yaml-cpp and cannot be built here)
-                 timed single-threaded on a bounded sample of the same workload, on this box's host cores.
+                 timed single-threaded on a bounded sample of the same workload, on this box's host cores, with a
+                 per-instance parity check against the GPU results; cpu_baseline_all_cores repeats the sample with one
+                 instance per thread on all host threads the bench uses (SURVEY.md §8d asks for both).
 """
 import argparse
 import json
@@ -122,6 +128,22 @@ def main():
     if rank == 0:
         kernel_s = lls["kernel_ms"] / 1e3
         achieved = ALGO_BYTES_PER_EXPANSION * lls["expansions"] / max(kernel_s, 1e-12) / 1e9
+        # HBM bytes per launch: bench.py cannot run rocprofv3's PMC passes on itself, so it scales the bytes per expansion
+        # measured by the committed passes over this same program (profiles/hbm_traffic_pmc.json, FETCH_SIZE + WRITE_SIZE
+        # in separate passes, raw counter values) by the expansions of its own launches; null when the file is absent
+        traffic = None
+        issue_bound = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic_pmc.json")) as f:
+                pmc = json.load(f)
+            traffic = pmc["bytes_per_expansion_raw"] * lls["expansions"] / max(lls["launches"], 1)
+            ipe = pmc["instructions_per_expansion"]
+            ceiling = 256 * 4 * pmc.get("shader_clock_hz", 2.2e9) / (4.0 * ipe)
+            issue_bound = {"instructions_per_expansion": ipe, "ceiling_expansions_per_s": ceiling,
+                           "frac": (exp_all / elapsed_max) / world / ceiling,
+                           "source": "profiles/hbm_traffic_pmc.json (SQ_INSTS_* passes, scripts/pmc_ll.sh)"}
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "low_level_node_expansions_per_sec",
             "value": exp_all / elapsed_max,
@@ -150,12 +172,13 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "achieved_all_launches_concurrently": ALGO_BYTES_PER_EXPANSION * (exp_all / elapsed_max) / 1e9,
                 "kernel": "mrp_ll_persistent_kernel",
                 "launches": lls["launches"],
                 "avg_launch_ms": lls["kernel_ms"] / max(lls["launches"], 1),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EXPANSION * lls["expansions"] / max(lls["launches"], 1),
+                "issue_bound": issue_bound,
                 "note": "rank-0 launches of the timed region: session mode keeps one resident launch per host thread "
                         "per step (fed through the pinned-host job ring), and the launches of the threads overlap in time",
             },

@@ -240,6 +240,13 @@ class LowLevelEngine:
                                 action_costs=costs[i, :max(m - 1, 0)].tolist()))
         return out
 
+    def configure_tiers(self, lds_nodes: int = 0, lds_rows: int = 0, lds_path_bytes: int = 0) -> int:
+        """Geometry of the LDS fast tier for the launches that follow (0 = keep); returns resident searches per CU."""
+        occ = ctypes.c_int32(0)
+        self._check(self._lib.mrp_ll_configure_tiers(self._h, lds_nodes, lds_rows, lds_path_bytes, ctypes.byref(occ)),
+                    "mrp_ll_configure_tiers")
+        return occ.value
+
     def session_begin(self, workgroups: int = 0):
         """Keep `workgroups` wavefronts resident and feed them through the host job ring (see mrp_ll.h)."""
         self._check(self._lib.mrp_ll_session_begin(self._h, workgroups), "mrp_ll_session_begin")

@@ -18,6 +18,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   find $O/pmc_$c -name "*kernel_trace.csv" -delete
 done
 echo "pmc done"
+bash $R/scripts/pmc_ll.sh > $O/pmc_ll.log 2>&1 || { tail -5 $O/pmc_ll.log; exit 1; }
+echo "pmc_ll done"
 cd $R
 timeout -k 10 300 python bench.py --agents 20 --instances 32768 --steps 2 --warmup 1 --cpu-sample 1024 > $O/bench_agents20.json 2> $O/bench_agents20.err || exit 1
 timeout -k 10 300 python bench.py --agents 50 --instances 4096 --steps 2 --warmup 1 --cpu-sample 128 > $O/bench_agents50.json 2> $O/bench_agents50.err || exit 1

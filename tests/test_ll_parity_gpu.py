@@ -107,6 +107,31 @@ def test_tiers_agree(oracle_mod, bench_instances):
             eng.close()
 
 
+def test_configure_tiers_changes_nothing_but_the_tier(oracle_mod, bench_instances):
+    """mrp_ll_configure_tiers: any LDS geometry (heaps hold nodes/2 entries, so a tiny tier also overflows through the
+    open-list bound) gives the same bits; occupancy follows the tier size."""
+    from libmultirobotplanning_amd import ll
+    cases = _harvest(oracle_mod, bench_instances, ["map_32by32_obst204_agents10_ex%d" % k for k in range(10, 14)],
+                     oracle_mod.ECBS, 1.3, 3_000_000)
+    eng = ll.LowLevelEngine(device=0, n_tickets=1, slots=256)
+    try:
+        occ = []
+        for geom in ((400, 48, 2048), (64, 16, 64), (1024, 96, 8192), (8, 8, 32)):
+            occ.append(eng.configure_tiers(*geom))
+            res = _run_and_compare(eng, cases, ll.ASTAR_EPS, 1.3)
+            if geom[0] <= 64:
+                assert any(r.tier == 1 for r in res)
+        assert occ[0] == 8 and occ[2] < occ[0]
+        eng.session_begin(64)
+        try:
+            with pytest.raises(RuntimeError):
+                eng.configure_tiers(256, 32, 1024)  # MRP_LL_E_BUSY while a session is open
+        finally:
+            eng.session_end()
+    finally:
+        eng.close()
+
+
 def test_session_mode_matches_oracle(oracle_mod, bench_instances):
     """Session mode (resident wavefronts fed through the pinned-host job ring): same jobs, same bits, any order."""
     from libmultirobotplanning_amd import ll
