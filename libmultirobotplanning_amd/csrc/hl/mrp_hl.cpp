@@ -476,7 +476,7 @@ int mrp_hl_solver_create(int32_t device, int32_t nThreads, const mrp_ll_options*
   std::memset(&s->llOpt, 0, sizeof(s->llOpt));
   if (llOpt) s->llOpt = *llOpt;
   s->llOpt.device = device;
-  if (s->llOpt.n_tickets <= 0) s->llOpt.n_tickets = 1;
+  s->llOpt.n_tickets = std::max(s->llOpt.n_tickets, 2);  // the prioritized-SIPP driver keeps two batches in flight
   if (s->llOpt.slots <= 0) s->llOpt.slots = 512;
   if (s->llOpt.arena_nodes <= 0) s->llOpt.arena_nodes = 65536;
   for (int32_t t = 0; t < nThreads; ++t) {
@@ -649,9 +649,18 @@ void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, const mrp_hl_instance* insta
                   const std::vector<int32_t>& idx, GroupResult& out) {
   struct Iv { int32_t s, e; };
   struct Prio {
-    int32_t mapId = -1, agent = 0;
-    std::map<std::pair<int32_t, int32_t>, std::vector<Iv>> all;  // allCollisionIntervals (:215), ordered by (x, y)
-    std::vector<int32_t> xy, cnt, ivs;                            // flattened for the job of the current round
+    int32_t mapId = -1, agent = 0, dimx = 0;
+    // allCollisionIntervals (mapf_prioritized_sipp.cpp:215): the reference keeps a std::map keyed by location and hands
+    // every entry to setCollisionIntervals, whose result does not depend on the order of the locations; here: one list
+    // per cell plus the cells that have one, in first-touch order
+    std::vector<std::vector<Iv>> perCell;
+    std::vector<int32_t> touched;
+    std::vector<int32_t> xy, cnt, ivs;  // flattened for the job of the current round
+    void add(int32_t x, int32_t y, Iv iv) {
+      std::vector<Iv>& v = perCell[static_cast<size_t>(y) * dimx + x];
+      if (v.empty()) touched.push_back(y * dimx + x);
+      v.push_back(iv);
+    }
   };
   const size_t n = idx.size();
   std::vector<Prio> st(n);
@@ -665,26 +674,41 @@ void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, const mrp_hl_instance* insta
     sols[idx[q]].cost = 0;
     sols[idx[q]].low_level_expanded = 0;
     sols[idx[q]].n_planned = 0;
+    st[q].dimx = in.dimx;
+    st[q].perCell.assign(static_cast<size_t>(std::max(in.dimx, 0)) * std::max(in.dimy, 0), std::vector<Iv>());
   }
   const int32_t cap = std::max(horizon, 64);
-  std::vector<mrp_ll_job> jobs;
-  std::vector<mrp_ll_result> results;
-  std::vector<int32_t> owner, statesPool;
-  for (;;) {
-    jobs.clear();
-    owner.clear();
-    for (size_t q = 0; q < n; ++q) {
+  // Two halves of the instances take turns: while the searches of one half run on the GPU, the host consumes the
+  // results of the other half and packs its next round (a round of a half still ends with its slowest search).
+  struct Half {
+    std::vector<size_t> members;
+    std::vector<mrp_ll_job> jobs;
+    std::vector<mrp_ll_result> results;
+    std::vector<int32_t> owner, statesPool;
+    int32_t ticket = -1;
+    bool inflight = false;
+  };
+  Half half[2];
+  for (size_t q = 0; q < n; ++q) half[n >= 64 ? (q & 1) : 0].members.push_back(q);
+  int64_t roundsOf[2] = {0, 0};
+
+  // round of one half: agent p.agent of every member that still has one; returns false when there was nothing to do
+  auto launch = [&](Half& H) -> bool {
+    H.jobs.clear();
+    H.owner.clear();
+    for (size_t q : H.members) {
       Prio& p = st[q];
       const mrp_hl_instance& in = instances[idx[q]];
       if (p.agent >= in.n_agents) continue;
       p.xy.clear();
       p.cnt.clear();
       p.ivs.clear();
-      for (const auto& kv : p.all) {  // sipp.setCollisionIntervals(location, intervals) for every location (:224-226)
-        p.xy.push_back(kv.first.first);
-        p.xy.push_back(kv.first.second);
-        p.cnt.push_back(static_cast<int32_t>(kv.second.size()));
-        for (const Iv& iv : kv.second) {
+      for (int32_t cell : p.touched) {  // sipp.setCollisionIntervals(location, intervals) for every location (:224-226)
+        const std::vector<Iv>& v = p.perCell[cell];
+        p.xy.push_back(cell % p.dimx);
+        p.xy.push_back(cell / p.dimx);
+        p.cnt.push_back(static_cast<int32_t>(v.size()));
+        for (const Iv& iv : v) {
           p.ivs.push_back(iv.s);
           p.ivs.push_back(iv.e);
         }
@@ -703,34 +727,43 @@ void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, const mrp_hl_instance* insta
       j.collision_xy = p.xy.data();
       j.collision_count = p.cnt.data();
       j.collision_intervals = p.ivs.data();
-      jobs.push_back(j);
-      owner.push_back(static_cast<int32_t>(q));
+      H.jobs.push_back(j);
+      H.owner.push_back(static_cast<int32_t>(q));
     }
-    if (jobs.empty()) break;
-    results.assign(jobs.size(), mrp_ll_result());
-    statesPool.resize(jobs.size() * static_cast<size_t>(cap) * 3);
-    for (size_t q = 0; q < jobs.size(); ++q) {
-      std::memset(&results[q], 0, sizeof(mrp_ll_result));
-      results[q].states_txy = statesPool.data() + q * static_cast<size_t>(cap) * 3;
-      results[q].states_cap = cap;
+    if (H.jobs.empty()) return false;
+    H.results.assign(H.jobs.size(), mrp_ll_result());
+    H.statesPool.resize(H.jobs.size() * static_cast<size_t>(cap) * 3);
+    for (size_t q = 0; q < H.jobs.size(); ++q) {
+      std::memset(&H.results[q], 0, sizeof(mrp_ll_result));
+      H.results[q].states_txy = H.statesPool.data() + q * static_cast<size_t>(cap) * 3;
+      H.results[q].states_cap = cap;
     }
-    int rc = mrp_ll_search_batch(ctx, static_cast<int32_t>(jobs.size()), jobs.data(), results.data());
+    int rc = mrp_ll_submit(ctx, static_cast<int32_t>(H.jobs.size()), H.jobs.data(), H.results.data(), &H.ticket);
     if (rc != MRP_LL_SUCCESS) {
-      out.err = std::string("mrp_ll_search_batch: ") + mrp_ll_last_error(ctx);
-      return;
+      out.err = std::string("mrp_ll_submit: ") + mrp_ll_last_error(ctx);
+      return false;
     }
-    out.rounds += 1;
-    out.searches += static_cast<int64_t>(jobs.size());
-    for (size_t jq = 0; jq < jobs.size(); ++jq) {
-      Prio& p = st[owner[jq]];
-      mrp_hl_sipp_solution& so = sols[idx[owner[jq]]];
-      const mrp_ll_result& r = results[jq];
+    H.inflight = true;
+    out.searches += static_cast<int64_t>(H.jobs.size());
+    return true;
+  };
+  auto consume = [&](Half& H) -> bool {
+    int rc = mrp_ll_wait(ctx, H.ticket);
+    H.inflight = false;
+    if (rc != MRP_LL_SUCCESS) {
+      out.err = std::string("mrp_ll_wait: ") + mrp_ll_last_error(ctx);
+      return false;
+    }
+    for (size_t jq = 0; jq < H.jobs.size(); ++jq) {
+      Prio& p = st[H.owner[jq]];
+      mrp_hl_sipp_solution& so = sols[idx[H.owner[jq]]];
+      const mrp_ll_result& r = H.results[jq];
       const int32_t a = p.agent;
       so.low_level_expanded += r.expanded;
       out.expansions += r.expanded;
       if (r.status != MRP_LL_OK && r.status != MRP_LL_NO_SOLUTION) {
         out.err = "prioritized SIPP: low-level capacity status " + std::to_string(r.status);
-        return;
+        return false;
       }
       const bool ok = r.status == MRP_LL_OK;
       if (so.planned) so.planned[a] = ok ? 1 : 0;
@@ -743,14 +776,14 @@ void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, const mrp_hl_instance* insta
         int32_t lx = S[1], ly = S[2], lt = S[0];
         for (int32_t i = 1; i < r.n_states; ++i) {
           if (S[3 * i + 1] != lx || S[3 * i + 2] != ly) {
-            p.all[{lx, ly}].push_back(Iv{lt, S[3 * i] - 1});
+            p.add(lx, ly, Iv{lt, S[3 * i] - 1});
             lx = S[3 * i + 1];
             ly = S[3 * i + 2];
             lt = S[3 * i];
           }
         }
         const int32_t last = r.n_states - 1;
-        p.all[{S[3 * last + 1], S[3 * last + 2]}].push_back(Iv{S[3 * last], INT32_MAX});
+        p.add(S[3 * last + 1], S[3 * last + 2], Iv{S[3 * last], INT32_MAX});
         if (so.states_xyt)
           for (int32_t i = 0; i < r.n_states && i < so.state_cap; ++i) {
             int32_t* dst = so.states_xyt + (static_cast<size_t>(a) * so.state_cap + i) * 3;
@@ -761,7 +794,26 @@ void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, const mrp_hl_instance* insta
       }
       p.agent += 1;
     }
+    return true;
+  };
+
+  for (int hIdx = 0; hIdx < 2; ++hIdx)
+    if (launch(half[hIdx])) roundsOf[hIdx] += 1;
+  if (!out.err.empty()) return;
+  for (int cur = 0; half[0].inflight || half[1].inflight; cur ^= 1) {
+    Half& H = half[cur];
+    if (!H.inflight) continue;
+    if (!consume(H)) {
+      if (half[cur ^ 1].inflight) (void)mrp_ll_wait(ctx, half[cur ^ 1].ticket);  // do not leave a batch behind
+      return;
+    }
+    if (launch(H)) roundsOf[cur] += 1;
+    if (!out.err.empty()) {
+      if (half[cur ^ 1].inflight) (void)mrp_ll_wait(ctx, half[cur ^ 1].ticket);
+      return;
+    }
   }
+  out.rounds = std::max(roundsOf[0], roundsOf[1]);
 }
 
 }  // namespace

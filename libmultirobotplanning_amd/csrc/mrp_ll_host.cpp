@@ -167,6 +167,7 @@ struct mrp_ll_ctx {
   Ring ring;
   std::vector<SessTicket> sess;
   std::vector<int32_t> sessFree;   // free session-ticket ids (stack)
+  void* sippScratch = nullptr;     // SippScratch, created on first use (packSipp)
 };
 
 namespace {
@@ -226,6 +227,14 @@ struct ConsSinkBuf {
   void push(uint32_t w) {
     if (b.push(w) != hipSuccess) failed = true;
   }
+  uint32_t* grow(size_t n) {  // n consecutive words, written by the caller
+    const size_t at = b.size;
+    if (b.resize(at + n) != hipSuccess) {
+      failed = true;
+      return nullptr;
+    }
+    return b.host + at;
+  }
 };
 struct PathSinkBuf {
   PinnedBuf<uint16_t>& b;
@@ -252,6 +261,15 @@ struct ConsSinkSlot {
     }
     area[used++] = w;
   }
+  uint32_t* grow(size_t n) {
+    if (used + n > cap) {
+      failed = true;
+      return nullptr;
+    }
+    uint32_t* p = area + used;
+    used += static_cast<uint32_t>(n);
+    return p;
+  }
 };
 struct PathSinkSlot {
   uint16_t* area;
@@ -270,61 +288,99 @@ struct PathSinkSlot {
 // SIPP job tables (see runSipp in ll_kernel.hip).  Safe intervals are derived from the collision intervals exactly as
 // SIPPEnvironment::setCollisionIntervals does (sipp.hpp:245-284): sort by start; a safe interval [start, ci.start-1]
 // in front of every collision interval when non-empty; a final [start, INT_MAX] unless the last one ends at INT_MAX.
+struct SippScratch {  // reused across jobs of a context: packSipp allocates nothing in the steady state
+  struct Iv { int32_t s, e; };
+  std::vector<int32_t> cellIdx;            // cell -> special index + 1
+  std::vector<uint32_t> first, count;      // per special cell: block of safe intervals inside `pool`
+  std::vector<Iv> pool, ci;
+};
+
+SippScratch& sippScratchOf(mrp_ll_ctx* ctx) {
+  if (!ctx->sippScratch) ctx->sippScratch = new SippScratch();
+  return *static_cast<SippScratch*>(ctx->sippScratch);
+}
+
 template <class ConsSink>
 bool packSipp(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, ConsSink& cs, DevJob& d) {
-  (void)ctx;
   const int cells = mp.dimx * mp.dimy;
   if (j.n_collision_locations < 0) return false;
   if (j.n_collision_locations > 0 && (!j.collision_xy || !j.collision_count || !j.collision_intervals)) return false;
-  struct Iv { int32_t s, e; };
-  std::vector<int32_t> cellIdx(cells, 0);
-  std::vector<std::vector<Iv>> safe;  // per special cell
+  typedef SippScratch::Iv Iv;
+  SippScratch& sc0 = sippScratchOf(ctx);
+  std::vector<int32_t>& cellIdx = sc0.cellIdx;
+  cellIdx.assign(cells, 0);
+  sc0.first.clear();
+  sc0.count.clear();
+  sc0.pool.clear();
   size_t off = 0;
   for (int n = 0; n < j.n_collision_locations; ++n) {
     const int x = j.collision_xy[2 * n], y = j.collision_xy[2 * n + 1];
     const int cnt = j.collision_count[n];
-    std::vector<Iv> ci;
-    for (int k = 0; k < cnt; ++k) ci.push_back(Iv{j.collision_intervals[2 * (off + k)], j.collision_intervals[2 * (off + k) + 1]});
+    const int32_t* civ = j.collision_intervals + 2 * off;
     off += cnt;
     if (x < 0 || x >= mp.dimx || y < 0 || y >= mp.dimy) continue;  // never visited
     const int cell = y * mp.dimx + x;
-    std::vector<Iv> si;
+    const uint32_t p0 = static_cast<uint32_t>(sc0.pool.size());
     if (cnt > 0) {
-      std::stable_sort(ci.begin(), ci.end(), [](const Iv& a, const Iv& b) { return a.s < b.s; });
+      std::vector<Iv>& ci = sc0.ci;
+      ci.clear();
+      bool sorted = true;
+      for (int k = 0; k < cnt; ++k) {
+        ci.push_back(Iv{civ[2 * k], civ[2 * k + 1]});
+        if (k && ci[k].s < ci[k - 1].s) sorted = false;
+      }
+      if (!sorted) std::stable_sort(ci.begin(), ci.end(), [](const Iv& a, const Iv& b) { return a.s < b.s; });
       long long start = 0;
       int32_t lastEnd = 0;
       for (const Iv& c : ci) {
-        if (start <= static_cast<long long>(c.s) - 1) si.push_back(Iv{static_cast<int32_t>(start), c.s - 1});
+        if (start <= static_cast<long long>(c.s) - 1) sc0.pool.push_back(Iv{static_cast<int32_t>(start), c.s - 1});
         start = static_cast<long long>(c.e) + 1;
         lastEnd = c.e;
       }
-      if (lastEnd < INT32_MAX) si.push_back(Iv{static_cast<int32_t>(start), INT32_MAX});
+      if (lastEnd < INT32_MAX) sc0.pool.push_back(Iv{static_cast<int32_t>(start), INT32_MAX});
     }
+    const uint32_t nSafe = static_cast<uint32_t>(sc0.pool.size()) - p0;
     // erase + re-create (sipp.hpp:247-251): an empty list restores the default single interval
     if (cellIdx[cell]) {
-      safe[cellIdx[cell] - 1] = si;
-      if (cnt == 0) safe[cellIdx[cell] - 1] = std::vector<Iv>{Iv{0, INT32_MAX}};
+      const int k = cellIdx[cell] - 1;
+      if (cnt == 0) {
+        sc0.first[k] = static_cast<uint32_t>(sc0.pool.size());
+        sc0.pool.push_back(Iv{0, INT32_MAX});
+        sc0.count[k] = 1;
+      } else {
+        sc0.first[k] = p0;
+        sc0.count[k] = nSafe;
+      }
     } else if (cnt > 0) {
-      safe.push_back(si);
-      cellIdx[cell] = static_cast<int32_t>(safe.size());
+      sc0.first.push_back(p0);
+      sc0.count.push_back(nSafe);
+      cellIdx[cell] = static_cast<int32_t>(sc0.first.size());
     }
   }
+  const uint32_t K = static_cast<uint32_t>(sc0.first.size());
+  uint32_t total = 0;
+  for (uint32_t k = 0; k < K; ++k) total += sc0.count[k];
   d.algo = MRP_LL_SIPP;
   d.max_expansions = j.max_expansions;
   d.vc_off = static_cast<uint32_t>(cs.size());
-  for (int c = 0; c < cells; ++c) cs.push(static_cast<uint32_t>(cellIdx[c]));
-  uint32_t total = 0;
-  for (const auto& v : safe) {
-    cs.push(total);
-    total += static_cast<uint32_t>(v.size());
-  }
-  cs.push(total);
-  for (const auto& v : safe)
-    for (const Iv& iv : v) {
-      cs.push(static_cast<uint32_t>(iv.s));
-      cs.push(static_cast<uint32_t>(iv.e));
+  {  // cellIdx[cells], specFirst[K + 1], ivals[total][2]
+    uint32_t* w = cs.grow(static_cast<size_t>(cells) + K + 1 + 2 * static_cast<size_t>(total));
+    if (!w) return false;
+    std::memcpy(w, cellIdx.data(), sizeof(uint32_t) * cells);
+    w += cells;
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+      w[k] = run;
+      run += sc0.count[k];
     }
-  d.n_vc = static_cast<uint32_t>(safe.size());
+    w[K] = run;
+    w += K + 1;
+    for (uint32_t k = 0; k < K; ++k) {
+      std::memcpy(w, sc0.pool.data() + sc0.first[k], sizeof(Iv) * sc0.count[k]);
+      w += 2 * sc0.count[k];
+    }
+  }
+  d.n_vc = K;
   d.n_ec = total;
   d.ec_off = 0;
   d.n_agents_pad = 0;
@@ -336,8 +392,8 @@ bool packSipp(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, ConsSink& 
   if (!cellIdx[sc]) {
     startIv = 0;
   } else {
-    const auto& v = safe[cellIdx[sc] - 1];
-    for (size_t k = 0; k < v.size(); ++k)
+    const Iv* v = sc0.pool.data() + sc0.first[cellIdx[sc] - 1];
+    for (uint32_t k = 0; k < sc0.count[cellIdx[sc] - 1]; ++k)
       if (v[k].s <= 0 && v[k].e >= 0) {
         startIv = static_cast<int>(k);
         break;
@@ -652,6 +708,7 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
   if (ctx->ring.block) (void)hipHostFree(ctx->ring.block);
   if (ctx->ring.compCountDev) (void)hipFree(ctx->ring.compCountDev);
   if (ctx->ring.ticksDev) (void)hipFree(ctx->ring.ticksDev);
+  delete static_cast<SippScratch*>(ctx->sippScratch);
   for (auto& t : ctx->tickets) {
     if (t.inFlight && t.evK1) (void)hipEventSynchronize(t.evK1);
     if (t.stream) (void)hipStreamSynchronize(t.stream);

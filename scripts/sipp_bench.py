@@ -13,7 +13,11 @@ s = hl.BatchSolver(device=0, n_threads=threads, slots=512)
 insts = [hl.generate_instance(640000 + 1000 * agents + k, 64, 64, 410, agents) for k in range(n)]
 s.prioritized_sipp(insts[:64])
 for rep in range(2):
+    s.ll_stats(reset=True)
     res, st = s.prioritized_sipp(insts)
+    ls = s.ll_stats()
+    print("   engine totals over %d threads: launches %d, kernel %.1f ms, pack %.1f ms, unpack %.1f ms" % (
+        threads, ls["launches"], ls["kernel_ms"], ls["pack_ms"], ls["unpack_ms"]), flush=True)
     print("rep %d: %d instances x %d agents: wall %.3f s, %.3e exp/s, %.1f inst/s, rounds %d searches %d planned-all %d" % (
         rep, n, agents, st["wall_seconds"], st["ll_expansions"] / st["wall_seconds"], n / st["wall_seconds"], st["rounds"],
         st["ll_searches"], st["solved"]), flush=True)

@@ -107,6 +107,17 @@ def test_tiers_agree(oracle_mod, bench_instances):
             eng.close()
 
 
+def test_more_than_128_agents_in_the_focal_context(engine, oracle_mod):
+    """150 agents: the path table rows are 160 entries wide, so the focal heuristics take the chunked branch of the
+    kernel (columns >= 128) that the shipped benchmark sizes (<= 100 agents) never reach."""
+    from libmultirobotplanning_amd import hl, ll
+    inst = hl.generate_instance(424242, 32, 32, 204, 150)
+    summary, calls = oracle_mod.mapf_record(oracle_mod.ECBS, inst, w=1.3, cap_total=200000)
+    assert len(calls) > 300 and max(len(c["ctx_paths"]) for c in calls) == 150
+    res = _run_and_compare(engine, [("synthetic150", inst, c) for c in calls], ll.ASTAR_EPS, 1.3)
+    assert sum(r.expanded for r in res) == sum(c["expanded"] for c in calls)
+
+
 def test_configure_tiers_changes_nothing_but_the_tier(oracle_mod, bench_instances):
     """mrp_ll_configure_tiers: any LDS geometry (heaps hold nodes/2 entries, so a tiny tier also overflows through the
     open-list bound) gives the same bits; occupancy follows the tier size."""
