@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <climits>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <string>
@@ -23,6 +24,8 @@ struct mrp_hl_preloaded {
   int32_t nInst = 0;
   const mrp_hl_instance* instances = nullptr;
   std::vector<std::vector<int32_t>> idx, mapIds;  // per worker: instance indices and their map ids on that engine
+  std::vector<int32_t> mapBase;                   // per worker: map id of instance 0 on that engine (every engine
+                                                  // holds every map, so any worker can take any instance)
 };
 
 struct mrp_hl_solver {
@@ -189,10 +192,14 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
 
 // Session mode: the engine keeps `workgroups` wavefronts resident (mrp_ll_session_begin) and every instance submits
 // its next searches the moment its previous ones have finished — no instance ever waits for another one's search.
+// `shared` != nullptr: the workers draw instances 0..nTotal-1 from one counter as their own active set drains, so a
+// worker whose instances turn out easy takes more of them (map id of instance k on this engine = mapBase + k);
+// otherwise the worker owns exactly idx[...].
 void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance* instIn, mrp_hl_solution* sols,
                      const std::vector<int32_t>& idx, const std::vector<int32_t>& mapIds, int32_t horizon,
-                     int32_t workgroups, GroupResult& out) {
-  const size_t n = idx.size();
+                     int32_t workgroups, GroupResult& out, std::atomic<int32_t>* shared = nullptr, int32_t nTotal = 0,
+                     int32_t mapBase = 0) {
+  const size_t n = shared ? static_cast<size_t>(nTotal) : idx.size();
   struct Live {
     std::unique_ptr<Instance> inst;
     std::vector<LLRequest> req;
@@ -201,8 +208,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     std::vector<int32_t> states;
     int32_t ticket = -1;
     bool waitingToSubmit = false;
+    double tAdmit = 0, tDone = 0;  // MRP_HL_TIMING only: seconds since the loop started
   };
-  std::vector<Live> live(n);
+  std::deque<Live> live;        // grows as instances are admitted; references stay valid
+  std::vector<int32_t> gidx;    // live entry -> instance index
   const int32_t cap = horizon;
   std::vector<mrp_ll_job> jobs;
   std::vector<int32_t> pathLenPool;
@@ -282,13 +291,37 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   std::vector<int32_t> doneTickets(64);  // small harvest chunks keep the latency of any one instance's chain low
   std::vector<size_t> ticketOwner;  // session ticket id -> local instance
   std::vector<size_t> doneOwners;
-  // Optional admission control (MRP_HL_ACTIVE_LIMIT): at most that many instances are active at a time.  Measured on
-  // MI355X it does not pay — an instance with a long conflict-tree chain that is admitted late simply finishes late —
-  // so by default every instance of the group starts at once.
-  size_t nextToStart = 0;
-  size_t activeLimit = n;
+  // Admission control (MRP_HL_ACTIVE_LIMIT): at most that many instances of this worker are active at a time; the rest
+  // wait in the pool.  With the job slots recycled in completion order it costs nothing (measured 1536..3584 at the
+  // bench shape: same step time as "everything at once"), and with a shared pool it is what lets the workers balance.
+  size_t nextStatic = 0;
+  bool exhausted = false;
+  size_t activeLimit = shared ? 1536 : n;
   if (const char* e = std::getenv("MRP_HL_ACTIVE_LIMIT")) activeLimit = std::max(1, std::atoi(e));
-  for (size_t k = 0; k < n; ++k) live[k].inst.reset(new Instance(instIn[idx[k]], mapIds[k], opt));
+  auto admit = [&]() -> bool {  // next instance of the pool, false when it is empty
+    int32_t k, mid;
+    if (shared) {
+      k = shared->fetch_add(1, std::memory_order_relaxed);
+      if (k >= nTotal) {
+        exhausted = true;
+        return false;
+      }
+      mid = mapBase + k;
+    } else {
+      if (nextStatic >= n) {
+        exhausted = true;
+        return false;
+      }
+      k = idx[nextStatic];
+      mid = mapIds[nextStatic];
+      nextStatic += 1;
+    }
+    live.emplace_back();
+    gidx.push_back(k);
+    live.back().inst.reset(new Instance(instIn[k], mid, opt));
+    if (timing) live.back().tAdmit = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
+    return true;
+  };
   bool failed = false;
   auto t0 = std::chrono::steady_clock::now();
   auto tg2 = t0;
@@ -299,14 +332,13 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   auto secsS = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double>(b - a).count();
   };
-  while (!failed && (nInflight != 0 || !backlog.empty() || nextToStart < n)) {
+  while (!failed && (nInflight != 0 || !backlog.empty() || !exhausted)) {
     bool progress = false;
     auto tA = nowS();
-    while (nextToStart < n && nInflight + backlog.size() < activeLimit) {
-      Live& L = live[nextToStart];
+    while (!exhausted && nInflight + backlog.size() < activeLimit && admit()) {
+      Live& L = live.back();
       L.inst->advance(L.ans, L.req);
-      if (!L.req.empty()) backlog.push_back(nextToStart);
-      nextToStart += 1;
+      if (!L.req.empty()) backlog.push_back(live.size() - 1);
       progress = true;
     }
     // publish as many waiting instances as the ring takes
@@ -383,6 +415,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       auto tu1 = nowS();
       L.inst->advance(L.ans, L.req);
       auto tu2 = nowS();
+      if (timing && L.req.empty()) L.tDone = secsS(tg0, tu2);
       tmUnpack += secsS(tu0, tu1);
       tmAdvance += secsS(tu1, tu2);
       if (!L.req.empty()) {
@@ -427,7 +460,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     mrp_ll_stats ls;
     mrp_ll_get_stats(ctx, &ls);
     std::fprintf(stderr, "[mrp_hl] group of %zu: session_begin %.2f ms, build instances %.2f ms, loop %.2f ms, session_end %.2f ms; "
-                 "cumulative: active wgs %lld, busy %.0f ms, idle %.0f ms, searches %lld, expansions %lld\n", n,
+                 "cumulative: active wgs %lld, busy %.0f ms, idle %.0f ms, searches %lld, expansions %lld\n", live.size(),
                  ms(tg0, tg1), ms(tg1, tg2), ms(tg2, tg3), ms(tg3, tg4), (long long)ls.session_active_wgs,
                  ls.session_busy_ms, ls.session_idle_ms, (long long)ls.jobs, (long long)ls.expansions);
     std::fprintf(stderr, "[mrp_hl]   host ms: submit ok %.1f, submit busy %.1f (%llu), poll empty %.1f (%llu), poll hit %.1f (%llu), "
@@ -435,10 +468,21 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
                  (unsigned long long)nSubmitBusy, tmPollEmpty * 1e3, (unsigned long long)nPollEmpty, tmPollHit * 1e3,
                  (unsigned long long)nPollHit, tmUnpack * 1e3, tmAdvance * 1e3, (long long)out.rounds, (long long)out.searches);
   }
+  if (timing) {  // the instances this worker finished last
+    std::vector<size_t> order(live.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return live[a].tDone > live[b].tDone; });
+    for (size_t q = 0; q < std::min<size_t>(3, order.size()); ++q) {
+      const Live& L = live[order[q]];
+      std::fprintf(stderr, "[mrp_hl]     last #%zu: instance %d admitted %.1f ms done %.1f ms, HL %lld, LL %lld, searches %d\n", q,
+                   gidx[order[q]], L.tAdmit * 1e3, L.tDone * 1e3, (long long)L.inst->hlExpanded(),
+                   (long long)L.inst->llExpanded(), L.inst->llSearches());
+    }
+  }
   if (failed) return;
-  for (size_t k = 0; k < n; ++k) {
+  for (size_t k = 0; k < live.size(); ++k) {
     const Instance& I = *live[k].inst;
-    mrp_hl_solution& s = sols[idx[k]];
+    mrp_hl_solution& s = sols[gidx[k]];
     s.status = I.status();
     s.n_ll_searches = I.llSearches();
     s.high_level_expanded = I.hlExpanded();
@@ -538,27 +582,37 @@ int mrp_hl_solver_preload(mrp_hl_solver* s, int32_t nThreadsWanted, int32_t nIns
   p->instances = instances;
   p->idx.resize(nThreads);
   p->mapIds.resize(nThreads);
-  // instance k -> thread k % nThreads (interleaved, so easy and hard agent counts mix evenly)
+  // Every engine receives every map (a 32x32 bitmap is 128 bytes), so any worker can run any instance: the session
+  // driver lets the workers draw instances from one pool.  idx / mapIds keep the interleaved static split (instance k ->
+  // thread k % nThreads) for the round-based schedule.
   for (int32_t k = 0; k < nInst; ++k) p->idx[k % nThreads].push_back(k);
-  for (int32_t t = 0; t < nThreads; ++t)
-    for (int32_t k : p->idx[t]) {
-      const mrp_hl_instance& in = instances[k];
-      int32_t mid = -1;
-      int rc = mrp_ll_upload_map(s->engines[t], in.dimx, in.dimy, in.n_obstacles, in.obstacles_xy, &mid);
-      if (rc != MRP_LL_SUCCESS) {
-        s->err = std::string("mrp_ll_upload_map: ") + mrp_ll_last_error(s->engines[t]);
-        delete p;
-        return rc;
-      }
-      p->mapIds[t].push_back(mid);
-    }
-  for (int32_t t = 0; t < nThreads; ++t) {  // push the bitmaps to the device now, not at the first launch
-    int rc = mrp_ll_sync_maps(s->engines[t]);
-    if (rc != MRP_LL_SUCCESS) {
-      s->err = std::string("mrp_ll_sync_maps: ") + mrp_ll_last_error(s->engines[t]);
+  p->mapBase.assign(nThreads, 0);
+  std::vector<int> rcs(nThreads, MRP_LL_SUCCESS);
+  {
+    std::vector<std::thread> th;
+    for (int32_t t = 0; t < nThreads; ++t)
+      th.emplace_back([&, t]() {
+        for (int32_t k = 0; k < nInst; ++k) {
+          const mrp_hl_instance& in = instances[k];
+          int32_t mid = -1;
+          int rc = mrp_ll_upload_map(s->engines[t], in.dimx, in.dimy, in.n_obstacles, in.obstacles_xy, &mid);
+          if (rc != MRP_LL_SUCCESS) {
+            rcs[t] = rc;
+            return;
+          }
+          if (k == 0) p->mapBase[t] = mid;
+        }
+        rcs[t] = mrp_ll_sync_maps(s->engines[t]);  // push the bitmaps to the device now, not at the first launch
+      });
+    for (auto& x : th) x.join();
+  }
+  for (int32_t t = 0; t < nThreads; ++t) {
+    if (rcs[t] != MRP_LL_SUCCESS) {
+      s->err = std::string("mrp_ll_upload_map / mrp_ll_sync_maps: ") + mrp_ll_last_error(s->engines[t]);
       delete p;
-      return rc;
+      return rcs[t];
     }
+    for (int32_t k : p->idx[t]) p->mapIds[t].push_back(p->mapBase[t] + k);
   }
   *out = p;
   return MRP_LL_SUCCESS;
@@ -598,8 +652,12 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   int32_t occupancy = 4;
   if (s->llOpt.lds_nodes == 0 && opt.mode != 1) {  // the caller did not choose a geometry: pick one for this batch
     const int32_t pathBytes = opt.algo == MRP_HL_ECBS ? std::min(16384, std::max(2048, agentsPad * 2 * 64)) : 32;
+    // a small batch ends with its longest searches, and those run faster with the SIMD to themselves: then the roomier
+    // tier (fewer overflows into the HBM tier, about one wave per SIMD) is the better trade
+    const bool small = nInst < 32768;
     for (int32_t t = 0; t < nThreads; ++t)
-      if (mrp_ll_configure_tiers(s->engines[t], 400, 48, pathBytes, &occupancy) != MRP_LL_SUCCESS) {
+      if (mrp_ll_configure_tiers(s->engines[t], small ? 512 : 400, small ? 64 : 48, small ? std::max(4096, pathBytes) : pathBytes,
+                                 &occupancy) != MRP_LL_SUCCESS) {
         s->err = std::string("mrp_ll_configure_tiers: ") + mrp_ll_last_error(s->engines[t]);
         return MRP_LL_E_DEVICE;
       }
@@ -607,6 +665,9 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   // resident wavefronts per engine: the chip holds 256 CUs x `occupancy` workgroups of this kernel at once
   int32_t sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, (256 * occupancy) / nThreads));
   if (const char* e = std::getenv("MRP_HL_SESSION_WGS")) sessionWgs = std::max(1, std::atoi(e));  // tuning knob
+  // one pool of instances for all workers (MRP_HL_STATIC_SPLIT=1 restores the fixed interleaved split)
+  std::atomic<int32_t> nextInstance(0);
+  const bool sharedPool = std::getenv("MRP_HL_STATIC_SPLIT") == nullptr;
   auto t0 = std::chrono::steady_clock::now();
   {
     std::vector<std::thread> th;
@@ -614,6 +675,9 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
       th.emplace_back([&, t]() {
         if (opt.mode == 1)
           runGroup(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, gr[t]);
+        else if (sharedPool)
+          runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, gr[t],
+                          &nextInstance, nInst, pre->mapBase[t]);
         else
           runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, gr[t]);
       });
