@@ -167,6 +167,9 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket);
  * any order, so a caller can keep thousands of independent conflict trees moving without waiting for the slowest
  * search of a batch.  Results are identical to the batch mode's. */
 int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups /* 0 = mrp_ll_options.slots */);
+/* The same for MRP_LL_SIPP jobs (a session serves one kind: A* / A*-epsilon jobs, or SIPP jobs — the other kind comes
+ * back as MRP_LL_BAD_JOB).  At most 512 SIPP jobs are in flight at a time (MRP_LL_E_BUSY beyond that). */
+int mrp_ll_session_begin_sipp(mrp_ll_ctx* ctx, int32_t workgroups);
 int mrp_ll_session_end(mrp_ll_ctx* ctx);
 /* Session mode: `lane` 0 = the bulk ring (first in, first out), 1 = the priority ring: every resident wavefront looks
  * there before it takes its next bulk job, so a lane-1 search starts within one job time however long the bulk queue is

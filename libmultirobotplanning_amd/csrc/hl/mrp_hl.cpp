@@ -880,6 +880,193 @@ void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, const mrp_hl_instance* insta
   out.rounds = std::max(roundsOf[0], roundsOf[1]);
 }
 
+// The same loop in session mode: the SIPP kernel stays resident and every instance publishes its next agent's search the
+// moment the previous one has come back — no round barrier, so an instance never waits for another instance's search.
+void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const mrp_hl_instance* instances,
+                         mrp_hl_sipp_solution* sols, const std::vector<int32_t>& idx, GroupResult& out) {
+  struct Iv { int32_t s, e; };
+  struct Prio {
+    int32_t mapId = -1, agent = 0, dimx = 0, ticket = -1;
+    std::vector<std::vector<Iv>> perCell;
+    std::vector<int32_t> touched;
+    std::vector<int32_t> xy, cnt, ivs, states;
+    mrp_ll_result res;
+    void add(int32_t x, int32_t y, Iv iv) {
+      std::vector<Iv>& v = perCell[static_cast<size_t>(y) * dimx + x];
+      if (v.empty()) touched.push_back(y * dimx + x);
+      v.push_back(iv);
+    }
+  };
+  const size_t n = idx.size();
+  const int32_t cap = std::max(horizon, 64);
+  std::vector<Prio> st(n);
+  for (size_t q = 0; q < n; ++q) {
+    const mrp_hl_instance& in = instances[idx[q]];
+    int rc = mrp_ll_upload_map(ctx, in.dimx, in.dimy, in.n_obstacles, in.obstacles_xy, &st[q].mapId);
+    if (rc != MRP_LL_SUCCESS) {
+      out.err = std::string("mrp_ll_upload_map: ") + mrp_ll_last_error(ctx);
+      return;
+    }
+    sols[idx[q]].cost = 0;
+    sols[idx[q]].low_level_expanded = 0;
+    sols[idx[q]].n_planned = 0;
+    st[q].dimx = in.dimx;
+    st[q].perCell.assign(static_cast<size_t>(std::max(in.dimx, 0)) * std::max(in.dimy, 0), std::vector<Iv>());
+    st[q].states.resize(static_cast<size_t>(cap) * 3);
+  }
+  // at most one wavefront per instance, and about two per SIMD over all workers: the SIPP kernel waits on HBM for most
+  // of an expansion, more resident wavefronts only slow each other down (measured 64 / 128 / 256 per worker: 0.59 /
+  // 0.56 / 0.70 s for 4096 instances x 50 agents)
+  int32_t wgs = static_cast<int32_t>(std::min<size_t>(std::min<size_t>(std::max<size_t>(n, 16), slots), 128));
+  if (const char* e = std::getenv("MRP_HL_SIPP_WGS")) wgs = std::max(1, std::atoi(e));          // tuning knob
+  if (mrp_ll_session_begin_sipp(ctx, wgs) != MRP_LL_SUCCESS) {
+    out.err = std::string("mrp_ll_session_begin_sipp: ") + mrp_ll_last_error(ctx);
+    return;
+  }
+  // 1 published, 0 no free job slot (retry later), -1 error
+  auto submit = [&](size_t q) -> int {
+    Prio& p = st[q];
+    const mrp_hl_instance& in = instances[idx[q]];
+    p.xy.clear();
+    p.cnt.clear();
+    p.ivs.clear();
+    for (int32_t cell : p.touched) {  // sipp.setCollisionIntervals(location, intervals) for every location (:224-226)
+      const std::vector<Iv>& v = p.perCell[cell];
+      p.xy.push_back(cell % p.dimx);
+      p.xy.push_back(cell / p.dimx);
+      p.cnt.push_back(static_cast<int32_t>(v.size()));
+      for (const Iv& iv : v) {
+        p.ivs.push_back(iv.s);
+        p.ivs.push_back(iv.e);
+      }
+    }
+    mrp_ll_job j;
+    std::memset(&j, 0, sizeof(j));
+    j.map_id = p.mapId;
+    j.algo = MRP_LL_SIPP;
+    j.w = 1.0f;
+    j.start_x = in.starts_xy[2 * p.agent];
+    j.start_y = in.starts_xy[2 * p.agent + 1];
+    j.goal_x = in.goals_xy[2 * p.agent];
+    j.goal_y = in.goals_xy[2 * p.agent + 1];
+    j.max_expansions = -1;
+    j.n_collision_locations = static_cast<int32_t>(p.cnt.size());
+    j.collision_xy = p.xy.data();
+    j.collision_count = p.cnt.data();
+    j.collision_intervals = p.ivs.data();
+    std::memset(&p.res, 0, sizeof(p.res));
+    p.res.states_txy = p.states.data();
+    p.res.states_cap = cap;
+    int rc = mrp_ll_submit(ctx, 1, &j, &p.res, &p.ticket);
+    if (rc == MRP_LL_E_BUSY) return 0;
+    if (rc != MRP_LL_SUCCESS) {
+      out.err = std::string("mrp_ll_submit: ") + mrp_ll_last_error(ctx);
+      return -1;
+    }
+    out.searches += 1;
+    return 1;
+  };
+  std::vector<size_t> backlog, ticketOwner, doneOwners;
+  std::vector<int32_t> doneTickets(64);
+  for (size_t q = n; q-- > 0;)
+    if (instances[idx[q]].n_agents > 0) backlog.push_back(q);
+  size_t nInflight = 0;
+  bool failed = false;
+  int64_t maxAgents = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  uint64_t idleSpins = 0;
+  while (!failed && (nInflight != 0 || !backlog.empty())) {
+    bool progress = false;
+    while (!backlog.empty()) {
+      const size_t q = backlog.back();
+      int r = submit(q);
+      if (r < 0) failed = true;
+      if (r <= 0) break;
+      backlog.pop_back();
+      if (static_cast<size_t>(st[q].ticket) >= ticketOwner.size()) ticketOwner.resize(st[q].ticket + 1, 0);
+      ticketOwner[st[q].ticket] = q;
+      nInflight += 1;
+      progress = true;
+    }
+    if (failed) break;
+    int32_t nDone = 0;
+    if (mrp_ll_poll_any(ctx, doneTickets.data(), static_cast<int32_t>(doneTickets.size()), &nDone) != MRP_LL_SUCCESS) {
+      out.err = std::string("mrp_ll_poll_any: ") + mrp_ll_last_error(ctx);
+      failed = true;
+      break;
+    }
+    doneOwners.resize(nDone);
+    for (int32_t d = 0; d < nDone; ++d) doneOwners[d] = ticketOwner[doneTickets[d]];
+    for (int32_t d = 0; d < nDone && !failed; ++d) {
+      const size_t q = doneOwners[d];
+      Prio& p = st[q];
+      const mrp_hl_instance& in = instances[idx[q]];
+      mrp_hl_sipp_solution& so = sols[idx[q]];
+      const mrp_ll_result& r = p.res;
+      const int32_t a = p.agent;
+      progress = true;
+      nInflight -= 1;
+      so.low_level_expanded += r.expanded;
+      out.expansions += r.expanded;
+      if (r.status != MRP_LL_OK && r.status != MRP_LL_NO_SOLUTION) {
+        out.err = "prioritized SIPP: low-level capacity status " + std::to_string(r.status);
+        failed = true;
+        break;
+      }
+      const bool ok = r.status == MRP_LL_OK;
+      if (so.planned) so.planned[a] = ok ? 1 : 0;
+      if (so.n_states) so.n_states[a] = ok ? r.n_states : 0;
+      if (ok) {
+        so.n_planned += 1;
+        so.cost += r.cost;
+        const int32_t* S = r.states_txy;  // [t, x, y]
+        int32_t lx = S[1], ly = S[2], lt = S[0];  // collision intervals (:237-246): one per maximal stay on a cell
+        for (int32_t i = 1; i < r.n_states; ++i) {
+          if (S[3 * i + 1] != lx || S[3 * i + 2] != ly) {
+            p.add(lx, ly, Iv{lt, S[3 * i] - 1});
+            lx = S[3 * i + 1];
+            ly = S[3 * i + 2];
+            lt = S[3 * i];
+          }
+        }
+        const int32_t last = r.n_states - 1;
+        p.add(S[3 * last + 1], S[3 * last + 2], Iv{S[3 * last], INT32_MAX});
+        if (so.states_xyt)
+          for (int32_t i = 0; i < r.n_states && i < so.state_cap; ++i) {
+            int32_t* dst = so.states_xyt + (static_cast<size_t>(a) * so.state_cap + i) * 3;
+            dst[0] = S[3 * i + 1];
+            dst[1] = S[3 * i + 2];
+            dst[2] = S[3 * i];
+          }
+      }
+      p.agent += 1;
+      maxAgents = std::max<int64_t>(maxAgents, p.agent);
+      if (p.agent < in.n_agents) {
+        int rr = backlog.empty() ? submit(q) : 0;
+        if (rr < 0) {
+          failed = true;
+        } else if (rr == 1) {
+          if (static_cast<size_t>(p.ticket) >= ticketOwner.size()) ticketOwner.resize(p.ticket + 1, 0);
+          ticketOwner[p.ticket] = q;
+          nInflight += 1;
+        } else {
+          backlog.push_back(q);
+        }
+      }
+    }
+    if (progress) {
+      idleSpins = 0;
+    } else if ((++idleSpins & 0xFFFFF) == 0 &&
+               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 600.0) {
+      out.err = "prioritized SIPP session: no progress for too long";
+      failed = true;
+    }
+  }
+  if (mrp_ll_session_end(ctx) != MRP_LL_SUCCESS && out.err.empty())
+    out.err = std::string("mrp_ll_session_end: ") + mrp_ll_last_error(ctx);
+  out.rounds = maxAgents;  // longest chain of dependent searches
+}
+
 }  // namespace
 
 int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl_instance* instances,
@@ -891,11 +1078,17 @@ int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl
   std::vector<std::vector<int32_t>> idx(nThreads);
   for (int32_t k = 0; k < nInst; ++k) idx[k % nThreads].push_back(k);
   std::vector<GroupResult> gr(nThreads);
+  const bool batchMode = std::getenv("MRP_HL_SIPP_BATCH") != nullptr;  // the round-based schedule, for comparison
   auto t0 = std::chrono::steady_clock::now();
   {
     std::vector<std::thread> th;
     for (int32_t t = 0; t < nThreads; ++t)
-      th.emplace_back([&, t]() { runSippGroup(s->engines[t], horizon, instances, sols, idx[t], gr[t]); });
+      th.emplace_back([&, t]() {
+        if (batchMode)
+          runSippGroup(s->engines[t], horizon, instances, sols, idx[t], gr[t]);
+        else
+          runSippGroupSession(s->engines[t], horizon, s->llOpt.slots, instances, sols, idx[t], gr[t]);
+      });
     for (auto& x : th) x.join();
   }
   mrp_hl_batch_stats bs;

@@ -1107,8 +1107,35 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchPara
   DBG(P, 4, 1);
 }
 
-// SIPP batches (MRP_LL_SIPP jobs only) run in their own kernel so that the CBS/ECBS kernels' register allocation is not
-// widened by a path they never take.  Same queue discipline as mrp_ll_search_kernel.
+// One SIPP job whose descriptor is at `jobSrc` (host memory): result + raw A* states back to host memory.
+DEVI void processSippJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* resDst, uint16_t* pathDst,
+                         uint8_t* arenaSlot, DevJob& jobS, DevResult& resS) {
+  const uint32_t lane = threadIdx.x;
+  __syncthreads();
+  {
+    const uint32_t* src = (const uint32_t*)jobSrc;
+    if (lane < sizeof(DevJob) / 4) ((uint32_t*)&jobS)[lane] = src[lane];
+  }
+  __syncthreads();
+  DevResult res;
+  res.status = ST_BAD; res.cost = 0; res.fmin = 0; res.n_states = 0; res.expanded = 0; res.nodes_created = 0;
+  res.tier = 1;
+  for (int q = 0; q < 8; ++q) res.prof[q] = 0;
+  uint16_t* outPath = (uint16_t*)(arenaSlot + P.arena_scratch_off);
+  if (rfl(jobS.algo) == 2) runSipp(P, jobS, arenaSlot, res, outPath);  // anything else stays ST_BAD
+  __syncthreads();
+  resS = res;
+  __syncthreads();
+  if (lane < sizeof(DevResult) / 4) ((uint32_t*)resDst)[lane] = ((const uint32_t*)&resS)[lane];
+  if (res.status == ST_OK) {  // one u32 (cell | g << 16) per raw A* state
+    const uint32_t* src = (const uint32_t*)outPath;
+    uint32_t* dst = (uint32_t*)pathDst;
+    for (uint32_t i = lane; i < (uint32_t)res.n_states; i += 64) dst[i] = src[i];
+  }
+}
+
+// SIPP batches (MRP_LL_SIPP jobs only) run in their own kernels so that the CBS/ECBS kernels' register allocation is
+// not widened by a path they never take.  Same queue discipline as mrp_ll_search_kernel.
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams P) {
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
@@ -1118,27 +1145,7 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams
     uint32_t j = atomicAdd(P.queue_head, lane == 0 ? 1u : 0u);
     j = rfl(j) - P.queue_base;
     if (j >= P.n_jobs) break;
-    __syncthreads();
-    {
-      const uint32_t* src = (const uint32_t*)(P.jobs + j);
-      if (lane < sizeof(DevJob) / 4) ((uint32_t*)&jobS)[lane] = src[lane];
-    }
-    __syncthreads();
-    DevResult res;
-    res.status = ST_BAD; res.cost = 0; res.fmin = 0; res.n_states = 0; res.expanded = 0; res.nodes_created = 0;
-    res.tier = 1;
-    for (int q = 0; q < 8; ++q) res.prof[q] = 0;
-    uint16_t* outPath = (uint16_t*)(arenaSlot + P.arena_scratch_off);
-    runSipp(P, jobS, arenaSlot, res, outPath);
-    __syncthreads();
-    resS = res;
-    __syncthreads();
-    if (lane < sizeof(DevResult) / 4) ((uint32_t*)(P.results + j))[lane] = ((const uint32_t*)&resS)[lane];
-    if (res.status == ST_OK) {  // one u32 (cell | g << 16) per raw A* state
-      const uint32_t* src = (const uint32_t*)outPath;
-      uint32_t* dst = (uint32_t*)(P.out_paths + (size_t)j * P.out_stride);
-      for (uint32_t i = lane; i < (uint32_t)res.n_states; i += 64) dst[i] = src[i];
-    }
+    processSippJob(P, P.jobs + j, P.results + j, P.out_paths + (size_t)j * P.out_stride, arenaSlot, jobS, resS);
   }
 }
 
@@ -1152,10 +1159,8 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams
 // The finished job's slot gets ring_done[slot] = (ticket + 1) & 0x3FFFFFFF | 1 << 30 | lane << 31 (never 0) and an
 // entry in the completion queue.
 // Exit conditions every wave reaches: *ring_stop != 0, or no job for ring_idle_limit_s seconds.
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(LaunchParams P) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ DevJob jobS;
-  __shared__ DevResult resS;
+template <bool SIPP>
+DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevResult& resS) {
   const uint32_t lane = threadIdx.x;
   uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
   const uint64_t idleLimit = (uint64_t)P.ring_idle_limit_s * 100000000ull;  // s_memrealtime ticks at 100 MHz
@@ -1235,8 +1240,11 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
     const uint64_t t1c = __builtin_amdgcn_s_memrealtime();
     idleTicks += t1c - t0;
     if (stop) break;
-    processJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, smem, arenaSlot, jobS,
-               resS);
+    if (SIPP)
+      processSippJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, arenaSlot, jobS, resS);
+    else
+      processJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, smem, arenaSlot, jobS,
+                 resS);
     __threadfence_system();
     __hip_atomic_store(P.ring_done + slot, doneVal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring
@@ -1249,6 +1257,20 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(Launch
   atomicAdd(P.sess_ticks + 0, lane == 0 ? (unsigned long long)busyTicks : 0ull);
   atomicAdd(P.sess_ticks + 1, lane == 0 ? (unsigned long long)idleTicks : 0ull);
   atomicAdd(P.sess_ticks + 2, (lane == 0 && busyTicks != 0) ? 1ull : 0ull);  // workgroups that ran at least one job
+}
+
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(LaunchParams P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ DevJob jobS;
+  __shared__ DevResult resS;
+  residentLoop<false>(P, smem, jobS, resS);
+}
+
+// The same resident loop for SIPP sessions (jobs of algo MRP_LL_SIPP only; no LDS tier).
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_persistent_kernel(LaunchParams P) {
+  __shared__ DevJob jobS;
+  __shared__ DevResult resS;
+  residentLoop<true>(P, nullptr, jobS, resS);
 }
 
 }  // namespace mrp
@@ -1272,6 +1294,11 @@ extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, u
 
 extern "C" hipError_t mrp_ll_launch_sipp(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream) {
   hipLaunchKernelGGL(mrp::mrp_ll_sipp_kernel, dim3(grid), dim3(64), 0, stream, *P);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mrp_ll_launch_sipp_persistent(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(mrp::mrp_ll_sipp_persistent_kernel, dim3(grid), dim3(64), 0, stream, *P);
   return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@
 extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes);
 extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t mrp_ll_launch_sipp(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream);
+extern "C" hipError_t mrp_ll_launch_sipp_persistent(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t mrp_ll_launch_persistent(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes,
                                                hipStream_t stream);
 
@@ -132,6 +133,13 @@ struct Ring {
   bool active = false;
   uint32_t grid = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // SIPP sessions (mrp_ll_session_begin_sipp): the jobs' safe-interval tables are far larger than a slot's constraint
+  // area, so they get their own pinned buffer, and only the first kSippSlots job slots are used
+  static constexpr uint32_t kSippSlots = 512;
+  bool sipp = false;
+  uint32_t* sippCons = nullptr;
+  uint32_t sippSlotWords = 0;      // capacity per slot the buffer was allocated with
+  std::vector<int32_t> slotDimx;   // SIPP: grid width of the slot's job (cell -> x, y when unpacking)
 };
 struct SessTicket {
   bool used = false;
@@ -706,6 +714,7 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
   if (ctx->ring.ev0) (void)hipEventDestroy(ctx->ring.ev0);
   if (ctx->ring.ev1) (void)hipEventDestroy(ctx->ring.ev1);
   if (ctx->ring.block) (void)hipHostFree(ctx->ring.block);
+  if (ctx->ring.sippCons) (void)hipHostFree(ctx->ring.sippCons);
   if (ctx->ring.compCountDev) (void)hipFree(ctx->ring.compCountDev);
   if (ctx->ring.ticksDev) (void)hipFree(ctx->ring.ticksDev);
   delete static_cast<SippScratch*>(ctx->sippScratch);
@@ -795,7 +804,7 @@ int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t ldsNodes, int32_t ldsRows, i
 }
 
 // ---- session mode ---------------------------------------------------------------------------------------------
-int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
+static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp) {
   if (!ctx) return MRP_LL_E_INVALID;
   Ring& g = ctx->ring;
   if (g.active) return MRP_LL_E_INVALID;
@@ -852,7 +861,21 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   g.tkSlot.assign(Ring::kTickets, 0xFFFFFFFFu);
   g.tkSeq.assign(Ring::kTickets, 0);
   g.freeSlots.clear();
-  for (uint32_t sl = Ring::kSlots; sl-- > 0;) g.freeSlots.push_back(sl);
+  g.sipp = sipp;
+  for (uint32_t sl = sipp ? Ring::kSippSlots : Ring::kSlots; sl-- > 0;) g.freeSlots.push_back(sl);
+  if (sipp) {
+    // table of a job: cellIdx[cells] + specFirst[K + 1] + 2 words per safe interval; 8 words per cell cover about three
+    // intervals on every cell
+    const uint32_t want = std::max<uint32_t>(8192u, ctx->maxWpr * 32u * 8u);
+    if (want > g.sippSlotWords) {
+      if (g.sippCons) (void)hipHostFree(g.sippCons);
+      g.sippCons = nullptr;
+      HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&g.sippCons), static_cast<size_t>(Ring::kSippSlots) * want * 4,
+                                hipHostMallocMapped | hipHostMallocCoherent));
+      g.sippSlotWords = want;
+    }
+    g.slotDimx.assign(R, 0);
+  }
   ctx->sess.clear();
   ctx->sessFree.clear();
   auto devPtr = [&](void* hostPtr) {
@@ -865,7 +888,7 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   P.jobs = static_cast<const DevJob*>(devPtr(g.jobs));
   P.results = static_cast<DevResult*>(devPtr(g.results));
   P.out_paths = static_cast<uint16_t*>(devPtr(g.outPaths));
-  P.cons = static_cast<const uint32_t*>(devPtr(g.cons));
+  P.cons = static_cast<const uint32_t*>(devPtr(sipp ? g.sippCons : g.cons));
   P.paths = static_cast<const uint16_t*>(devPtr(g.paths));
   P.ring_state = static_cast<uint32_t*>(devPtr(g.state));
   P.ring_done = static_cast<uint32_t*>(devPtr(g.done));
@@ -895,12 +918,18 @@ int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) {
   HIPCHK(ctx, hipMemsetAsync(g.ticksDev, 0, 32, t.stream));
   t.queueBase = 0;
   HIPCHK(ctx, hipEventRecord(g.ev0, t.stream));
-  HIPCHK(ctx, mrp_ll_launch_persistent(&P, g.grid, ldsBytes, t.stream));
+  if (sipp)
+    HIPCHK(ctx, mrp_ll_launch_sipp_persistent(&P, g.grid, t.stream));
+  else
+    HIPCHK(ctx, mrp_ll_launch_persistent(&P, g.grid, ldsBytes, t.stream));
   HIPCHK(ctx, hipEventRecord(g.ev1, t.stream));
   g.active = true;
   ctx->stats.launches += 1;
   return MRP_LL_SUCCESS;
 }
+
+int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) { return sessionBegin(ctx, workgroups, false); }
+int mrp_ll_session_begin_sipp(mrp_ll_ctx* ctx, int32_t workgroups) { return sessionBegin(ctx, workgroups, true); }
 
 int mrp_ll_session_end(mrp_ll_ctx* ctx) {
   if (!ctx) return MRP_LL_E_INVALID;
@@ -938,7 +967,7 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
     return MRP_LL_E_INVALID;
   }
   // consume finished tickets first; the bulk lane leaves kReserve1 slots to the priority lane
-  if (g.freeSlots.size() < static_cast<size_t>(nJobs) + (lane ? 0u : Ring::kReserve1)) return MRP_LL_E_BUSY;
+  if (g.freeSlots.size() < static_cast<size_t>(nJobs) + ((lane || g.sipp) ? 0u : Ring::kReserve1)) return MRP_LL_E_BUSY;
   for (int i = 0; i < nJobs; ++i) {
     // a ticket entry may be overwritten once the job published there a whole ring ago has been consumed
     const uint32_t qi = qBase + static_cast<uint32_t>((g.head[lane] + i) % Q);
@@ -974,8 +1003,15 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
     PathSinkSlot ps{g.paths + static_cast<size_t>(slot) * Ring::kSlotPathHalfs, slot * Ring::kSlotPathHalfs,
                     Ring::kSlotPathHalfs};
     DevJob d;
-    if (jobs[i].algo == MRP_LL_SIPP || !packJob(ctx, jobs[i], cs, ps, d)) {  // SIPP is batch-mode only; also:
-      // constraint list / path table larger than a ring slot
+    bool ok;
+    if (g.sipp) {  // a SIPP session takes SIPP jobs only, an A* / A*-epsilon session none
+      ConsSinkSlot csS{g.sippCons + static_cast<size_t>(slot) * g.sippSlotWords, slot * g.sippSlotWords, g.sippSlotWords};
+      ok = jobs[i].algo == MRP_LL_SIPP && packJob(ctx, jobs[i], csS, ps, d);
+      if (ok) g.slotDimx[slot] = ctx->maps[jobs[i].map_id].dimx;
+    } else {
+      ok = jobs[i].algo != MRP_LL_SIPP && packJob(ctx, jobs[i], cs, ps, d);
+    }
+    if (!ok) {  // wrong kind of job for this session, or constraint list / table larger than a ring slot
       trivialRejectedJob(ctx, d);
       st.state[i] = 2;
     }
@@ -1019,7 +1055,7 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
     const uint32_t slot = st.slots[i];
     if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != st.seq[i]) continue;
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
-                 st.res[i]);
+                 st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0);
     st.state[i] = 1;
     st.remaining -= 1;
     g.busy[slot] = 0;
@@ -1051,7 +1087,7 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
     SessTicket& st = ctx->sess[g.slotTicket[slot]];
     const int32_t i = g.slotJob[slot];
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
-                 st.res[i]);
+                 st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0);
     st.state[i] = 1;
     st.remaining -= 1;
     g.busy[slot] = 0;

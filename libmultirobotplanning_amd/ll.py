@@ -58,7 +58,7 @@ class mrp_ll_stats(ctypes.Structure):
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
            "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version",
            "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any", "mrp_ll_submit_lane", "mrp_ll_sync_maps",
-           "mrp_ll_configure_tiers"]
+           "mrp_ll_configure_tiers", "mrp_ll_session_begin_sipp"]
 
 _lib = None
 

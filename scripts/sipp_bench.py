@@ -16,8 +16,9 @@ for rep in range(2):
     s.ll_stats(reset=True)
     res, st = s.prioritized_sipp(insts)
     ls = s.ll_stats()
-    print("   engine totals over %d threads: launches %d, kernel %.1f ms, pack %.1f ms, unpack %.1f ms" % (
-        threads, ls["launches"], ls["kernel_ms"], ls["pack_ms"], ls["unpack_ms"]), flush=True)
+    print("   engine totals over %d threads: launches %d, kernel %.1f ms, pack %.1f ms, unpack %.1f ms; resident workgroups busy %.1f s, waiting %.1f s" % (
+        threads, ls["launches"], ls["kernel_ms"], ls["pack_ms"], ls["unpack_ms"], ls["session_busy_ms"] / 1e3,
+        ls["session_idle_ms"] / 1e3), flush=True)
     print("rep %d: %d instances x %d agents: wall %.3f s, %.3e exp/s, %.1f inst/s, rounds %d searches %d planned-all %d" % (
         rep, n, agents, st["wall_seconds"], st["ll_expansions"] / st["wall_seconds"], n / st["wall_seconds"], st["rounds"],
         st["ll_searches"], st["solved"]), flush=True)

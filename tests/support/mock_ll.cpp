@@ -112,6 +112,7 @@ int mrp_ll_configure_tiers(mrp_ll_ctx*, int32_t, int32_t, int32_t, int32_t* occ)
   return MRP_LL_SUCCESS;
 }
 int mrp_ll_session_begin(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
+int mrp_ll_session_begin_sipp(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
 int mrp_ll_session_end(mrp_ll_ctx*) { return MRP_LL_SUCCESS; }
 int mrp_ll_poll(mrp_ll_ctx*, int32_t, int32_t* done) {
   *done = 1;  // the mock runs every job synchronously inside mrp_ll_submit

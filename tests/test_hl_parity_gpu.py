@@ -148,6 +148,16 @@ def test_bench_scale_properties_and_determinism(solver):
     res_a, st_a = solver.solve(insts, algo=hl.ECBS, w=1.3, max_ll_expansions=50000)
     res_b, st_b = solver.solve(insts, algo=hl.ECBS, w=1.3, max_ll_expansions=50000, n_threads=3)
     assert st_a["ll_expansions"] == st_b["ll_expansions"]
+    # ... and so do the fixed interleaved split of the instances over the workers (instead of the shared pool) and a
+    # tight admission limit (instances wait in the pool; the pool is refilled as they finish)
+    import os
+    for knob, val in (("MRP_HL_STATIC_SPLIT", "1"), ("MRP_HL_ACTIVE_LIMIT", "37")):
+        os.environ[knob] = val
+        try:
+            res_c, st_c = solver.solve(insts[:1024], algo=hl.ECBS, w=1.3, max_ll_expansions=50000)
+        finally:
+            del os.environ[knob]
+        assert res_c == res_a[:1024], knob
     n_solved = 0
     for inst, a, b in zip(insts, res_a, res_b):
         assert a == b
