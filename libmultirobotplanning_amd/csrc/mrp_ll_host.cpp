@@ -959,7 +959,7 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
 static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results,
                          int32_t* ticketOut) {
   Ring& g = ctx->ring;
-  const uint32_t nSlotsLane = lane ? Ring::kSlots : Ring::kSlots - Ring::kReserve1;
+  const uint32_t nSlotsLane = g.sipp ? Ring::kSippSlots : (lane ? Ring::kSlots : Ring::kSlots - Ring::kReserve1);
   const uint32_t Q = g.Q[lane];
   const uint32_t qBase = lane ? g.Q[0] : 0;
   if (nJobs > static_cast<int32_t>(nSlotsLane)) {

@@ -251,6 +251,10 @@ class LowLevelEngine:
         """Keep `workgroups` wavefronts resident and feed them through the host job ring (see mrp_ll.h)."""
         self._check(self._lib.mrp_ll_session_begin(self._h, workgroups), "mrp_ll_session_begin")
 
+    def session_begin_sipp(self, workgroups: int = 0):
+        """A session for MRP_LL_SIPP jobs (resident SIPP kernel); other jobs come back as BAD_JOB."""
+        self._check(self._lib.mrp_ll_session_begin_sipp(self._h, workgroups), "mrp_ll_session_begin_sipp")
+
     def session_end(self):
         self._check(self._lib.mrp_ll_session_end(self._h), "mrp_ll_session_end")
 

@@ -312,6 +312,22 @@ def test_sipp_reference_case_and_random_jobs(engine, oracle_mod, ref_tests):
             assert r.expanded == o_exp
             assert r.cost == o_states[-1][2]
     assert n_ok > 60
+    # the same jobs through a SIPP session (resident SIPP kernel fed through the job ring): identical results; a session
+    # serves one kind of job, the other kind is rejected, not guessed
+    engine.session_begin_sipp(32)
+    try:
+        res_s = engine.search_batch(jobs + [ll.LLJob(map_id=mid2, algo=ll.ASTAR, start=free[0], goal=free[1])])
+    finally:
+        engine.session_end()
+    assert res_s[-1].status == ll.BAD_JOB
+    for a, b in zip(res, res_s[:-1]):
+        assert (a.status, a.cost, a.expanded, a.states, a.actions, a.action_costs) == (
+            b.status, b.cost, b.expanded, b.states, b.actions, b.action_costs)
+    engine.session_begin(32)
+    try:
+        assert engine.search_batch(jobs[:3])[0].status == ll.BAD_JOB
+    finally:
+        engine.session_end()
 
 
 def test_stats_report_kernel_time(engine):
