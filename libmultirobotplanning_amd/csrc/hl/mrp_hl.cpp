@@ -652,12 +652,8 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   int32_t occupancy = 4;
   if (s->llOpt.lds_nodes == 0 && opt.mode != 1) {  // the caller did not choose a geometry: pick one for this batch
     const int32_t pathBytes = opt.algo == MRP_HL_ECBS ? std::min(16384, std::max(2048, agentsPad * 2 * 64)) : 32;
-    // a small batch ends with its longest searches, and those run faster with the SIMD to themselves: then the roomier
-    // tier (fewer overflows into the HBM tier, about one wave per SIMD) is the better trade
-    const bool small = nInst < 32768;
     for (int32_t t = 0; t < nThreads; ++t)
-      if (mrp_ll_configure_tiers(s->engines[t], small ? 512 : 400, small ? 64 : 48, small ? std::max(4096, pathBytes) : pathBytes,
-                                 &occupancy) != MRP_LL_SUCCESS) {
+      if (mrp_ll_configure_tiers(s->engines[t], 400, 48, pathBytes, &occupancy) != MRP_LL_SUCCESS) {
         s->err = std::string("mrp_ll_configure_tiers: ") + mrp_ll_last_error(s->engines[t]);
         return MRP_LL_E_DEVICE;
       }
