@@ -977,41 +977,113 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
       break;
     }
     bool fail = false;
-    for (uint32_t m = 0; m < 4 && !fail; ++m) {  // Up, Down, Left, Right
-      const uint32_t nx = cx + (m == 3) - (m == 2), ny = cy + (m == 0) - (m == 1);
-      if (nx >= dimx || ny >= dimy) continue;
-      const uint32_t nc = ny * dimx + nx;
-      if ((rfl(obst[nc >> 5]) >> (nc & 31)) & 1u) continue;
-      const uint32_t nk = rfl(cellIdx[nc]);
-      uint32_t first = 0, cnt = 1;
-      if (nk) {
-        first = rfl(specFirst[nk - 1]);
-        cnt = rfl(specFirst[nk]) - first;
+    // ---- neighbours.  Lanes 0..3 probe the four motions Up, Down, Left, Right at once (bounds, obstacle bit, the
+    // cell's safe-interval list); when no list is longer than 16 the intervals of all four cells are then evaluated on
+    // lanes 16*m + i together with their open/closed status — three dependent global round trips per expansion
+    // instead of three to five per motion.  Candidates are consumed in lane order, which IS the reference's order
+    // (motion-major, interval-minor, sipp.hpp:205-222).
+    uint32_t c4[4], f4[4], nc4[4], nk4[4], h4[4];
+    {
+      const uint32_t nxL = cx + (lane == 3) - (lane == 2), nyL = cy + (lane == 0) - (lane == 1);
+      const bool inbL = lane < 4 && nxL < dimx && nyL < dimy;
+      const uint32_t ncL = inbL ? nyL * dimx + nxL : 0;
+      uint32_t obstW = 0xFFFFFFFFu, nkL = 0;
+      if (inbL) {
+        obstW = obst[ncL >> 5];
+        nkL = cellIdx[ncL];
       }
-      const uint32_t hN = (nx > gx ? nx - gx : gx - nx) + (ny > gy ? ny - gy : gy - ny);
-      for (uint32_t base = 0; base < cnt && !fail; base += 64) {
-        const uint32_t i = base + lane;
-        int32_t siS = 0, siE = kIntMax;
-        if (nk && i < cnt) {
-          siS = ivals[2 * (first + i)];
-          siE = ivals[2 * (first + i) + 1];
+      const bool validL = inbL && !((obstW >> (ncL & 31)) & 1u);
+      uint32_t firstL = 0, cntL = validL ? 1u : 0u;
+      if (validL && nkL) {
+        firstL = specFirst[nkL - 1];
+        cntL = specFirst[nkL] - firstL;
+      }
+      const uint32_t hL = (nxL > gx ? nxL - gx : gx - nxL) + (nyL > gy ? nyL - gy : gy - nyL);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        c4[m] = __builtin_amdgcn_readlane(cntL, m);
+        f4[m] = __builtin_amdgcn_readlane(firstL, m);
+        nc4[m] = __builtin_amdgcn_readlane(ncL, m);
+        nk4[m] = __builtin_amdgcn_readlane(nkL, m);
+        h4[m] = __builtin_amdgcn_readlane(hL, m);
+      }
+    }
+    const uint32_t cMax = max(max(c4[0], c4[1]), max(c4[2], c4[3]));
+    if (cMax <= 16) {
+      const uint32_t mm = lane >> 4, i = lane & 15;
+      const uint32_t cntM = mm == 0 ? c4[0] : mm == 1 ? c4[1] : mm == 2 ? c4[2] : c4[3];
+      const uint32_t firstM = mm == 0 ? f4[0] : mm == 1 ? f4[1] : mm == 2 ? f4[2] : f4[3];
+      const uint32_t ncM = mm == 0 ? nc4[0] : mm == 1 ? nc4[1] : mm == 2 ? nc4[2] : nc4[3];
+      const uint32_t nkM = mm == 0 ? nk4[0] : mm == 1 ? nk4[1] : mm == 2 ? nk4[2] : nk4[3];
+      const uint32_t hM = mm == 0 ? h4[0] : mm == 1 ? h4[1] : mm == 2 ? h4[2] : h4[3];
+      const bool act = i < cntM;
+      int32_t siS = 0, siE = kIntMax;
+      const uint32_t sidL = nkM ? cells + firstM + i : ncM;
+      uint32_t stL = 0;
+      if (act) {
+        if (nkM) {
+          siS = ivals[2 * (firstM + i)];
+          siE = ivals[2 * (firstM + i) + 1];
         }
-        // sipp.hpp:209: skip if si.start - m_time > end_t || si.end < start_t
-        const bool cand = (i < cnt) && !((int64_t)siS - 1 > (int64_t)endT || siE < (int32_t)startT);
-        const uint32_t tArr = (uint32_t)(siS > (int32_t)startT ? siS : (int32_t)startT);
-        uint64_t mask = ballot64(cand);
-        while (mask) {
+        stL = g.bits[sidL];
+      }
+      // sipp.hpp:209: skip if si.start - m_time > end_t || si.end < start_t
+      const bool cand = act && !((int64_t)siS - 1 > (int64_t)endT || siE < (int32_t)startT);
+      const uint32_t tArr = (uint32_t)(siS > (int32_t)startT ? siS : (int32_t)startT);
+      const uint64_t candMask = ballot64(cand);
+      const uint64_t lateMask = ballot64(cand && tArr > kGMask);
+      const uint64_t openMask = ballot64(cand && stL != 0 && !(stL & kStClosed));   // already in the open list
+      const uint64_t newMask = ballot64(cand && stL == 0);
+      const uint32_t nNew = (uint32_t)__popcll(newMask);
+      if (lateMask) {
+        res.status = ST_CAP_HORIZON;
+        fail = true;
+      } else if (openMask == 0 && nNew <= 5) {
+        // the usual case — nothing to re-key: all pushes of the expansion in one round trip (PushChains)
+        if (nNodes + nNew > g.capNodes) {
+          res.status = ST_CAP_NODES;
+          fail = true;
+        } else if (nNew) {
+          uint64_t e[5];
+          uint64_t mk = newMask;
+#pragma unroll
+          for (uint32_t k = 0; k < 5; ++k) {
+            e[k] = 0;
+            if (k < nNew) {
+              const uint32_t l = (uint32_t)__builtin_ctzll(mk);
+              mk &= mk - 1;
+              const uint32_t t = __builtin_amdgcn_readlane(tArr, l);
+              const uint32_t sid = __builtin_amdgcn_readlane(sidL, l);
+              const uint32_t nc = __builtin_amdgcn_readlane(ncM, l);
+              const uint32_t hN = __builtin_amdgcn_readlane(hM, l);
+              const uint32_t nid = nNodes + k;
+              u32x4 nn;
+              nn.x = nc | ((l & 15u) << 16);
+              nn.y = curId;
+              nn.z = t;
+              nn.w = 0;
+              g.nodes[nid] = nn;
+              g.bits[sid] = nid + 1;
+              e[k] = packEntry(0, t + hN, t, nid);
+            }
+          }
+          const uint32_t pm = (1u << nNew) - 1u;
+          PushChains<1> pc;
+          pc.load(g.open, nOpen, pm);
+          pc.template resolve<0, true>(g, g.open, nOpen, pm, e);
+          nNodes += nNew;
+          nOpen += nNew;
+        }
+      } else {
+        uint64_t mask = candMask;
+        while (mask && !fail) {
           const uint32_t l = (uint32_t)__builtin_ctzll(mask);
           mask &= mask - 1;
-          const uint32_t ii = base + l;
           const uint32_t t = __builtin_amdgcn_readlane(tArr, l);
-          if (t > kGMask) {
-            res.status = ST_CAP_HORIZON;
-            fail = true;
-            break;
-          }
-          const uint32_t sid = nk ? cells + first + ii : nc;
-          const uint32_t st = rfl(g.bits[sid]);
+          const uint32_t sid = __builtin_amdgcn_readlane(sidL, l);
+          const uint32_t nc = __builtin_amdgcn_readlane(ncM, l);
+          const uint32_t hN = __builtin_amdgcn_readlane(hM, l);
+          const uint32_t st = __builtin_amdgcn_readlane(stL, l);
           if (st & kStClosed) continue;                   // closedSet.find (a_star.hpp:117)
           if (st == 0) {                                   // new state (a_star.hpp:120-129)
             if (nNodes >= g.capNodes) {
@@ -1021,7 +1093,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
             }
             const uint32_t nid = nNodes++;
             u32x4 nn;
-            nn.x = nc | (ii << 16);
+            nn.x = nc | ((l & 15u) << 16);
             nn.y = curId;
             nn.z = t;
             nn.w = 0;
@@ -1038,6 +1110,73 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
             nn.z = t;
             g.nodes[nid] = nn;                             // cameFrom update + new g
             siftUp<1, 0, true>(g, g.open, rfl(on.w), packEntry(0, t + hN, t, nid));  // increase(handle)
+          }
+        }
+      }
+    } else {
+      // a cell with more than 16 safe intervals: one motion at a time, 64 intervals per pass
+      for (uint32_t m = 0; m < 4 && !fail; ++m) {  // Up, Down, Left, Right
+        const uint32_t nx = cx + (m == 3) - (m == 2), ny = cy + (m == 0) - (m == 1);
+        if (nx >= dimx || ny >= dimy) continue;
+        const uint32_t nc = ny * dimx + nx;
+        if ((rfl(obst[nc >> 5]) >> (nc & 31)) & 1u) continue;
+        const uint32_t nk = rfl(cellIdx[nc]);
+        uint32_t first = 0, cnt = 1;
+        if (nk) {
+          first = rfl(specFirst[nk - 1]);
+          cnt = rfl(specFirst[nk]) - first;
+        }
+        const uint32_t hN = (nx > gx ? nx - gx : gx - nx) + (ny > gy ? ny - gy : gy - ny);
+        for (uint32_t base = 0; base < cnt && !fail; base += 64) {
+          const uint32_t i = base + lane;
+          int32_t siS = 0, siE = kIntMax;
+          if (nk && i < cnt) {
+            siS = ivals[2 * (first + i)];
+            siE = ivals[2 * (first + i) + 1];
+          }
+          // sipp.hpp:209: skip if si.start - m_time > end_t || si.end < start_t
+          const bool cand = (i < cnt) && !((int64_t)siS - 1 > (int64_t)endT || siE < (int32_t)startT);
+          const uint32_t tArr = (uint32_t)(siS > (int32_t)startT ? siS : (int32_t)startT);
+          uint64_t mask = ballot64(cand);
+          while (mask) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1;
+            const uint32_t ii = base + l;
+            const uint32_t t = __builtin_amdgcn_readlane(tArr, l);
+            if (t > kGMask) {
+              res.status = ST_CAP_HORIZON;
+              fail = true;
+              break;
+            }
+            const uint32_t sid = nk ? cells + first + ii : nc;
+            const uint32_t st = rfl(g.bits[sid]);
+            if (st & kStClosed) continue;                   // closedSet.find (a_star.hpp:117)
+            if (st == 0) {                                   // new state (a_star.hpp:120-129)
+              if (nNodes >= g.capNodes) {
+                res.status = ST_CAP_NODES;
+                fail = true;
+                break;
+              }
+              const uint32_t nid = nNodes++;
+              u32x4 nn;
+              nn.x = nc | (ii << 16);
+              nn.y = curId;
+              nn.z = t;
+              nn.w = 0;
+              g.nodes[nid] = nn;
+              g.bits[sid] = nid + 1;
+              siftUp<1, 0, true>(g, g.open, nOpen, packEntry(0, t + hN, t, nid));
+              nOpen += 1;
+            } else {                                         // already in open (a_star.hpp:130-146)
+              const uint32_t nid = st - 1;
+              const u32x4 on = g.nodes[nid];
+              if (t >= rfl(on.z)) continue;
+              u32x4 nn = on;
+              nn.y = curId;
+              nn.z = t;
+              g.nodes[nid] = nn;                             // cameFrom update + new g
+              siftUp<1, 0, true>(g, g.open, rfl(on.w), packEntry(0, t + hN, t, nid));  // increase(handle)
+            }
           }
         }
       }
