@@ -198,7 +198,8 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
 void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance* instIn, mrp_hl_solution* sols,
                      const std::vector<int32_t>& idx, const std::vector<int32_t>& mapIds, int32_t horizon,
                      int32_t workgroups, GroupResult& out, std::atomic<int32_t>* shared = nullptr, int32_t nTotal = 0,
-                     int32_t mapBase = 0) {
+                     int32_t mapBase = 0, int32_t nWorkersIn = 1) {
+  const size_t nWorkers = static_cast<size_t>(std::max(nWorkersIn, 1));
   const size_t n = shared ? static_cast<size_t>(nTotal) : idx.size();
   struct Live {
     std::unique_ptr<Instance> inst;
@@ -296,7 +297,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   // bench shape: same step time as "everything at once"), and with a shared pool it is what lets the workers balance.
   size_t nextStatic = 0;
   bool exhausted = false;
-  size_t activeLimit = shared ? 1536 : n;
+  // shared pool: no worker may hold more than its fair share at a time, or a small batch is drained by the first few
+  size_t activeLimit = shared ? std::min<size_t>(1536, (static_cast<size_t>(nTotal) + nWorkers - 1) / nWorkers) : n;
   if (const char* e = std::getenv("MRP_HL_ACTIVE_LIMIT")) activeLimit = std::max(1, std::atoi(e));
   auto admit = [&]() -> bool {  // next instance of the pool, false when it is empty
     int32_t k, mid;
@@ -673,7 +675,7 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
           runGroup(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, gr[t]);
         else if (sharedPool)
           runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, gr[t],
-                          &nextInstance, nInst, pre->mapBase[t]);
+                          &nextInstance, nInst, pre->mapBase[t], nThreads);
         else
           runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, gr[t]);
       });
