@@ -298,7 +298,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   size_t nextStatic = 0;
   bool exhausted = false;
   // shared pool: no worker may hold more than its fair share at a time, or a small batch is drained by the first few
-  size_t activeLimit = shared ? std::min<size_t>(1536, (static_cast<size_t>(nTotal) + nWorkers - 1) / nWorkers) : n;
+  size_t activeLimit =
+      shared ? std::max<size_t>(1, std::min<size_t>(1536, (static_cast<size_t>(nTotal) + nWorkers - 1) / nWorkers)) : n;
   if (const char* e = std::getenv("MRP_HL_ACTIVE_LIMIT")) activeLimit = std::max(1, std::atoi(e));
   auto admit = [&]() -> bool {  // next instance of the pool, false when it is empty
     int32_t k, mid;
