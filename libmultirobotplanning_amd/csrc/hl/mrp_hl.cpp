@@ -523,7 +523,11 @@ int mrp_hl_solver_create(int32_t device, int32_t nThreads, const mrp_ll_options*
   std::memset(&s->llOpt, 0, sizeof(s->llOpt));
   if (llOpt) s->llOpt = *llOpt;
   s->llOpt.device = device;
-  s->llOpt.n_tickets = std::max(s->llOpt.n_tickets, 2);  // the prioritized-SIPP driver keeps two batches in flight
+  // One batch in flight per engine.  A second ticket (MRP_HL_TICKETS=2: the round-based prioritized-SIPP schedule then
+  // pipelines two half-batches) means a second arena per engine, and with it allocated the resident A*-epsilon searches
+  // ran 7 % slower (busy workgroup time 731 s -> 788 s per 65 536 instances, same kernel) — so it is opt-in.
+  if (s->llOpt.n_tickets <= 0) s->llOpt.n_tickets = 1;
+  if (const char* e = std::getenv("MRP_HL_TICKETS")) s->llOpt.n_tickets = std::max(1, std::atoi(e));
   if (s->llOpt.slots <= 0) s->llOpt.slots = 512;
   if (s->llOpt.arena_nodes <= 0) s->llOpt.arena_nodes = 65536;
   for (int32_t t = 0; t < nThreads; ++t) {
@@ -708,8 +712,8 @@ namespace {
 // The loop of mapf_prioritized_sipp.cpp:214-270 for instances idx[...] on one engine: round r plans agent r of every
 // instance that still has one (agents of one instance are a chain — each plans against the intervals the earlier ones
 // occupy — instances are independent).
-void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, const mrp_hl_instance* instances, mrp_hl_sipp_solution* sols,
-                  const std::vector<int32_t>& idx, GroupResult& out) {
+void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, int32_t nTickets, const mrp_hl_instance* instances,
+                  mrp_hl_sipp_solution* sols, const std::vector<int32_t>& idx, GroupResult& out) {
   struct Iv { int32_t s, e; };
   struct Prio {
     int32_t mapId = -1, agent = 0, dimx = 0;
@@ -752,7 +756,7 @@ void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, const mrp_hl_instance* insta
     bool inflight = false;
   };
   Half half[2];
-  for (size_t q = 0; q < n; ++q) half[n >= 64 ? (q & 1) : 0].members.push_back(q);
+  for (size_t q = 0; q < n; ++q) half[(n >= 64 && nTickets >= 2) ? (q & 1) : 0].members.push_back(q);
   int64_t roundsOf[2] = {0, 0};
 
   // round of one half: agent p.agent of every member that still has one; returns false when there was nothing to do
@@ -1084,7 +1088,7 @@ int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl
     for (int32_t t = 0; t < nThreads; ++t)
       th.emplace_back([&, t]() {
         if (batchMode)
-          runSippGroup(s->engines[t], horizon, instances, sols, idx[t], gr[t]);
+          runSippGroup(s->engines[t], horizon, s->llOpt.n_tickets, instances, sols, idx[t], gr[t]);
         else
           runSippGroupSession(s->engines[t], horizon, s->llOpt.slots, instances, sols, idx[t], gr[t]);
       });
