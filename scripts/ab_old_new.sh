@@ -1,4 +1,4 @@
-# A/B of two builds of the libraries on one box (dev tool): lib_old/ (an earlier commit) vs lib/ (current), static split
+# A/B of two builds of the libraries on one box (dev tool): build an earlier commit's csrc into libmultirobotplanning_amd/lib_old/ first (git show <rev>:... + hipcc); lib/ is the current build; static split for both
 export MRP_HL_STATIC_SPLIT=1
 for rep in 1 2; do
   for which in old new new1; do
