@@ -1,6 +1,9 @@
 // C-ABI of the host-side conflict-tree drivers (include/mrp_hl.h).  Worker threads each own one low-level engine
-// context (mrp_ll_ctx is not thread-safe) and a share of the instances; every round a thread gathers the ready
-// low-level searches of all its instances into one mrp_ll_search_batch call.
+// context (mrp_ll_ctx is not thread-safe).  Default schedule (session mode): every worker keeps a resident kernel fed
+// through the engine's job ring, draws instances from one shared pool and publishes an instance's next searches the
+// moment its previous ones are back (runGroupSession, runSippGroupSession).  Round-based schedule (mode 1 /
+// MRP_HL_SIPP_BATCH): every round a thread gathers the ready searches of its instances into one batch (runGroup,
+// runSippGroup).
 #include <atomic>
 #include <chrono>
 #include <cstdio>

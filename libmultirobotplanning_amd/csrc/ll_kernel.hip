@@ -11,7 +11,10 @@
 //     ballot + popcount per discovered successor;
 //   * bitmap rows are initialised lazily, 64 words per instruction.
 // Search state lives in LDS (fast tier); a search that outgrows it migrates to a per-workgroup HBM arena and
-// continues with the same code instantiated for global pointers.
+// continues with the same code instantiated for global pointers.  The pop and the pushes of one expansion are batched
+// (popFocalEraseOpen, PushChains): their loads are issued together and the sequential heap semantics are resolved in
+// registers.  Kernels: mrp_ll_search_kernel (one launch per batch), mrp_ll_persistent_kernel (resident, fed through a
+// host job ring), mrp_ll_sipp_kernel / mrp_ll_sipp_persistent_kernel (SIPP, sipp.hpp).
 //
 // Reference semantics implemented here (file:line in /root/reference):
 //   AStarEpsilon::search   include/libMultiRobotPlanning/a_star_epsilon.hpp:86-285
