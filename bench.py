@@ -183,7 +183,7 @@ def main():
                         "per step (fed through the pinned-host job ring), and the launches of the threads overlap in time",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU legs run at N=1 only (rank 0)
             import oracle
             oracle.build()
             n = min(args.cpu_sample, B)
