@@ -69,12 +69,17 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # MRP_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo — only to rehearse the multi-rank control flow on a
+    # one-GPU box (RCCL refuses two ranks on one device); never used for a reported number
+    rehearsal = os.environ.get("MRP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist_mod.init_process_group(backend="gloo" if rehearsal else "nccl", rank=rank, world_size=world)
         dist = dist_mod
 
     from libmultirobotplanning_amd import hl
@@ -123,7 +128,7 @@ def main():
 
     # totals: the only exchange this path needs (max of the elapsed times, sum of the counters)
     elapsed_max, (exp_all, solved_all, searches_all, inst_all) = sharding.reduce_totals(
-        dist, "cuda", elapsed, [exp_total, solved_total, searches_total, K * B])
+        dist, "cpu" if rehearsal else "cuda", elapsed, [exp_total, solved_total, searches_total, K * B])
 
     if rank == 0:
         kernel_s = lls["kernel_ms"] / 1e3
