@@ -107,6 +107,58 @@ def test_tiers_agree(oracle_mod, bench_instances):
             eng.close()
 
 
+def test_random_jobs_with_many_constraints(engine, oracle_mod):
+    """Fuzz: random 16x16 maps, random vertex constraints, up to 150 edge constraints per job (more than one wave's
+    worth: the kernel keeps 64 keys in a register and walks the rest), random focal contexts, both algorithms."""
+    import random
+    from libmultirobotplanning_amd import ll
+    rng = random.Random(20260401)
+    dim = 16
+    moves = [(0, 0), (-1, 0), (1, 0), (0, 1), (0, -1)]
+    total = 0
+    for trial in range(6):
+        obst = sorted({(rng.randrange(dim), rng.randrange(dim)) for _ in range(30)})
+        obst = [list(o) for o in obst]
+        free = [[x, y] for x in range(dim) for y in range(dim) if [x, y] not in obst]
+        mid = engine.upload_map(dim, dim, obst)
+        mp = dict(dimx=dim, dimy=dim, obstacles=obst)
+        jobs, specs = [], []
+        for case in range(40):
+            st, go = rng.choice(free), rng.choice(free)
+            vc = [[rng.randrange(0, 30)] + rng.choice(free) for _ in range(rng.randrange(0, 40))]
+            ec = []
+            for _ in range(rng.choice([0, 3, 20, 70, 150])):
+                c = rng.choice(free)
+                dx, dy = rng.choice(moves[1:])
+                ec.append([rng.randrange(0, 30), c[0], c[1], c[0] + dx, c[1] + dy])
+            ctx = []
+            if case % 2:
+                for a in range(rng.randrange(2, 9)):  # random walks as the other agents' paths; agent 0 is the searcher
+                    p = [rng.choice(free)]
+                    for _ in range(rng.randrange(0, 25)):
+                        dx, dy = rng.choice(moves)
+                        q = [p[-1][0] + dx, p[-1][1] + dy]
+                        p.append(q if q in free else p[-1])
+                    ctx.append(p if a else [])
+            algo = ll.ASTAR_EPS if case % 2 else ll.ASTAR
+            w = rng.choice([1.0, 1.3, 2.0]) if algo == ll.ASTAR_EPS else 1.0
+            specs.append((algo, st, go, vc, ec, ctx, w))
+            jobs.append(ll.LLJob(map_id=mid, algo=algo, start=st, goal=go, agent_idx=0, w=w, vertex_constraints=vc,
+                                 edge_constraints=ec, ctx_paths=ctx, max_expansions=30000))
+        res = engine.search_batch(jobs)
+        for (algo, st, go, vc, ec, ctx, w), r in zip(specs, res):
+            o = oracle_mod.ll_search(algo, mp, 0, st, go, vc, ec, ctx, w=w, cap_expansions=30000)
+            if o["rc"] == -1:
+                assert r.status == ll.CAP_EXPANSIONS
+                continue
+            assert r.success == o["success"], (trial, st, go)
+            assert r.expanded == o["expanded"], (trial, st, go, len(ec))
+            if o["success"]:
+                assert (r.cost, r.fmin, r.states, r.actions) == (o["cost"], o["fmin"], o["states"], o["actions"])
+            total += 1
+    assert total > 150
+
+
 def test_more_than_128_agents_in_the_focal_context(engine, oracle_mod):
     """150 agents: the path table rows are 160 entries wide, so the focal heuristics take the chunked branch of the
     kernel (columns >= 128) that the shipped benchmark sizes (<= 100 agents) never reach."""
