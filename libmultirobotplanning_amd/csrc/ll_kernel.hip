@@ -441,12 +441,7 @@ DEVI void popFocalEraseOpen(Mem<AS>& m, uint32_t& nFocal, uint32_t& nOpen, uint3
 // ---- ordered walk (open.ordered_begin(), a_star_epsilon.hpp:141-152) ----------------------------------------
 // libstdc++ std::priority_queue<…> restated: push = __push_heap, pop = __pop_heap/__adjust_heap (bits/stl_heap.h).
 template <int AS>
-DEVI void auxPush(Mem<AS>& m, uint32_t& npq, uint64_t v) {
-  siftUp<AS, 2, false>(m, m.aux, npq, v);
-  npq += 1;
-}
-template <int AS>
-DEVI uint32_t auxPop(Mem<AS>& m, uint32_t& npq) {
+DEVI uint64_t auxPop(Mem<AS>& m, uint32_t& npq) {
   const uint64_t result = ld64<AS>(m.aux, 0);
   npq -= 1;
   if (npq > 0) {
@@ -454,7 +449,7 @@ DEVI uint32_t auxPop(Mem<AS>& m, uint32_t& npq) {
     const uint32_t hole = descend<AS, 2, false, true>(m, m.aux, npq, 0, value);
     siftUp<AS, 2, false>(m, m.aux, hole, value);
   }
-  return (uint32_t)result;  // low 32 bits = index into the open array
+  return result;  // (open key << 32) | index into the open array
 }
 
 template <int AS>
@@ -462,26 +457,38 @@ DEVI void orderedWalk(Mem<AS>& m, SState& s, const Ctx& c, int32_t oldBest, DevR
   // int * float products in binary32, no contraction (a_star_epsilon.hpp:145,149)
   const float lo = __fmul_rn((float)oldBest, c.w);
   const float hi = __fmul_rn((float)s.bestF, c.w);
-  uint32_t npq = 0, cur = 0;
+  // The queue entry of a visited element carries its open key, so f is known without touching the open array again;
+  // the two children are pushed with one round trip (PushChains).  In a long search the walks are most of the time
+  // (every bestF increase visits every open node with f <= hi), so a round trip per visited node matters.
+  uint32_t npq = 0;
+  uint64_t curA = (uint64_t)openKey(ld64<AS>(m.open, 0)) << 32;  // index 0
   for (;;) {
-    uint32_t first = 2 * cur + 1;
+    const uint32_t cur = (uint32_t)curA;
+    const uint32_t first = 2 * cur + 1;
     if (first < s.nOpen) {
       uint64_t e1, e2;
       ldPair<AS>(m.open, first, e1, e2);
-      auxPush<AS>(m, npq, ((uint64_t)openKey(e1) << 32) | first);
-      if (first + 1 < s.nOpen) auxPush<AS>(m, npq, ((uint64_t)openKey(e2) << 32) | (first + 1));
+      uint64_t ee[5];
+      ee[0] = ((uint64_t)openKey(e1) << 32) | first;
+      ee[1] = ((uint64_t)openKey(e2) << 32) | (first + 1);
+      ee[2] = ee[3] = ee[4] = 0;
+      const uint32_t pm = first + 1 < s.nOpen ? 3u : 1u;
+      PushChains<AS> pc;
+      pc.load(m.aux, npq, pm);
+      pc.template resolve<2, false>(m, m.aux, npq, pm, ee);  // == __push_heap of the children in index order
+      npq += pm == 3u ? 2u : 1u;
     }
     PROF_INC(res, 7, 1);
 
-    uint64_t e = ld64<AS>(m.open, cur);
-    float fv = (float)entryF(e);
+    const float fv = (float)entryF(curA);
     if (fv > lo && fv <= hi) {
+      const uint64_t e = ld64<AS>(m.open, cur);
       siftUp<AS, 1, false>(m, m.focal, s.nFocal, e);
       s.nFocal += 1;
     }
     if (fv > hi) break;
     if (npq == 0) break;
-    cur = auxPop<AS>(m, npq);
+    curA = auxPop<AS>(m, npq);
   }
 }
 
