@@ -5,24 +5,30 @@ Contract (one JSON line on rank 0):
   python bench.py --gpus N --steps K --warmup W
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" = one batch of B fresh synthetic instances per GPU solved to completion by the host conflict-tree driver, every
-low-level search of which runs in the HIP kernel (through the C-ABI).  metric = low-level node expansions per second
-(the reference's `lowLevelExpanded` counter, example/ecbs.cpp:476-479,599) over the whole job; `instances_per_s` rides
-along.  Instances are generated (splitmix64, seeds 1000*agents + k) before the timed region and their maps are uploaded
-to HBM before it starts, as the reference constructs its Environment before its Timer (example/ecbs.cpp:576-582).
+A "step" = one batch of B fresh synthetic agents10 instances per GPU (BASELINE.json configs[1] shape) solved to
+completion by the host conflict-tree driver, every low-level search of which runs in the HIP kernel (through the C-ABI).
+metric = low-level node expansions per second (the reference's `lowLevelExpanded` counter, example/ecbs.cpp:476-479,599)
+over the whole job; `instances_per_s` rides along.  Instances are generated natively (splitmix64, seeds 1000*agents + k,
+one mrp_hl_generate_instances call per batch) before the timed region and their maps are uploaded to HBM before it
+starts, as the reference constructs its Environment before its Timer (example/ecbs.cpp:576-582).
 
-Extra objects:
-  roofline     — dominant kernel mrp_ll_persistent_kernel (session mode: one resident launch per host thread per step):
+Extra objects in the same line:
+  by_workload  — N = 1 only: one timed step each of the other shapes north_star names, after the headline region:
+                 agents50, agents100 (synthetic, same generator) and "shipped" (the 150 committed
+                 benchmark/32x32_obst204 inputs of tests/golden/bench_instances.json as ONE batch, checked against
+                 tests/golden/oracle_expected.json).  Each carries value (expansions/s), instances_per_s, capped,
+                 cpu_baseline (the CPU port, one thread, on a bounded sample of the SAME instances) and
+                 parity_mismatches_vs_gpu over that sample.
+  roofline     — dominant kernel of the headline region (session mode: one resident launch per host thread per step):
                  achieved = 128 B/expansion x expansions of the timed launches / sum of their hipEvent
-                 durations; bound = HBM (8 TB/s); traffic = HBM bytes per launch scaled from the committed PMC passes.
-                 The fraction is tiny by construction — the path is an issue-bound replay of sequential heaps whose
-                 working set sits in LDS / L2 — so `issue_bound` rides along: the chip-wide ceiling of
-                 the kernel's measured instruction stream (instructions per expansion from the committed PMC passes x 4
-                 cycles per issue slot, 256 CUs x 4 SIMDs) and the fraction of it this run reached.
-  cpu_baseline — the oracle's CPU restatement (kind "port"; the reference needs Boost/yaml-cpp and cannot be built here)
-                 timed single-threaded on a bounded sample of the same workload, on this box's host cores, with a
-                 per-instance parity check against the GPU results; cpu_baseline_all_cores repeats the sample with one
-                 instance per thread on all host threads the bench uses (SURVEY.md §8d asks for both).
+                 durations; bound = HBM (8 TB/s); traffic = HBM bytes per launch SCALED from the committed PMC passes
+                 (bench.py cannot run rocprofv3's counter passes on itself).  The fraction is tiny by construction — the
+                 path is an issue-bound replay of sequential heaps whose working set sits in LDS / L2 —
+                 so `issue_bound` rides along (instructions per expansion from the same PMC passes).
+  cpu_baseline — the oracle's CPU restatement (kind "port"; the reference needs Boost/yaml-cpp and cannot be built
+                 here) timed single-threaded on a bounded sample of the headline workload on this box's host cores,
+                 with a per-instance parity check against the GPU results; cpu_baseline_all_cores = the same port, one
+                 instance per thread on every CPU this process may use, WALL-CLOCK (expansions / pool wall seconds).
 """
 import argparse
 import json
@@ -43,21 +49,51 @@ ALGO_BYTES_PER_EXPANSION = 128
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
 
+def usable_cpus():
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 8
+
+
+def cpu_leg(oracle, ia, gpu_results, cap, n_sample, hl):
+    """The CPU port, one thread, on the first n_sample instances of `ia`; per-instance parity against gpu_results."""
+    n = min(n_sample, len(ia))
+    per, wall = oracle.mapf_solve_batch(oracle.ECBS, ia.dimx, ia.dimy, ia.obstacles[:n], ia.starts[:n], ia.goals[:n],
+                                        w=1.3, cap_total=cap, n_threads=1)
+    search_s = float(per[:, 5].sum()) / 1e9
+    mism = 0
+    for k in range(n):
+        rc, cost, mk, hle, lle = (int(v) for v in per[k, :5])
+        r = gpu_results[k]
+        if rc == 1:
+            if (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) != (hl.SOLVED, cost, mk, hle, lle):
+                mism += 1
+        elif r["status"] != hl.CAP:  # capped on the CPU => must be capped on the GPU too
+            mism += 1
+    return {"value": float(per[:, 4].sum()) / max(search_s, 1e-12), "unit": "expansions/s", "cores": 1, "kind": "port",
+            "sample": "first %d instances of the leg's batch, oracle ECBS w=1.3 (g++ -O3), search() time only" % n,
+            "instances_per_s": n / max(search_s, 1e-12), "seconds": search_s,
+            "capped": int((per[:, 0] == -1).sum()), "parity_mismatches_vs_gpu": mism}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=65536, help="instances per GPU per step")
+    ap.add_argument("--instances", type=int, default=65536, help="instances per GPU per step (headline workload)")
     ap.add_argument("--agents", type=int, default=10)
     ap.add_argument("--threads", type=int, default=0, help="host worker threads per GPU (0 = auto)")
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--lds-nodes", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=8192, help="instances of step 0 timed on the CPU oracle (rank 0)")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="headline instances timed on the CPU port (rank 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--legs", default="auto", help="'auto' (all at N=1, none otherwise), 'none', or a comma list of "
+                                                   "agents50,agents100,shipped")
     ap.add_argument("--max-ll-expansions", type=int, default=50000,
-                    help="harness cap per instance (the reference has none and never returns on infeasible inputs); "
-                         "applied identically to the GPU path and to the CPU baseline")
+                    help="harness cap per instance of the headline workload (the reference has none and never returns "
+                         "on infeasible inputs); applied identically to the GPU path and to the CPU baseline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -82,24 +118,23 @@ def main():
         dist_mod.init_process_group(backend="gloo" if rehearsal else "nccl", rank=rank, world_size=world)
         dist = dist_mod
 
-    from libmultirobotplanning_amd import hl
-    hc = os.cpu_count() or 8
+    from libmultirobotplanning_amd import hl, sharding
+    hc = usable_cpus()
     threads = args.threads or max(2, min(16, hc // max(1, world)))
     solver = hl.BatchSolver(device=local_rank, n_threads=threads, slots=args.slots, lds_nodes=args.lds_nodes)
 
     B, K, W = args.instances, args.steps, args.warmup
 
-    from libmultirobotplanning_amd import sharding
-
     def batch(step_idx):
         # distinct seeds per (rank, step); step indices of the timed steps start after the warm-up ones
-        base = sharding.seed_base(args.agents, rank, K + W, step_idx, B)
-        return [hl.generate_instance(base + k, 32, 32, 204, args.agents) for k in range(B)]
+        return hl.generate_instances(sharding.seed_base(args.agents, rank, K + W, step_idx, B), B, 32, 32, 204, args.agents)
 
+    t_gen = time.perf_counter()
     batches = [batch(i) for i in range(K + W)]
     # marshal the batches and upload their static maps to HBM before the timed region (the reference constructs its
     # Environment before it starts its Timer, example/ecbs.cpp:576-582); the timed region is the searches only
     prepared = [solver.prepare(b, want_paths=False) for b in batches]
+    t_gen = time.perf_counter() - t_gen
 
     def barrier():
         torch.cuda.synchronize()
@@ -125,6 +160,10 @@ def main():
     elapsed = time.perf_counter() - t0
     lls = solver.ll_stats()
     first_results = solver.results_of(prepared[W]) if K > 0 else []
+    first_batch = batches[W] if K > 0 else None
+    for i, p in enumerate(prepared):
+        solver.release(p)
+    capped_first = sum(1 for r in first_results if r["status"] == hl.CAP)
 
     # totals: the only exchange this path needs (max of the elapsed times, sum of the counters)
     elapsed_max, (exp_all, solved_all, searches_all, inst_all) = sharding.reduce_totals(
@@ -133,9 +172,6 @@ def main():
     if rank == 0:
         kernel_s = lls["kernel_ms"] / 1e3
         achieved = ALGO_BYTES_PER_EXPANSION * lls["expansions"] / max(kernel_s, 1e-12) / 1e9
-        # HBM bytes per launch: bench.py cannot run rocprofv3's PMC passes on itself, so it scales the bytes per expansion
-        # measured by the committed passes over this same program (profiles/hbm_traffic_pmc.json, FETCH_SIZE + WRITE_SIZE
-        # in separate passes, raw counter values) by the expansions of its own launches; null when the file is absent
         traffic = None
         issue_bound = None
         try:
@@ -146,7 +182,8 @@ def main():
             ceiling = 256 * 4 * pmc.get("shader_clock_hz", 2.2e9) / (4.0 * ipe)
             issue_bound = {"instructions_per_expansion": ipe, "ceiling_expansions_per_s": ceiling,
                            "frac": (exp_all / elapsed_max) / world / ceiling,
-                           "source": "profiles/hbm_traffic_pmc.json (SQ_INSTS_* passes, scripts/pmc_ll.sh)"}
+                           "source": "scaled from the committed PMC pass profiles/hbm_traffic_pmc.json "
+                                     "(SQ_INSTS_* passes, scripts/pmc_ll.sh), not measured in this run"}
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -156,7 +193,7 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": 1e3 * elapsed_max / K,
+            "ms_per_step": 1e3 * elapsed_max / max(K, 1),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -170,7 +207,9 @@ def main():
             "instances_per_s": inst_all / elapsed_max,
             "solved": int(solved_all),
             "instances": int(inst_all),
+            "capped_in_first_timed_step": capped_first,
             "ll_searches": int(searches_all),
+            "setup_seconds_generate_and_preload": t_gen,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -178,8 +217,9 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": "scaled from the committed PMC passes (profiles/hbm_traffic_pmc.json), raw counter bytes",
                 "achieved_all_launches_concurrently": ALGO_BYTES_PER_EXPANSION * (exp_all / elapsed_max) / 1e9,
-                "kernel": "mrp_ll_persistent_kernel",
+                "kernel": "mrp_ll_ecbs_persistent_kernel",
                 "launches": lls["launches"],
                 "avg_launch_ms": lls["kernel_ms"] / max(lls["launches"], 1),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EXPANSION * lls["expansions"] / max(lls["launches"], 1),
@@ -188,47 +228,106 @@ def main():
                         "per step (fed through the pinned-host job ring), and the launches of the threads overlap in time",
             },
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU legs run at N=1 only (rank 0)
+        do_cpu = not args.no_cpu_baseline and world == 1  # the CPU legs run at N=1 only (rank 0)
+        oracle = None
+        if do_cpu:
             import oracle
             oracle.build()
-            n = min(args.cpu_sample, B)
-            t_cpu = 0.0
-            e_cpu = 0
-            mism = 0
-            for inst, r in zip(batches[W][:n], first_results[:n]):
-                o = oracle.mapf_solve(oracle.ECBS, inst, w=1.3, cap_total=args.max_ll_expansions, path_cap=1024)
-                t_cpu += o["elapsed_ns"] / 1e9
-                e_cpu += o["ll_expanded"]
-                if o["rc"] == 1:
-                    if (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) != (
-                            hl.SOLVED, o["cost"], o["makespan"], o["hl_expanded"], o["ll_expanded"]):
-                        mism += 1
-                elif r["status"] != hl.CAP:  # capped on the CPU => must be capped on the GPU too
-                    mism += 1
-            out["cpu_baseline"] = {
-                "value": e_cpu / max(t_cpu, 1e-12), "unit": "expansions/s", "cores": 1, "kind": "port",
-                "sample": "first %d instances of timed step 0 (rank 0), oracle ECBS w=1.3, g++ -O3, search() time only"
-                          % n,
-                "instances_per_s": n / max(t_cpu, 1e-12), "seconds": t_cpu,
-                "host_cpus": hc, "parity_mismatches_vs_gpu": mism,
-            }
-            # SURVEY.md §8(d) also asks for "one instance per thread on all host cores": the same sample again on a
-            # thread pool (the oracle call is a ctypes call, i.e. runs without the GIL); wall time of the whole pool
-            from concurrent.futures import ThreadPoolExecutor
-            pool_n = max(1, min(threads, hc))
-            t1 = time.perf_counter()
-            with ThreadPoolExecutor(pool_n) as ex:
-                outs = list(ex.map(lambda inst: oracle.mapf_solve(oracle.ECBS, inst, w=1.3,
-                                                                  cap_total=args.max_ll_expansions, path_cap=1024),
-                                   batches[W][:n]))
-            wall = time.perf_counter() - t1
-            busy = sum(o["elapsed_ns"] for o in outs) / 1e9  # search() time summed over the concurrent searches
+            out["cpu_baseline"] = cpu_leg(oracle, first_batch, first_results, args.max_ll_expansions, args.cpu_sample, hl)
+            out["cpu_baseline"]["host_cpus"] = hc
+            out["vs_cpu_port_1core"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-12)
+            # SURVEY.md §8(d) also asks for "one instance per thread on all host cores": wall clock of a native pool on
+            # every CPU this process may use, over enough instances to keep them busy for a second or so
+            n_all = min(len(first_batch), max(args.cpu_sample, 64 * hc))
+            per, wall = oracle.mapf_solve_batch(oracle.ECBS, 32, 32, first_batch.obstacles[:n_all], first_batch.starts[:n_all],
+                                                first_batch.goals[:n_all], w=1.3, cap_total=args.max_ll_expansions,
+                                                n_threads=hc)
             out["cpu_baseline_all_cores"] = {
-                "value": sum(o["ll_expanded"] for o in outs) / max(busy / pool_n, 1e-12), "unit": "expansions/s",
-                "cores": pool_n, "kind": "port", "pool_wall_seconds": wall, "search_seconds_sum": busy,
-                "sample": "the same %d instances, one instance per thread on %d threads; expansions / (sum of search() "
-                          "times / threads), i.e. Python marshalling between searches is not charged" % (n, pool_n),
+                "value": float(per[:, 4].sum()) / max(wall, 1e-12), "unit": "expansions/s", "cores": hc, "kind": "port",
+                "nproc": hc, "pool_wall_seconds": wall, "instances_per_s": n_all / max(wall, 1e-12),
+                "sample": "first %d instances of timed step 0, one instance per thread on %d threads (all CPUs this "
+                          "process may use); expansions / pool wall-clock seconds" % (n_all, hc),
             }
+            out["vs_cpu_port_all_cores"] = out["value"] / max(out["cpu_baseline_all_cores"]["value"], 1e-12)
+
+        legs = args.legs
+        if legs == "auto":
+            legs = "agents50,agents100,shipped" if world == 1 else "none"
+        by = {"agents%d" % args.agents: {"value": out["value"], "instances_per_s": out["instances_per_s"],
+                                         "instances": int(inst_all), "capped": capped_first,
+                                         "cap_per_instance": args.max_ll_expansions, "see": "top-level fields"}}
+        leg_specs = {  # name -> (agents, instances, cap per instance, CPU sample)
+            "agents50": (50, 8192, 400000, 192),
+            "agents100": (100, 2048, 2000000, 24),
+        }
+        for name in [x for x in legs.split(",") if x and x != "none"]:
+            if name in leg_specs:
+                ag, nb, cap, ncpu = leg_specs[name]
+                ia = hl.generate_instances(1000 * ag, nb, 32, 32, 204, ag)
+                small = solver.prepare(ia[:64], want_paths=False)
+                solver.solve_prepared(small, algo=hl.ECBS, w=1.3, max_ll_expansions=cap, raw=True)  # warm-up, same shape
+                solver.release(small)
+                prep = solver.prepare(ia, want_paths=False)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                _, st = solver.solve_prepared(prep, algo=hl.ECBS, w=1.3, max_ll_expansions=cap, raw=True)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                res = solver.results_of(prep)
+                solver.release(prep)
+                leg = {"value": st["ll_expansions"] / dt, "unit": "expansions/s", "instances_per_s": nb / dt,
+                       "instances": nb, "seconds": dt, "solved": int(st["solved"]),
+                       "capped": sum(1 for r in res if r["status"] == hl.CAP), "cap_per_instance": cap,
+                       "ll_searches": int(st["ll_searches"]),
+                       "workload": "ECBS w=1.3, synthetic 32x32_obst204-shaped, agents%d, seeds %d.." % (ag, 1000 * ag)}
+                if do_cpu:
+                    leg["cpu_baseline"] = cpu_leg(oracle, ia, res, cap, ncpu, hl)
+                    leg["vs_cpu_port_1core"] = leg["value"] / max(leg["cpu_baseline"]["value"], 1e-12)
+                by[name] = leg
+            elif name == "shipped":
+                with open(os.path.join(ROOT, "tests", "golden", "bench_instances.json")) as f:
+                    shipped = json.load(f)
+                with open(os.path.join(ROOT, "tests", "golden", "oracle_expected.json")) as f:
+                    expected = json.load(f)
+                names = [n for n in sorted(shipped) if "32by32" in n]
+                insts = [shipped[n] for n in names]
+                cap = 3000000  # the cap oracle_expected.json was produced with (tests/golden/make_fixtures.py)
+                prep = solver.prepare(insts, want_paths=False)
+                solver.solve_prepared(prep, algo=hl.ECBS, w=1.3, max_ll_expansions=cap, raw=True)  # warm-up
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                _, st = solver.solve_prepared(prep, algo=hl.ECBS, w=1.3, max_ll_expansions=cap, raw=True)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                res = solver.results_of(prep)
+                solver.release(prep)
+                mism = 0
+                for n, r in zip(names, res):
+                    e = expected[n]["ecbs_w1.3"]
+                    if e["rc"] == 1:
+                        mism += (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) != (
+                            hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"])
+                    else:
+                        mism += r["status"] != hl.CAP
+                leg = {"value": st["ll_expansions"] / dt, "unit": "expansions/s", "instances_per_s": len(insts) / dt,
+                       "instances": len(insts), "seconds": dt, "solved": int(st["solved"]),
+                       "capped": sum(1 for r in res if r["status"] == hl.CAP), "cap_per_instance": cap,
+                       "parity_mismatches_vs_golden": int(mism),
+                       "workload": "the %d committed benchmark/32x32_obst204 inputs (agents10 x100, 20 x10, 30 x10, 50 x20, "
+                                   "100 x10) as one batch, ECBS w=1.3" % len(insts)}
+                if do_cpu:  # the whole shipped set on one CPU thread
+                    t_cpu = 0.0
+                    e_cpu = 0
+                    for inst in insts:
+                        o = oracle.mapf_solve(oracle.ECBS, inst, w=1.3, cap_total=cap, path_cap=1024)
+                        t_cpu += o["elapsed_ns"] / 1e9
+                        e_cpu += o["ll_expanded"]
+                    leg["cpu_baseline"] = {"value": e_cpu / max(t_cpu, 1e-12), "unit": "expansions/s", "cores": 1,
+                                           "kind": "port", "sample": "all %d instances" % len(insts),
+                                           "instances_per_s": len(insts) / max(t_cpu, 1e-12), "seconds": t_cpu}
+                    leg["vs_cpu_port_1core"] = leg["value"] / max(leg["cpu_baseline"]["value"], 1e-12)
+                by[name] = leg
+        out["by_workload"] = by
         print(json.dumps(out), flush=True)
     solver.close()
     if dist is not None:

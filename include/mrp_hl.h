@@ -122,6 +122,10 @@ int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t n_instances, const 
  * Buffers: obstacles_xy [n_obstacles][2], starts_xy / goals_xy [n_agents][2]. Returns 0, or -1 if impossible. */
 int mrp_hl_generate_instance(uint64_t seed, int32_t dimx, int32_t dimy, int32_t n_obstacles, int32_t n_agents,
                              int32_t* obstacles_xy, int32_t* starts_xy, int32_t* goals_xy);
+/* The same for seeds seed0 .. seed0 + n - 1 in one call (host threads): instance k fills obstacles_xy[k][n_obstacles][2],
+ * starts_xy[k][n_agents][2], goals_xy[k][n_agents][2].  Returns 0, or -1 if any instance was impossible. */
+int mrp_hl_generate_instances(uint64_t seed0, int32_t n, int32_t dimx, int32_t dimy, int32_t n_obstacles,
+                              int32_t n_agents, int32_t* obstacles_xy, int32_t* starts_xy, int32_t* goals_xy);
 
 #ifdef __cplusplus
 }

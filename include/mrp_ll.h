@@ -102,6 +102,15 @@ typedef struct mrp_ll_job {
   const int32_t* collision_xy;        /* [n][2]   x, y                                                        */
   const int32_t* collision_count;     /* [n]      intervals of that location                                  */
   const int32_t* collision_intervals; /* [sum][2] start, end (inclusive; end may be INT32_MAX)                 */
+  /* The fork's extra search arguments (both default to 0 in the reference):
+   *   MRP_LL_ASTAR     : AStar::search(start, solution, initialCost)   a_star.hpp:63-64,78,100 — the start node's gScore;
+   *                      cost and fmin come back offset by it (a start that already is the goal keeps fmin = h(start),
+   *                      because the start node's fScore is pushed without it, a_star.hpp:78)
+   *   MRP_LL_SIPP      : SIPP::search(start, waitAction, solution, startTime)  sipp.hpp:92-103 — the safe interval of the
+   *                      start cell is looked up at this time, state times are absolute, cost = arrival - startTime
+   *   MRP_LL_ASTAR_EPS : AStarEpsilon::search has no such argument: a non-zero value is rejected (MRP_LL_BAD_JOB) */
+  int32_t initial_cost;
+  int32_t reserved;
 } mrp_ll_job;
 
 typedef struct mrp_ll_result {
@@ -144,6 +153,10 @@ int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t n_obs
 /* Copies every map uploaded so far to the device now (otherwise done lazily by the next submit / session_begin). */
 int mrp_ll_sync_maps(mrp_ll_ctx* ctx);
 
+/* Forgets every uploaded map (host copy and device buffer contents; map ids start again at 0).  For callers that keep
+ * one context across many batches of instances.  MRP_LL_E_BUSY while a batch or a session is in flight. */
+int mrp_ll_release_maps(mrp_ll_ctx* ctx);
+
 /* Geometry of the LDS-resident fast tier for the launches / sessions that follow: node capacity, (time, cell) bitmap
  * rows and bytes of the focal path table kept in LDS per resident search (0 = keep the current value; lds_nodes < 0
  * disables the tier).  Smaller tiers let more searches share a CU (occupancy = 160 KiB / tier bytes) at the price of
@@ -165,11 +178,19 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket);
  * no stream command) and returns MRP_LL_E_BUSY when the ring has no room for the whole batch (consume finished
  * tickets, then retry); mrp_ll_poll is the non-blocking form of mrp_ll_wait.  Searches of different tickets finish in
  * any order, so a caller can keep thousands of independent conflict trees moving without waiting for the slowest
- * search of a batch.  Results are identical to the batch mode's. */
+ * search of a batch.  Results are identical to the batch mode's.
+ * Liveness: the resident wavefronts watch a heartbeat that every mrp_ll_submit* / mrp_ll_poll* / mrp_ll_wait call
+ * moves, and leave on their own only when it has stood still for 20 s (a caller that died); a caller that keeps
+ * polling may pause between submits for as long as it likes.  If the resident kernel is gone while jobs are in flight
+ * (that limit, or a device fault), mrp_ll_poll_any / mrp_ll_wait return MRP_LL_E_DEVICE instead of spinning. */
 int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups /* 0 = mrp_ll_options.slots */);
 /* The same for MRP_LL_SIPP jobs (a session serves one kind: A* / A*-epsilon jobs, or SIPP jobs — the other kind comes
  * back as MRP_LL_BAD_JOB).  At most 512 SIPP jobs are in flight at a time (MRP_LL_E_BUSY beyond that). */
 int mrp_ll_session_begin_sipp(mrp_ll_ctx* ctx, int32_t workgroups);
+/* A session for jobs of ONE algorithm (MRP_LL_ASTAR, MRP_LL_ASTAR_EPS or MRP_LL_SIPP): the resident kernel is the one
+ * specialised for it — half the code and fewer registers than the mixed kernel of mrp_ll_session_begin, same results;
+ * jobs of another algorithm come back as MRP_LL_BAD_JOB.  What the conflict-tree drivers use. */
+int mrp_ll_session_begin_algo(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups);
 int mrp_ll_session_end(mrp_ll_ctx* ctx);
 /* Session mode: `lane` 0 = the bulk ring (first in, first out), 1 = the priority ring: every resident wavefront looks
  * there before it takes its next bulk job, so a lane-1 search starts within one job time however long the bulk queue is

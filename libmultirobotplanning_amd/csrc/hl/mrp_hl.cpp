@@ -24,6 +24,7 @@
 using namespace mrp_hl;
 
 struct mrp_hl_preloaded {
+  mrp_hl_solver* owner = nullptr;
   int32_t nInst = 0;
   const mrp_hl_instance* instances = nullptr;
   std::vector<std::vector<int32_t>> idx, mapIds;  // per worker: instance indices and their map ids on that engine
@@ -36,6 +37,7 @@ struct mrp_hl_solver {
   std::vector<mrp_ll_ctx*> engines;
   mrp_ll_options llOpt;
   std::string err;
+  int32_t nPreloaded = 0;  // live mrp_hl_preloaded objects (their maps are released with the last one)
 };
 
 namespace {
@@ -44,6 +46,9 @@ namespace {
 // default: with the job slots recycled in completion order the bulk lane no longer starves long chains (measured
 // neutral for ECBS at the bench shape), and for CBS — where nearly every instance is deep — it only adds contention.
 constexpr int64_t kDeepHl = INT64_MAX;
+// A session loop gives up when nothing at all has come back for this long (a dead resident kernel is reported much
+// sooner by mrp_ll_poll_any's own liveness check).
+constexpr double kNoProgressLimitS = 600.0;
 
 struct GroupResult {
   int64_t rounds = 0, searches = 0, expansions = 0;
@@ -226,8 +231,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   int64_t deepHl = kDeepHl;
   if (const char* e = std::getenv("MRP_HL_DEEP")) deepHl = std::atoll(e);  // tuning knob
   auto tg0 = std::chrono::steady_clock::now();
-  if (mrp_ll_session_begin(ctx, workgroups) != MRP_LL_SUCCESS) {
-    out.err = std::string("mrp_ll_session_begin: ") + mrp_ll_last_error(ctx);
+  if (mrp_ll_session_begin_algo(ctx, opt.algo == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR, workgroups) != MRP_LL_SUCCESS) {
+    out.err = std::string("mrp_ll_session_begin_algo: ") + mrp_ll_last_error(ctx);
     return;
   }
   // returns 1 submitted, 0 ring full (retry later), -1 error
@@ -332,6 +337,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   auto t0 = std::chrono::steady_clock::now();
   auto tg2 = t0;
   uint64_t idleSpins = 0;
+  bool sinceProgress = false;
+  auto lastProgress = t0;
   double tmSubmitOk = 0, tmSubmitBusy = 0, tmPollEmpty = 0, tmPollHit = 0, tmUnpack = 0, tmAdvance = 0;
   uint64_t nSubmitBusy = 0, nPollEmpty = 0, nPollHit = 0;
   auto nowS = []() { return std::chrono::steady_clock::now(); };
@@ -446,10 +453,15 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     out.buildS += secsS(tA, tB);
     out.llS += secsS(tB, tC);
     out.consumeS += secsS(tC, tD);
-    if (progress) {
+    if (progress) {  // the guard measures the time since the LAST progress, not since the start of the batch
       idleSpins = 0;
-    } else if ((++idleSpins & 0xFFFFF) == 0) {
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 600.0) {
+      sinceProgress = false;
+    } else if ((++idleSpins & 0xFFFF) == 0) {
+      const auto nowT = std::chrono::steady_clock::now();
+      if (!sinceProgress) {
+        sinceProgress = true;
+        lastProgress = nowT;
+      } else if (std::chrono::duration<double>(nowT - lastProgress).count() > kNoProgressLimitS) {
         out.err = "session: no progress for too long";
         failed = true;
       }
@@ -588,6 +600,7 @@ int mrp_hl_solver_preload(mrp_hl_solver* s, int32_t nThreadsWanted, int32_t nIns
   if (nThreadsWanted > 0) nThreads = std::min(nThreads, nThreadsWanted);
   nThreads = std::max(1, std::min(nThreads, std::max(nInst, 1)));
   auto* p = new mrp_hl_preloaded();
+  p->owner = s;
   p->nInst = nInst;
   p->instances = instances;
   p->idx.resize(nThreads);
@@ -624,11 +637,19 @@ int mrp_hl_solver_preload(mrp_hl_solver* s, int32_t nThreadsWanted, int32_t nIns
     }
     for (int32_t k : p->idx[t]) p->mapIds[t].push_back(p->mapBase[t] + k);
   }
+  s->nPreloaded += 1;
   *out = p;
   return MRP_LL_SUCCESS;
 }
 
-void mrp_hl_preloaded_free(mrp_hl_preloaded* p) { delete p; }
+// The engines keep one map buffer for all preloaded batches alive at a time; when the last one goes, its maps go too
+// (otherwise a persistent solver would grow its host and device map buffers with every batch).
+void mrp_hl_preloaded_free(mrp_hl_preloaded* p) {
+  if (!p) return;
+  if (p->owner && --p->owner->nPreloaded == 0)
+    for (auto* e : p->owner->engines) (void)mrp_ll_release_maps(e);
+  delete p;
+}
 
 int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* optIn, int32_t nInst, const mrp_hl_instance* instances,
                         mrp_hl_solution* solutions, mrp_hl_batch_stats* stats) {
@@ -981,6 +1002,8 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
   int64_t maxAgents = 0;
   auto t0 = std::chrono::steady_clock::now();
   uint64_t idleSpins = 0;
+  bool sinceProgress = false;
+  auto lastProgress = t0;
   while (!failed && (nInflight != 0 || !backlog.empty())) {
     bool progress = false;
     while (!backlog.empty()) {
@@ -1062,10 +1085,16 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
     }
     if (progress) {
       idleSpins = 0;
-    } else if ((++idleSpins & 0xFFFFF) == 0 &&
-               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 600.0) {
-      out.err = "prioritized SIPP session: no progress for too long";
-      failed = true;
+      sinceProgress = false;
+    } else if ((++idleSpins & 0xFFFF) == 0) {
+      const auto nowT = std::chrono::steady_clock::now();
+      if (!sinceProgress) {
+        sinceProgress = true;
+        lastProgress = nowT;
+      } else if (std::chrono::duration<double>(nowT - lastProgress).count() > kNoProgressLimitS) {
+        out.err = "prioritized SIPP session: no progress for too long";
+        failed = true;
+      }
     }
   }
   if (mrp_ll_session_end(ctx) != MRP_LL_SUCCESS && out.err.empty())
@@ -1127,6 +1156,29 @@ int mrp_hl_solve_batch(int32_t device, const mrp_hl_options* opt, int32_t nInst,
 int mrp_hl_generate_instance(uint64_t seed, int32_t dimx, int32_t dimy, int32_t nObst, int32_t nAgents,
                              int32_t* obstXY, int32_t* startsXY, int32_t* goalsXY) {
   return generateInstance(seed, dimx, dimy, nObst, nAgents, obstXY, startsXY, goalsXY);
+}
+
+int mrp_hl_generate_instances(uint64_t seed0, int32_t n, int32_t dimx, int32_t dimy, int32_t nObst, int32_t nAgents,
+                              int32_t* obstXY, int32_t* startsXY, int32_t* goalsXY) {
+  if (n < 0 || (n > 0 && (!obstXY || !startsXY || !goalsXY))) return -1;
+  unsigned hc = std::thread::hardware_concurrency();
+  const int32_t nThreads = std::max<int32_t>(1, std::min<int32_t>(static_cast<int32_t>(hc ? hc : 8), std::min(n, 64)));
+  std::atomic<int32_t> next(0), bad(0);
+  std::vector<std::thread> th;
+  for (int32_t t = 0; t < nThreads; ++t)
+    th.emplace_back([&]() {
+      for (;;) {
+        const int32_t k0 = next.fetch_add(64, std::memory_order_relaxed);
+        if (k0 >= n) return;
+        for (int32_t k = k0; k < std::min(n, k0 + 64); ++k)
+          if (generateInstance(seed0 + static_cast<uint64_t>(k), dimx, dimy, nObst, nAgents,
+                               obstXY + static_cast<size_t>(k) * nObst * 2, startsXY + static_cast<size_t>(k) * nAgents * 2,
+                               goalsXY + static_cast<size_t>(k) * nAgents * 2) != 0)
+            bad.fetch_add(1, std::memory_order_relaxed);
+      }
+    });
+  for (auto& x : th) x.join();
+  return bad.load() == 0 ? 0 : -1;
 }
 
 }  // extern "C"

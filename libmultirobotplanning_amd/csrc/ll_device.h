@@ -21,6 +21,10 @@ constexpr uint32_t kMaxArenaNodes = 1u << 22;
 constexpr uint32_t kConsLocalWords = 2048;                        // constraint words copied into the arena slot
 constexpr uint32_t kNoParent = 0xFFFFFFFFu;
 constexpr uint32_t kEmptyCell = 0xFFFFu;                           // "no agent here" in the path table
+constexpr uint32_t kRingSlotBits = 11;                            // session mode: job-slot field of a ticket / completion entry
+constexpr uint32_t kRingSlots = 1u << kRingSlotBits;              // job slots of a session (host Ring::kSlots == this)
+constexpr uint32_t kRingSlotMask = kRingSlots - 1;
+constexpr uint32_t kHeartbeatWord = 32;                           // ring_head[32]: host heartbeat (bumped on every submit / poll)
 
 // status codes mirror include/mrp_ll.h
 enum : int32_t { ST_OK = 0, ST_NO_SOLUTION = 1, ST_CAP_EXP = 2, ST_CAP_NODES = 3, ST_CAP_HORIZON = 4, ST_BAD = 5 };
@@ -91,7 +95,7 @@ struct LaunchParams {
   uint32_t ring_size;         // ticket-ring entries of lane 0
   uint32_t ring_size1;        // ticket-ring entries of lane 1, the priority lane (stored after lane 0's)
   uint32_t n_slots;           // job slots (both lanes); at most 2048 (11-bit slot field)
-  uint32_t ring_idle_limit_s; // a workgroup that waited this long for a job exits (safety net if the host died)
+  uint32_t ring_idle_limit_s; // a workgroup leaves when the host heartbeat (ring_head[kHeartbeatWord]) stood still this long
 };
 
 }  // namespace mrp

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "ll_device.h"
 
 namespace mrp {
@@ -925,10 +927,13 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
     u32x4 n0;
     n0.x = sc | (si << 16);
     n0.y = kNoParent;
-    n0.z = 0;  // g = startTime = 0
+    // SIPP::search(..., startTime) (sipp.hpp:92-103): the start node's g is startTime, its f is h(start) alone
+    // (a_star.hpp:78 pushes Node(start, h, initialCost))
+    const uint32_t startTime = (uint32_t)J.last_goal_constraint;
+    n0.z = startTime;
     n0.w = 0;
     g.nodes[0] = n0;
-    g.open[0] = packEntry(0, h0, 0, 0);
+    g.open[0] = packEntry(0, h0, startTime, 0);
     const uint32_t k = rfl(cellIdx[sc]);
     const uint32_t sid = k ? cells + rfl(specFirst[k - 1]) + si : sc;
     g.bits[sid] = 1;
@@ -1199,6 +1204,11 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
 }
 
 // Runs the job whose descriptor is at `jobSrc` (host memory) and writes result + path to host memory.
+// KIND: 0 = the job's own algo field decides (mixed batches / sessions), 1 = A*-epsilon jobs only (ECBS), 2 = A* jobs
+// only (CBS).  The specialised kernels carry one search loop per memory tier instead of two, which halves their code
+// (instruction-cache footprint) and takes the other algorithm's live ranges out of the register allocation; a job of
+// the other kind comes back as ST_BAD.
+template <int KIND>
 DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* resDst, uint16_t* pathDst, uint8_t* smem,
                      uint8_t* arenaSlot, DevJob& jobS, DevResult& resS) {
   const uint32_t lane = threadIdx.x;
@@ -1216,10 +1226,16 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
   PROF_T0();
   uint16_t* outPath = (uint16_t*)(arenaSlot + P.arena_scratch_off);  // device scratch; copied out below
   const uint32_t algo = rfl(J.algo);
-  if (algo == 1)
-    runJob<true>(P, J, smem, arenaSlot, res, outPath);
-  else
-    runJob<false>(P, J, smem, arenaSlot, res, outPath);
+  if (KIND == 0) {
+    if (algo == 1)
+      runJob<true>(P, J, smem, arenaSlot, res, outPath);
+    else
+      runJob<false>(P, J, smem, arenaSlot, res, outPath);
+  } else if (KIND == 1) {
+    if (algo == 1) runJob<true>(P, J, smem, arenaSlot, res, outPath);
+  } else {
+    if (algo == 0) runJob<false>(P, J, smem, arenaSlot, res, outPath);
+  }
   PROF_ADD(res, 5);
   DBG(P, 2, res.status + 100);
   // result + path back to host memory with lane-parallel stores
@@ -1236,10 +1252,8 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
 }
 
 // Batch mode.  One workgroup == one wavefront; pulls jobs from the batch's queue (exit: queue exhausted).
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchParams P) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ DevJob jobS;
-  __shared__ DevResult resS;
+template <int KIND>
+DEVI void batchLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevResult& resS) {
   const uint32_t lane = threadIdx.x;
   uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
   DBG(P, 0, 1);
@@ -1250,10 +1264,29 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchPara
     j = rfl(j) - P.queue_base;
     DBG(P, 1, j + 1);
     if (j >= P.n_jobs) break;
-    processJob(P, P.jobs + j, P.results + j, P.out_paths + (size_t)j * P.out_stride, smem, arenaSlot, jobS, resS);
+    processJob<KIND>(P, P.jobs + j, P.results + j, P.out_paths + (size_t)j * P.out_stride, smem, arenaSlot, jobS, resS);
     DBG(P, 3, j + 1);
   }
   DBG(P, 4, 1);
+}
+
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchParams P) {  // mixed batches
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ DevJob jobS;
+  __shared__ DevResult resS;
+  batchLoop<0>(P, smem, jobS, resS);
+}
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_search_kernel(LaunchParams P) {  // A*-epsilon jobs only
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ DevJob jobS;
+  __shared__ DevResult resS;
+  batchLoop<1>(P, smem, jobS, resS);
+}
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_search_kernel(LaunchParams P) {  // A* jobs only
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ DevJob jobS;
+  __shared__ DevResult resS;
+  batchLoop<2>(P, smem, jobS, resS);
 }
 
 // One SIPP job whose descriptor is at `jobSrc` (host memory): result + raw A* states back to host memory.
@@ -1307,8 +1340,9 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams
 //                       the searches of an instance deep in its conflict tree never queue behind the bulk.
 // The finished job's slot gets ring_done[slot] = (ticket + 1) & 0x3FFFFFFF | 1 << 30 | lane << 31 (never 0) and an
 // entry in the completion queue.
-// Exit conditions every wave reaches: *ring_stop != 0, or no job for ring_idle_limit_s seconds.
-template <bool SIPP>
+// Exit conditions every wave reaches: *ring_stop != 0, or the host's heartbeat word has not moved for
+// ring_idle_limit_s seconds (the host is gone).
+template <bool SIPP, int KIND>
 DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevResult& resS) {
   const uint32_t lane = threadIdx.x;
   uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
@@ -1324,10 +1358,12 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
   const uint32_t compSize = P.n_slots;
   bool haveBulk = false;                          // a bulk ticket is held and not yet served
   uint32_t bulkT = 0;
+  uint32_t lastBeat = 0;                          // host heartbeat value seen at the last idle-limit check
   for (;;) {
     uint32_t slot = 0, doneVal = 0;
     bool stop = false;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t tBeat = t0;
     for (;;) {
       // priority lane: claim only what is already published
       const uint32_t hd1 = rfl(__hip_atomic_load(head1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
@@ -1352,8 +1388,8 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
           uint32_t e;
           do {  // published before head1 was advanced: visible on the first look in practice
             e = rfl(__hip_atomic_load(ring1 + cur % q1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
-          } while ((e >> 11) != gen);
-          slot = e & 2047u;
+          } while ((e >> kRingSlotBits) != gen);
+          slot = e & kRingSlotMask;
           doneVal = ((cur + 1u) & 0x3FFFFFFFu) | 0xC0000000u;
           break;
         }
@@ -1370,17 +1406,30 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
       if ((int32_t)(hd - bulkT) > 0) {
         const uint32_t gen = (bulkT / q0 + 1) & 0x1FFFFFu;
         const uint32_t e = rfl(__hip_atomic_load(ring0 + bulkT % q0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
-        if ((e >> 11) == gen) {
-          slot = e & 2047u;
+        if ((e >> kRingSlotBits) == gen) {
+          slot = e & kRingSlotMask;
           doneVal = ((bulkT + 1u) & 0x3FFFFFFFu) | 0x40000000u;
           haveBulk = false;
           break;
         }
       }
       const uint32_t sp = rfl(__hip_atomic_load(P.ring_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-      if (sp != 0 || __builtin_amdgcn_s_memrealtime() - t0 > idleLimit) {
+      if (sp != 0) {
         stop = true;
         break;
+      }
+      // Safety net for a host that died: the host bumps a heartbeat word on every submit / poll.  A workgroup — which
+      // always holds a bulk ticket while it waits — leaves only when that word has not moved for ring_idle_limit_s; a
+      // live host that is merely slow to publish (a long tail search elsewhere, a caller pausing between submits while
+      // it keeps polling) never loses the workgroup that holds the ticket it will publish next.
+      if (__builtin_amdgcn_s_memrealtime() - tBeat > idleLimit) {
+        const uint32_t hb = rfl(__hip_atomic_load(P.ring_head + kHeartbeatWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (hb == lastBeat) {
+          stop = true;
+          break;
+        }
+        lastBeat = hb;
+        tBeat = __builtin_amdgcn_s_memrealtime();
       }
       uint32_t naps = (int32_t)(bulkT - hd) > 0 ? 1 + (bulkT - hd) : 1;
       if (naps > 48) naps = 48;
@@ -1392,14 +1441,14 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
     if (SIPP)
       processSippJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, arenaSlot, jobS, resS);
     else
-      processJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, smem, arenaSlot, jobS,
-                 resS);
+      processJob<KIND>(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, smem, arenaSlot,
+                       jobS, resS);
     __threadfence_system();
     __hip_atomic_store(P.ring_done + slot, doneVal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring
     uint32_t cidx = atomicAdd(P.comp_count, lane == 0 ? 1u : 0u);
     cidx = rfl(cidx);
-    __hip_atomic_store(P.comp_ring + (cidx % compSize), ((cidx / compSize + 1) << 11) | slot, __ATOMIC_RELEASE,
+    __hip_atomic_store(P.comp_ring + (cidx % compSize), ((cidx / compSize + 1) << kRingSlotBits) | slot, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
     busyTicks += __builtin_amdgcn_s_memrealtime() - t1c;
   }
@@ -1408,18 +1457,45 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
   atomicAdd(P.sess_ticks + 2, (lane == 0 && busyTicks != 0) ? 1ull : 0ull);  // workgroups that ran at least one job
 }
 
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(LaunchParams P) {
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(LaunchParams P) {  // mixed sessions
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
-  residentLoop<false>(P, smem, jobS, resS);
+  residentLoop<false, 0>(P, smem, jobS, resS);
+}
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_persistent_kernel(LaunchParams P) {  // A*-epsilon only
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ DevJob jobS;
+  __shared__ DevResult resS;
+  residentLoop<false, 1>(P, smem, jobS, resS);
+}
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_persistent_kernel(LaunchParams P) {  // A* only
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ DevJob jobS;
+  __shared__ DevResult resS;
+  residentLoop<false, 2>(P, smem, jobS, resS);
 }
 
 // The same resident loop for SIPP sessions (jobs of algo MRP_LL_SIPP only; no LDS tier).
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_persistent_kernel(LaunchParams P) {
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
-  residentLoop<true>(P, nullptr, jobS, resS);
+  residentLoop<true, 0>(P, nullptr, jobS, resS);
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize (a workgroup may take up to the CU's 160 KiB minus the static jobS/resS) for
+// kernel number `which` on the calling thread's current device; thread-safe, done once per (kernel, device).
+static hipError_t allowFullLds(const void* fn, int which) {
+  static std::mutex mu;
+  static bool done[8][64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev >= 0 && dev < 64 && done[which][dev]) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+  if (e == hipSuccess && dev >= 0 && dev < 64) done[which][dev] = true;
+  return e;
 }
 
 }  // namespace mrp
@@ -1429,15 +1505,16 @@ extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t 
   return mrp::ldsBytes(capNodes, rows, rowWords, pathBytes);
 }
 
-extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, hipStream_t stream) {
-  static bool attrSet = false;
-  if (!attrSet) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mrp::mrp_ll_search_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);  // minus the static jobS/resS
+// kind: 0 = mixed, 1 = A*-epsilon jobs only, 2 = A* jobs only (see processJob)
+extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, int kind,
+                                    hipStream_t stream) {
+  typedef void (*Kern)(mrp::LaunchParams);
+  const Kern k = kind == 1 ? mrp::mrp_ll_ecbs_search_kernel : kind == 2 ? mrp::mrp_ll_cbs_search_kernel : mrp::mrp_ll_search_kernel;
+  {  // every worker thread launches through here, and the attribute is per device: set it under a lock, once per device
+    hipError_t e = mrp::allowFullLds(reinterpret_cast<const void*>(k), kind);
     if (e != hipSuccess) return e;
-    attrSet = true;
   }
-  hipLaunchKernelGGL(mrp::mrp_ll_search_kernel, dim3(grid), dim3(64), ldsBytes, stream, *P);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), ldsBytes, stream, *P);
   return hipGetLastError();
 }
 
@@ -1451,15 +1528,16 @@ extern "C" hipError_t mrp_ll_launch_sipp_persistent(const mrp::LaunchParams* P, 
   return hipGetLastError();
 }
 
-extern "C" hipError_t mrp_ll_launch_persistent(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes,
+extern "C" hipError_t mrp_ll_launch_persistent(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, int kind,
                                                hipStream_t stream) {
-  static bool attrSet = false;
-  if (!attrSet) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mrp::mrp_ll_persistent_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+  typedef void (*Kern)(mrp::LaunchParams);
+  const Kern k = kind == 1   ? mrp::mrp_ll_ecbs_persistent_kernel
+                 : kind == 2 ? mrp::mrp_ll_cbs_persistent_kernel
+                             : mrp::mrp_ll_persistent_kernel;
+  {
+    hipError_t e = mrp::allowFullLds(reinterpret_cast<const void*>(k), 3 + kind);
     if (e != hipSuccess) return e;
-    attrSet = true;
   }
-  hipLaunchKernelGGL(mrp::mrp_ll_persistent_kernel, dim3(grid), dim3(64), ldsBytes, stream, *P);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), ldsBytes, stream, *P);
   return hipGetLastError();
 }

@@ -16,10 +16,11 @@
 #include "ll_device.h"
 
 extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes);
-extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, int kind,
+                                    hipStream_t stream);
 extern "C" hipError_t mrp_ll_launch_sipp(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t mrp_ll_launch_sipp_persistent(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream);
-extern "C" hipError_t mrp_ll_launch_persistent(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes,
+extern "C" hipError_t mrp_ll_launch_persistent(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, int kind,
                                                hipStream_t stream);
 
 namespace {
@@ -95,7 +96,9 @@ struct Ticket {
   mrp_ll_result* userResults = nullptr;
   std::vector<uint8_t> rejected;  // per job: rejected on the host (MRP_LL_BAD_JOB)
   bool sipp = false;              // the batch holds MRP_LL_SIPP jobs (own kernel, own result format)
+  int kind = 0;                   // A* batches: 0 = mixed, 1 = all A*-epsilon, 2 = all A*
   std::vector<int32_t> jobDimx;   // SIPP: grid width per job (cell -> x, y when unpacking)
+  std::vector<int32_t> jobInit;   // per job: initial_cost (A*) / start_time (SIPP), applied when unpacking
 };
 
 // ---- session mode: job ring in coherent pinned host memory --------------------------------------------------
@@ -104,7 +107,7 @@ struct Ticket {
 // list.  A slot is tied up until its result has been consumed, a ticket entry only until a workgroup has started the
 // job, so one long search never blocks the publication of the searches behind it.
 struct Ring {
-  static constexpr uint32_t kSlots = 2048;                // job slots, shared by both lanes
+  static constexpr uint32_t kSlots = mrp::kRingSlots;     // job slots, shared by both lanes (the device masks with the same constant)
   static constexpr uint32_t kReserve1 = 256;              // slots the bulk lane leaves free for the priority lane
   static constexpr uint32_t kTickets0 = 1u << 17;         // ticket-ring entries of lane 0 / lane 1
   static constexpr uint32_t kTickets1 = 1u << 14;
@@ -116,6 +119,10 @@ struct Ring {
   uint32_t* compCountDev = nullptr;  // device counter
   unsigned long long* ticksDev = nullptr;  // device [2]: busy / idle ticks of the session's workgroups
   uint64_t compCursor = 0;           // next completion-queue entry the host expects
+  uint32_t heartbeat = 0;            // bumped on every submit / poll: resident workgroups leave only when it stands still
+  uint32_t emptyPolls = 0;           // consecutive polls that found nothing (liveness check of the resident kernel)
+  uint32_t inFlightJobs = 0;         // published, result not consumed yet
+  uint32_t idleLimitS = 20;
   DevJob* jobs = nullptr;
   DevResult* results = nullptr;
   uint16_t* outPaths = nullptr;
@@ -137,9 +144,11 @@ struct Ring {
   // area, so they get their own pinned buffer, and only the first kSippSlots job slots are used
   static constexpr uint32_t kSippSlots = 512;
   bool sipp = false;
+  int kind = 0;                    // A* sessions: 0 = mixed kernel, 1 = A*-epsilon jobs only, 2 = A* jobs only
   uint32_t* sippCons = nullptr;
   uint32_t sippSlotWords = 0;      // capacity per slot the buffer was allocated with
   std::vector<int32_t> slotDimx;   // SIPP: grid width of the slot's job (cell -> x, y when unpacking)
+  std::vector<int32_t> slotInit;   // initial_cost (A*) / start_time (SIPP) of the slot's job
 };
 struct SessTicket {
   bool used = false;
@@ -393,8 +402,11 @@ bool packSipp(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, ConsSink& 
   d.ec_off = 0;
   d.n_agents_pad = 0;
   d.path_off = 0;
-  d.last_goal_constraint = -1;
-  // findSafeInterval(start, startTime = 0) (sipp.hpp:98-100,286-296): no interval -> search() returns false
+  // SIPP::search(..., startTime) (sipp.hpp:92-103): carried in the field the A* kernels use for m_lastGoalConstraint
+  const int32_t startTime = j.initial_cost;
+  if (startTime > static_cast<int32_t>(mrp::kGMask)) return false;
+  d.last_goal_constraint = startTime;
+  // findSafeInterval(start, startTime) (sipp.hpp:98-100,286-296): no interval -> search() returns false
   const int sc = j.start_y * mp.dimx + j.start_x;
   int startIv = -1;
   if (!cellIdx[sc]) {
@@ -402,7 +414,7 @@ bool packSipp(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, ConsSink& 
   } else {
     const Iv* v = sc0.pool.data() + sc0.first[cellIdx[sc] - 1];
     for (uint32_t k = 0; k < sc0.count[cellIdx[sc] - 1]; ++k)
-      if (v[k].s <= 0 && v[k].e >= 0) {
+      if (v[k].s <= startTime && v[k].e >= startTime) {
         startIv = static_cast<int>(k);
         break;
       }
@@ -421,6 +433,8 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   if (j.map_id < 0 || j.map_id >= static_cast<int32_t>(ctx->maps.size())) return false;
   const MapRec& mp = ctx->maps[j.map_id];
   if (j.algo != MRP_LL_ASTAR && j.algo != MRP_LL_ASTAR_EPS && j.algo != MRP_LL_SIPP) return false;
+  if (j.algo == MRP_LL_ASTAR_EPS && j.initial_cost != 0) return false;  // AStarEpsilon::search has no initialCost
+  if (j.initial_cost < 0) return false;
   auto inGrid = [&](int x, int y) { return x >= 0 && x < mp.dimx && y >= 0 && y < mp.dimy; };
   if (!inGrid(j.start_x, j.start_y)) return false;
   if (j.n_vertex_constraints < 0 || j.n_edge_constraints < 0 || j.n_agents < 0) return false;
@@ -557,7 +571,7 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
 
 // Device result -> caller's mrp_ll_result (+ statistics).
 void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool rejected, mrp_ll_result& r,
-                  bool sipp = false, int dimx = 0) {
+                  bool sipp = false, int dimx = 0, int32_t init = 0) {
   if (rejected) {
     r.status = MRP_LL_BAD_JOB;
     r.cost = r.fmin = r.n_states = 0;
@@ -568,6 +582,14 @@ void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool r
   r.status = d.status;
   r.cost = d.cost;
   r.fmin = d.fmin;
+  if (d.status == mrp::ST_OK && init != 0) {
+    if (sipp) {
+      r.cost = d.cost - init;  // sipp.hpp:103; fmin stays the A* f value (absolute)
+    } else {                   // a_star.hpp:64,78: every node but the start carries initialCost in g and f
+      r.cost = d.cost + init;
+      if (d.n_states > 1) r.fmin = d.fmin + init;
+    }
+  }
   r.n_states = d.status == mrp::ST_OK ? d.n_states : 0;
   r.expanded = d.expanded;
   r.tier = static_cast<int32_t>(d.tier);
@@ -804,7 +826,8 @@ int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t ldsNodes, int32_t ldsRows, i
 }
 
 // ---- session mode ---------------------------------------------------------------------------------------------
-static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp) {
+// kind (A* sessions): 0 = jobs of both A* algorithms, 1 = MRP_LL_ASTAR_EPS only, 2 = MRP_LL_ASTAR only
+static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind = 0) {
   if (!ctx) return MRP_LL_E_INVALID;
   Ring& g = ctx->ring;
   if (g.active) return MRP_LL_E_INVALID;
@@ -876,6 +899,7 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp) {
     }
     g.slotDimx.assign(R, 0);
   }
+  g.slotInit.assign(R, 0);
   ctx->sess.clear();
   ctx->sessFree.clear();
   auto devPtr = [&](void* hostPtr) {
@@ -907,7 +931,13 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp) {
   P.ring_size = g.Q[0];
   P.ring_size1 = g.Q[1];
   P.n_slots = Ring::kSlots;
-  P.ring_idle_limit_s = 20;
+  g.idleLimitS = 20;
+  if (const char* e = std::getenv("MRP_LL_IDLE_LIMIT_S")) g.idleLimitS = static_cast<uint32_t>(std::max(1, std::atoi(e)));  // test knob
+  P.ring_idle_limit_s = g.idleLimitS;
+  g.heartbeat = 0;
+  g.emptyPolls = 0;
+  g.inFlightJobs = 0;
+  __atomic_store_n(g.headWord + mrp::kHeartbeatWord, 0u, __ATOMIC_RELEASE);
   uint32_t ldsBytes = 0;
   rc = fillCommonParams(ctx, t, P, ldsBytes);
   if (rc != MRP_LL_SUCCESS) return rc;
@@ -921,7 +951,8 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp) {
   if (sipp)
     HIPCHK(ctx, mrp_ll_launch_sipp_persistent(&P, g.grid, t.stream));
   else
-    HIPCHK(ctx, mrp_ll_launch_persistent(&P, g.grid, ldsBytes, t.stream));
+    HIPCHK(ctx, mrp_ll_launch_persistent(&P, g.grid, ldsBytes, kind, t.stream));
+  g.kind = sipp ? 0 : kind;
   HIPCHK(ctx, hipEventRecord(g.ev1, t.stream));
   g.active = true;
   ctx->stats.launches += 1;
@@ -929,6 +960,11 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp) {
 }
 
 int mrp_ll_session_begin(mrp_ll_ctx* ctx, int32_t workgroups) { return sessionBegin(ctx, workgroups, false); }
+int mrp_ll_session_begin_algo(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups) {
+  if (algo == MRP_LL_SIPP) return sessionBegin(ctx, workgroups, true);
+  if (algo != MRP_LL_ASTAR && algo != MRP_LL_ASTAR_EPS) return MRP_LL_E_INVALID;
+  return sessionBegin(ctx, workgroups, false, algo == MRP_LL_ASTAR_EPS ? 1 : 2);
+}
 int mrp_ll_session_begin_sipp(mrp_ll_ctx* ctx, int32_t workgroups) { return sessionBegin(ctx, workgroups, true); }
 
 int mrp_ll_session_end(mrp_ll_ctx* ctx) {
@@ -956,9 +992,26 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
   return MRP_LL_SUCCESS;
 }
 
+// Every host call into a live session moves the heartbeat word the resident workgroups watch (ll_kernel.hip residentLoop).
+static inline void sessionBeat(Ring& g) {
+  __atomic_store_n(g.headWord + mrp::kHeartbeatWord, ++g.heartbeat, __ATOMIC_RELAXED);
+}
+
+// The resident kernel must still be running while jobs are in flight; checked every few thousand empty polls.
+static int sessionAlive(mrp_ll_ctx* ctx) {
+  Ring& g = ctx->ring;
+  if (g.inFlightJobs == 0 || (++g.emptyPolls & 0xFFF) != 0) return MRP_LL_SUCCESS;
+  if (hipEventQuery(g.ev1) != hipErrorNotReady) {
+    ctx->err = "session: the resident kernel has exited while jobs were in flight (idle limit or device fault)";
+    return MRP_LL_E_DEVICE;
+  }
+  return MRP_LL_SUCCESS;
+}
+
 static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results,
                          int32_t* ticketOut) {
   Ring& g = ctx->ring;
+  sessionBeat(g);
   const uint32_t nSlotsLane = g.sipp ? Ring::kSippSlots : (lane ? Ring::kSlots : Ring::kSlots - Ring::kReserve1);
   const uint32_t Q = g.Q[lane];
   const uint32_t qBase = lane ? g.Q[0] : 0;
@@ -1009,13 +1062,15 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
       ok = jobs[i].algo == MRP_LL_SIPP && packJob(ctx, jobs[i], csS, ps, d);
       if (ok) g.slotDimx[slot] = ctx->maps[jobs[i].map_id].dimx;
     } else {
-      ok = jobs[i].algo != MRP_LL_SIPP && packJob(ctx, jobs[i], cs, ps, d);
+      ok = jobs[i].algo != MRP_LL_SIPP && (g.kind == 0 || jobs[i].algo == (g.kind == 1 ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR)) &&
+           packJob(ctx, jobs[i], cs, ps, d);
     }
     if (!ok) {  // wrong kind of job for this session, or constraint list / table larger than a ring slot
       trivialRejectedJob(ctx, d);
       st.state[i] = 2;
     }
     g.jobs[slot] = d;
+    g.slotInit[slot] = ok ? jobs[i].initial_cost : 0;
     g.busy[slot] = 1;
     g.slotTicket[slot] = ti;
     g.slotJob[slot] = i;
@@ -1025,9 +1080,10 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
     g.tkSeq[qi] = g.slotGen[slot];
     st.slots[i] = slot;
     st.seq[i] = g.slotGen[slot];
-    __atomic_store_n(g.state + qi, (gen << 11) | slot, __ATOMIC_RELEASE);  // publish: the job data above is visible first
+    __atomic_store_n(g.state + qi, (gen << mrp::kRingSlotBits) | slot, __ATOMIC_RELEASE);  // publish: the job data above is visible first
   }
   g.head[lane] += static_cast<uint64_t>(nJobs);
+  g.inFlightJobs += static_cast<uint32_t>(nJobs);
   // after every ticket entry
   __atomic_store_n(g.headWord + 16 * lane, static_cast<uint32_t>(g.head[lane]), __ATOMIC_RELEASE);
   ctx->stats.pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - packT0).count();
@@ -1050,15 +1106,18 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
   }
   if (ticket < 0 || ticket >= static_cast<int32_t>(ctx->sess.size()) || !ctx->sess[ticket].used) return MRP_LL_E_INVALID;
   SessTicket& st = ctx->sess[ticket];
+  sessionBeat(g);
   for (int i = 0; i < st.n && st.remaining > 0; ++i) {
     if (st.state[i] == 1) continue;
     const uint32_t slot = st.slots[i];
     if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != st.seq[i]) continue;
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
-                 st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0);
+                 st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);
     st.state[i] = 1;
     st.remaining -= 1;
     g.busy[slot] = 0;
+    g.inFlightJobs -= 1;
+    g.emptyPolls = 0;
     g.freeSlots.push_back(slot);
   }
   *doneOut = st.remaining == 0 ? 1 : 0;
@@ -1075,22 +1134,24 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
   if (!g.active) return MRP_LL_E_INVALID;
   const uint32_t R = Ring::kSlots;
   int32_t n = 0;
+  sessionBeat(g);
   // drain the completion queue: entry k holds (k / R + 1) << 11 | slot once the k-th finished job has been published
   while (n < cap) {
     const uint32_t e = __atomic_load_n(g.compRing + (g.compCursor % R), __ATOMIC_ACQUIRE);
-    if ((e >> 11) != static_cast<uint32_t>(g.compCursor / R) + 1) break;
+    if ((e >> mrp::kRingSlotBits) != static_cast<uint32_t>(g.compCursor / R) + 1) break;
     g.compCursor += 1;
-    const uint32_t slot = e & 2047u;
+    const uint32_t slot = e & mrp::kRingSlotMask;
     if (!g.busy[slot]) continue;  // already consumed through mrp_ll_poll / mrp_ll_wait
     // ... and if the slot has been re-used since, this entry is stale: only the occupant's own done word counts
     if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != g.slotGen[slot]) continue;
     SessTicket& st = ctx->sess[g.slotTicket[slot]];
     const int32_t i = g.slotJob[slot];
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
-                 st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0);
+                 st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);
     st.state[i] = 1;
     st.remaining -= 1;
     g.busy[slot] = 0;
+    g.inFlightJobs -= 1;
     g.freeSlots.push_back(slot);
     if (st.remaining == 0) {
       st.used = false;
@@ -1099,7 +1160,11 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
     }
   }
   *nOut = n;
-  return MRP_LL_SUCCESS;
+  if (n != 0) {
+    g.emptyPolls = 0;
+    return MRP_LL_SUCCESS;
+  }
+  return sessionAlive(ctx);
 }
 
 static int sessionWait(mrp_ll_ctx* ctx, int32_t ticket) {
@@ -1152,6 +1217,9 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
       return MRP_LL_E_INVALID;
     }
     t.sipp = nSipp != 0;
+    int nEps = 0;
+    for (int i = 0; i < nJobs; ++i) nEps += jobs[i].algo == MRP_LL_ASTAR_EPS ? 1 : 0;
+    t.kind = t.sipp ? 0 : nEps == nJobs ? 1 : nEps == 0 ? 2 : 0;  // a one-algorithm batch runs the specialised kernel
   }
   t.jobs.clear();
   t.cons.clear();
@@ -1166,6 +1234,8 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
       if (static_cast<int>(t.jobDimx.size()) < nJobs) t.jobDimx.resize(nJobs);
       t.jobDimx[i] = ok ? static_cast<int32_t>(t.jobs.host[i].dimx) : 1;
     }
+    if (static_cast<int>(t.jobInit.size()) < nJobs) t.jobInit.resize(nJobs);
+    t.jobInit[i] = ok ? jobs[i].initial_cost : 0;
     if (cs.failed || ps.failed) t.allocFailed = true;
     if (!ok) {
       // rejected: give the device a trivially capped job and remember the rejection
@@ -1209,7 +1279,7 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
   if (t.sipp)
     HIPCHK(ctx, mrp_ll_launch_sipp(&P, grid, t.stream));
   else
-    HIPCHK(ctx, mrp_ll_launch(&P, grid, ldsBytes, t.stream));
+    HIPCHK(ctx, mrp_ll_launch(&P, grid, ldsBytes, t.kind, t.stream));
   HIPCHK(ctx, hipEventRecord(t.evK1, t.stream));
   ctx->stats.launches += 1;
   return MRP_LL_SUCCESS;
@@ -1254,7 +1324,7 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
   auto unpackT0 = std::chrono::steady_clock::now();
   for (int i = 0; i < t.nJobs; ++i)
     unpackResult(ctx, t.results.host[i], t.outPaths.host + static_cast<size_t>(i) * outStride, t.rejected[i] != 0,
-                 t.userResults[i], t.sipp, t.sipp ? t.jobDimx[i] : 0);
+                 t.userResults[i], t.sipp, t.sipp ? t.jobDimx[i] : 0, t.jobInit[i]);
   ctx->stats.unpack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - unpackT0).count();
   return MRP_LL_SUCCESS;
 }
@@ -1264,6 +1334,17 @@ int mrp_ll_sync_maps(mrp_ll_ctx* ctx) {
   if (ctx->ring.active) return MRP_LL_SUCCESS;  // in-session uploads are copied immediately
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return syncMaps(ctx);
+}
+
+int mrp_ll_release_maps(mrp_ll_ctx* ctx) {
+  if (!ctx) return MRP_LL_E_INVALID;
+  if (ctx->ring.active) return MRP_LL_E_BUSY;
+  for (const Ticket& t : ctx->tickets)
+    if (t.inFlight) return MRP_LL_E_BUSY;
+  ctx->maps.clear();
+  ctx->mapWords.clear();
+  ctx->mapsDirty = false;  // nothing to copy; the device buffer (and its capacity) is kept for the next uploads
+  return MRP_LL_SUCCESS;
 }
 
 int mrp_ll_search_batch(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results) {

@@ -51,7 +51,7 @@ class mrp_hl_sipp_solution(ctypes.Structure):
 
 EXPORTS = ["mrp_hl_solver_prioritized_sipp", "mrp_hl_solver_preload", "mrp_hl_solver_solve_preloaded",
            "mrp_hl_preloaded_free", "mrp_hl_solve_batch", "mrp_hl_solver_create", "mrp_hl_solver_destroy", "mrp_hl_solver_solve",
-           "mrp_hl_solver_ll_stats", "mrp_hl_solver_last_error", "mrp_hl_generate_instance"]
+           "mrp_hl_solver_ll_stats", "mrp_hl_solver_last_error", "mrp_hl_generate_instance", "mrp_hl_generate_instances"]
 
 _lib = None
 
@@ -97,6 +97,9 @@ def load_library(path: Optional[str] = None):
         lib.mrp_hl_generate_instance.restype = ctypes.c_int
         lib.mrp_hl_generate_instance.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int32, I32P, I32P, I32P]
+        lib.mrp_hl_generate_instances.restype = ctypes.c_int
+        lib.mrp_hl_generate_instances.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_int32, ctypes.c_int32, I32P, I32P, I32P]
         if path is not None:
             return lib
         _lib = lib
@@ -114,6 +117,41 @@ def generate_instance(seed: int, dimx: int = 32, dimy: int = 32, n_obstacles: in
     if rc != 0:
         raise ValueError("instance generation failed")
     return dict(dimx=dimx, dimy=dimy, obstacles=ob.tolist(), starts=st.tolist(), goals=go.tolist())
+
+
+class InstanceArrays:
+    """n instances of one shape as three contiguous int32 arrays (what mrp_hl_generate_instances fills): obstacles
+    [n][n_obstacles][2], starts / goals [n][n_agents][2].  Indexing gives the dict form used elsewhere."""
+
+    def __init__(self, dimx, dimy, obstacles, starts, goals):
+        self.dimx, self.dimy = dimx, dimy
+        self.obstacles, self.starts, self.goals = obstacles, starts, goals
+
+    def __len__(self):
+        return len(self.starts)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return InstanceArrays(self.dimx, self.dimy, self.obstacles[k], self.starts[k], self.goals[k])
+        return dict(dimx=self.dimx, dimy=self.dimy, obstacles=self.obstacles[k].tolist(), starts=self.starts[k].tolist(),
+                    goals=self.goals[k].tolist())
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+
+def generate_instances(seed0: int, n: int, dimx: int = 32, dimy: int = 32, n_obstacles: int = 204,
+                       n_agents: int = 10) -> InstanceArrays:
+    """Seeds seed0 .. seed0+n-1 in ONE native call (SURVEY.md §8d generator); identical to n generate_instance calls."""
+    lib = load_library()
+    ob = np.zeros((n, n_obstacles, 2), dtype=np.int32)
+    st = np.zeros((n, n_agents, 2), dtype=np.int32)
+    go = np.zeros((n, n_agents, 2), dtype=np.int32)
+    rc = lib.mrp_hl_generate_instances(seed0, n, dimx, dimy, n_obstacles, n_agents, ob.ctypes.data_as(I32P),
+                                       st.ctypes.data_as(I32P), go.ctypes.data_as(I32P))
+    if rc != 0:
+        raise ValueError("instance generation failed")
+    return InstanceArrays(dimx, dimy, ob, st, go)
 
 
 class BatchSolver:
@@ -149,6 +187,21 @@ class BatchSolver:
         keep = []
         plen: List[Optional[np.ndarray]] = []
         pxy: List[Optional[np.ndarray]] = []
+        if isinstance(instances, InstanceArrays) and not want_paths:
+            # bulk form: fill the descriptor array through one numpy view instead of n x 7 ctypes attribute stores
+            ob, st, go = (np.ascontiguousarray(a) for a in (instances.obstacles, instances.starts, instances.goals))
+            keep.append((ob, st, go))
+            rec = np.dtype([("dimx", "<i4"), ("dimy", "<i4"), ("n_obstacles", "<i4"), ("_p0", "<i4"),
+                            ("obstacles_xy", "<u8"), ("n_agents", "<i4"), ("_p1", "<i4"), ("starts_xy", "<u8"),
+                            ("goals_xy", "<u8")])
+            assert rec.itemsize == ctypes.sizeof(mrp_hl_instance)
+            view = np.frombuffer(cin, dtype=rec, count=n)
+            view["dimx"], view["dimy"] = instances.dimx, instances.dimy
+            view["n_obstacles"], view["n_agents"] = ob.shape[1], st.shape[1]
+            view["obstacles_xy"] = ob.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(ob.shape[1] * 8)
+            view["starts_xy"] = st.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(st.shape[1] * 8)
+            view["goals_xy"] = go.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(go.shape[1] * 8)
+            instances = ()
         for i, inst in enumerate(instances):
             ob = np.ascontiguousarray(np.asarray(inst["obstacles"], dtype=np.int32).reshape(-1, 2))
             st = np.ascontiguousarray(np.asarray(inst["starts"], dtype=np.int32).reshape(-1, 2))

@@ -37,7 +37,7 @@ class mrp_ll_job(ctypes.Structure):
                 ("n_agents", ctypes.c_int32), ("path_len", I32P), ("path_xy", ctypes.POINTER(I32P)),
                 ("max_expansions", ctypes.c_int64),
                 ("n_collision_locations", ctypes.c_int32), ("collision_xy", I32P), ("collision_count", I32P),
-                ("collision_intervals", I32P)]
+                ("collision_intervals", I32P), ("initial_cost", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class mrp_ll_result(ctypes.Structure):
@@ -58,7 +58,7 @@ class mrp_ll_stats(ctypes.Structure):
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
            "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version",
            "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any", "mrp_ll_submit_lane", "mrp_ll_sync_maps",
-           "mrp_ll_configure_tiers", "mrp_ll_session_begin_sipp"]
+           "mrp_ll_configure_tiers", "mrp_ll_session_begin_sipp", "mrp_ll_release_maps", "mrp_ll_session_begin_algo"]
 
 _lib = None
 
@@ -97,6 +97,8 @@ def load_library(path: Optional[str] = None):
     lib.mrp_ll_version.argtypes = []
     lib.mrp_ll_session_begin.restype = ctypes.c_int
     lib.mrp_ll_session_begin.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.mrp_ll_session_begin_algo.restype = ctypes.c_int
+    lib.mrp_ll_session_begin_algo.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
     lib.mrp_ll_session_end.restype = ctypes.c_int
     lib.mrp_ll_session_end.argtypes = [ctypes.c_void_p]
     lib.mrp_ll_poll.restype = ctypes.c_int
@@ -106,6 +108,8 @@ def load_library(path: Optional[str] = None):
                                        ctypes.POINTER(mrp_ll_result), I32P]
     lib.mrp_ll_sync_maps.restype = ctypes.c_int
     lib.mrp_ll_sync_maps.argtypes = [ctypes.c_void_p]
+    lib.mrp_ll_release_maps.restype = ctypes.c_int
+    lib.mrp_ll_release_maps.argtypes = [ctypes.c_void_p]
     lib.mrp_ll_poll_any.restype = ctypes.c_int
     lib.mrp_ll_poll_any.argtypes = [ctypes.c_void_p, I32P, ctypes.c_int32, I32P]
     if path is None:
@@ -127,6 +131,7 @@ class LLJob:
     ctx_paths: Sequence[Sequence[Sequence[int]]] = ()  # per agent [[x, y], ...]; [] = empty path
     max_expansions: int = -1
     collision_intervals: Sequence[Sequence[int]] = ()  # SIPP: [x, y, start, end] (grouped per location, in order)
+    initial_cost: int = 0  # A*: AStar::search(..., initialCost) a_star.hpp:64; SIPP: SIPP::search(..., startTime) sipp.hpp:92
 
 
 @dataclass
@@ -201,6 +206,7 @@ class LowLevelEngine:
             cj.path_len = plen.ctypes.data_as(I32P)
             cj.path_xy = ctypes.cast(pptr, ctypes.POINTER(I32P))
             cj.max_expansions = j.max_expansions
+            cj.initial_cost = j.initial_cost
             if j.collision_intervals:
                 locs, counts, ivs = [], [], []
                 for x, y, a, b in j.collision_intervals:  # consecutive entries of one location form one list
@@ -250,6 +256,10 @@ class LowLevelEngine:
     def session_begin(self, workgroups: int = 0):
         """Keep `workgroups` wavefronts resident and feed them through the host job ring (see mrp_ll.h)."""
         self._check(self._lib.mrp_ll_session_begin(self._h, workgroups), "mrp_ll_session_begin")
+
+    def session_begin_algo(self, algo: int, workgroups: int = 0):
+        """A session for jobs of one algorithm only (the specialised resident kernel)."""
+        self._check(self._lib.mrp_ll_session_begin_algo(self._h, algo, workgroups), "mrp_ll_session_begin_algo")
 
     def session_begin_sipp(self, workgroups: int = 0):
         """A session for MRP_LL_SIPP jobs (resident SIPP kernel); other jobs come back as BAD_JOB."""

@@ -44,11 +44,24 @@ def lib():
         _LIB.oracle_mapf_solve.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P,
                                            ctypes.c_int, I32P, I32P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                            I64P, I32P, I32P, ctypes.c_int]
+        _LIB.oracle_mapf_solve_batch.restype = ctypes.c_int64
+        _LIB.oracle_mapf_solve_batch.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, I32P, ctypes.c_int, I32P, I32P, ctypes.c_int64,
+                                                 ctypes.c_int, I64P]
         _LIB.oracle_ll_search.restype = ctypes.c_int
         _LIB.oracle_ll_search.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, I32P, ctypes.c_int, I32P, ctypes.c_int, I32P, I32P,
                                           ctypes.c_int64, I32P, I64P, I32P, I32P, ctypes.c_int]
+        _LIB.oracle_ll_search_init.restype = ctypes.c_int
+        _LIB.oracle_ll_search_init.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, I32P, ctypes.c_int, I32P, ctypes.c_int, I32P, I32P,
+                                               ctypes.c_int64, ctypes.c_int, I32P, I64P, I32P, I32P, ctypes.c_int]
+        _LIB.oracle_sipp_single_at.restype = ctypes.c_int
+        _LIB.oracle_sipp_single_at.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, I32P,
+                                               ctypes.c_int, I64P, I32P]
         _LIB.oracle_mapf_record.restype = ctypes.c_int64
         _LIB.oracle_mapf_record.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             I32P, ctypes.c_int, I32P, I32P, ctypes.c_int64, I32P, ctypes.c_int64,
@@ -97,7 +110,7 @@ def mapf_solve(algo, inst, w=1.0, cap_per_search=-1, cap_total=-1, cap_hl=-1, pa
 
 
 def ll_search(algo, inst_map, agent_idx, start, goal, vertex_constraints=(), edge_constraints=(), ctx_paths=(),
-              w=1.0, cap_expansions=-1, cap=1024):
+              w=1.0, cap_expansions=-1, cap=1024, initial_cost=0):
     """One low-level search. ctx_paths: list (per agent) of [[x,y]..] (empty list = empty path)."""
     obst, obst_p = _i32(np.asarray(inst_map["obstacles"], dtype=np.int32).reshape(-1, 2))
     vc, vc_p = _i32(np.asarray(vertex_constraints, dtype=np.int32).reshape(-1, 3))
@@ -109,10 +122,11 @@ def ll_search(algo, inst_map, agent_idx, start, goal, vertex_constraints=(), edg
     expanded = np.zeros(1, dtype=np.int64)
     states = np.zeros((cap, 3), dtype=np.int32)
     actions = np.zeros(cap, dtype=np.int32)
-    rc = lib().oracle_ll_search(algo, w, inst_map["dimx"], inst_map["dimy"], len(obst), obst_p, agent_idx, start[0],
-                                start[1], goal[0], goal[1], len(vc), vc_p, len(ec), ec_p, len(ctx_len), ctx_len_p,
-                                ctx_xy_p, cap_expansions, out.ctypes.data_as(I32P), expanded.ctypes.data_as(I64P),
-                                states.ctypes.data_as(I32P), actions.ctypes.data_as(I32P), cap)
+    rc = lib().oracle_ll_search_init(algo, w, inst_map["dimx"], inst_map["dimy"], len(obst), obst_p, agent_idx,
+                                     start[0], start[1], goal[0], goal[1], len(vc), vc_p, len(ec), ec_p, len(ctx_len),
+                                     ctx_len_p, ctx_xy_p, cap_expansions, initial_cost, out.ctypes.data_as(I32P),
+                                     expanded.ctypes.data_as(I64P), states.ctypes.data_as(I32P),
+                                     actions.ctypes.data_as(I32P), cap)
     n = int(out[3])
     assert n <= cap
     return dict(rc=rc, success=bool(out[0]), cost=int(out[1]), fmin=int(out[2]), expanded=int(expanded[0]),
@@ -199,3 +213,30 @@ def sipp_single(dimx, dimy, obstacles, start, goal, collision_intervals, cap=102
     n = lib().oracle_sipp_single(dimx, dimy, len(obst), obst_p, start[0], start[1], goal[0], goal[1], len(ci), ci_p,
                                  states.ctypes.data_as(I32P), cap, expanded.ctypes.data_as(I64P))
     return states[:n].tolist(), int(expanded[0])
+
+
+def sipp_single_at(dimx, dimy, obstacles, start, goal, collision_intervals, start_time=0, cap=1024):
+    """SIPP::search(start, wait, solution, startTime) (sipp.hpp:92): (states [x,y,t], expanded, cost, fmin)."""
+    obst, obst_p = _i32(np.asarray(obstacles, dtype=np.int32).reshape(-1, 2))
+    ci, ci_p = _i32(np.asarray(collision_intervals, dtype=np.int32).reshape(-1, 4))
+    states = np.zeros((cap, 3), dtype=np.int32)
+    expanded = np.zeros(1, dtype=np.int64)
+    cf = np.zeros(2, dtype=np.int32)
+    n = lib().oracle_sipp_single_at(dimx, dimy, len(obst), obst_p, start[0], start[1], goal[0], goal[1], len(ci), ci_p,
+                                    start_time, states.ctypes.data_as(I32P), cap, expanded.ctypes.data_as(I64P),
+                                    cf.ctypes.data_as(I32P))
+    return states[:n].tolist(), int(expanded[0]), int(cf[0]), int(cf[1])
+
+
+def mapf_solve_batch(algo, dimx, dimy, obstacles, starts, goals, w=1.0, cap_total=-1, n_threads=1):
+    """n instances of one shape (int32 arrays [n][n_obst][2], [n][n_agents][2] x 2), one per thread on n_threads.
+    Returns (per-instance int64 array [n][6] = rc, cost, makespan, hl, ll, elapsed_ns ; pool wall seconds)."""
+    ob = np.ascontiguousarray(obstacles, dtype=np.int32)
+    st = np.ascontiguousarray(starts, dtype=np.int32)
+    go = np.ascontiguousarray(goals, dtype=np.int32)
+    n = len(st)
+    out = np.zeros((n, 6), dtype=np.int64)
+    wall = lib().oracle_mapf_solve_batch(algo, w, n, dimx, dimy, ob.shape[1], ob.ctypes.data_as(I32P), st.shape[1],
+                                         st.ctypes.data_as(I32P), go.ctypes.data_as(I32P), cap_total, n_threads,
+                                         out.ctypes.data_as(I64P))
+    return out, wall / 1e9

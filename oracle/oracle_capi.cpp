@@ -4,6 +4,8 @@
 #include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "grid2d_restated.hpp"
@@ -82,16 +84,70 @@ int oracle_mapf_solve(int algo, float w, int dimx, int dimy, int nObst, const in
   return rc;
 }
 
+// The same for n instances of one shape (the arrays mrp_hl_generate_instances fills), one instance per thread on
+// `nThreads` threads (the reference is single-threaded: this is "one ./ecbs process per core").
+// perInst[k][0..5] = rc, cost, makespan, highLevelExpanded, lowLevelExpanded, elapsed_ns (search() only)
+// Returns the wall-clock nanoseconds of the whole pool.
+int64_t oracle_mapf_solve_batch(int algo, float w, int n, int dimx, int dimy, int nObst, const int32_t* obstXY,
+                                int nAgents, const int32_t* startsXY, const int32_t* goalsXY, int64_t capTotal,
+                                int nThreads, int64_t* perInst) {
+  std::atomic<int> next(0);
+  auto t0 = std::chrono::steady_clock::now();
+  auto work = [&]() {
+    for (;;) {
+      const int k = next.fetch_add(1, std::memory_order_relaxed);
+      if (k >= n) return;
+      int64_t st[6];
+      const int rc = oracle_mapf_solve(algo, w, dimx, dimy, nObst, obstXY + static_cast<int64_t>(k) * nObst * 2, nAgents,
+                                       startsXY + static_cast<int64_t>(k) * nAgents * 2,
+                                       goalsXY + static_cast<int64_t>(k) * nAgents * 2, -1, capTotal, -1, st, nullptr,
+                                       nullptr, 0);
+      int64_t* o = perInst + static_cast<int64_t>(k) * 6;
+      o[0] = rc;
+      o[1] = st[0];
+      o[2] = st[1];
+      o[3] = st[2];
+      o[4] = st[3];
+      o[5] = st[4];
+    }
+  };
+  if (nThreads <= 1) {
+    work();
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nThreads; ++t) th.emplace_back(work);
+    for (auto& x : th) x.join();
+  }
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+}
+
 // One low-level search with everything explicit (the same information a mrp_ll_job carries).
 // algo 0 = AStar (CBS low level), 1 = AStarEpsilon (ECBS low level).
 // ctxLen[nCtx] = number of states of every agent's path in the CT node (0 = empty, skipped);
 // ctxXY = concatenation of the paths, [sum(ctxLen)][2].
 // out[0..3] = success, cost, fmin, n_states ; statesTXY [cap][3] ; actions [cap] (enum 0..4 = Up,Down,Left,Right,Wait)
 // Return 0, or -1 if expansion cap exceeded.
+// `initialCost`: AStar::search's third argument (a_star.hpp:63-64); AStarEpsilon::search has none, so it is only
+// applied when algo == 0.
+int oracle_ll_search_init(int algo, float w, int dimx, int dimy, int nObst, const int32_t* obstXY, int agentIdx,
+                          int startX, int startY, int goalX, int goalY, int nVC, const int32_t* vc, int nEC,
+                          const int32_t* ec, int nCtx, const int32_t* ctxLen, const int32_t* ctxXY,
+                          int64_t capExpansions, int initialCost, int32_t* out, int64_t* expanded, int32_t* statesTXY,
+                          int32_t* actions, int cap);
+
 int oracle_ll_search(int algo, float w, int dimx, int dimy, int nObst, const int32_t* obstXY, int agentIdx,
                      int startX, int startY, int goalX, int goalY, int nVC, const int32_t* vc, int nEC,
                      const int32_t* ec, int nCtx, const int32_t* ctxLen, const int32_t* ctxXY, int64_t capExpansions,
                      int32_t* out, int64_t* expanded, int32_t* statesTXY, int32_t* actions, int cap) {
+  return oracle_ll_search_init(algo, w, dimx, dimy, nObst, obstXY, agentIdx, startX, startY, goalX, goalY, nVC, vc, nEC,
+                               ec, nCtx, ctxLen, ctxXY, capExpansions, 0, out, expanded, statesTXY, actions, cap);
+}
+
+int oracle_ll_search_init(int algo, float w, int dimx, int dimy, int nObst, const int32_t* obstXY, int agentIdx,
+                          int startX, int startY, int goalX, int goalY, int nVC, const int32_t* vc, int nEC,
+                          const int32_t* ec, int nCtx, const int32_t* ctxLen, const int32_t* ctxXY,
+                          int64_t capExpansions, int initialCost, int32_t* out, int64_t* expanded, int32_t* statesTXY,
+                          int32_t* actions, int cap) {
   int nGoals = std::max(nCtx, agentIdx + 1);
   std::vector<int32_t> goals(2 * nGoals, 0);
   goals[2 * agentIdx] = goalX;
@@ -135,7 +191,7 @@ int oracle_ll_search(int algo, float w, int dimx, int dimy, int nObst, const int
   try {
     if (algo == 0) {
       AStar<State, Action, int, Shell, StateHash> ll(shell);
-      ok = ll.search(State(0, startX, startY), plan);
+      ok = ll.search(State(0, startX, startY), plan, initialCost);
     } else {
       AStarEpsilon<State, Action, int, Shell, StateHash> ll(shell, w);
       ok = ll.search(State(0, startX, startY), plan);
@@ -269,8 +325,19 @@ int oracle_prioritized_sipp(int dimx, int dimy, int nObst, const int32_t* obstXY
 }
 
 // ---- example/sipp.cpp: one agent, collision intervals given as [n][4] = x, y, start, end ----------------
+// `startTime`: SIPP::search's fourth argument (sipp.hpp:92); costFmin[0..1] receive solution.cost / solution.fmin.
+int oracle_sipp_single_at(int dimx, int dimy, int nObst, const int32_t* obstXY, int sx, int sy, int gx, int gy, int nCI,
+                          const int32_t* ci, int startTime, int32_t* statesXYT, int cap, int64_t* expanded,
+                          int32_t* costFmin);
+
 int oracle_sipp_single(int dimx, int dimy, int nObst, const int32_t* obstXY, int sx, int sy, int gx, int gy, int nCI,
                        const int32_t* ci, int32_t* statesXYT, int cap, int64_t* expanded) {
+  return oracle_sipp_single_at(dimx, dimy, nObst, obstXY, sx, sy, gx, gy, nCI, ci, 0, statesXYT, cap, expanded, nullptr);
+}
+
+int oracle_sipp_single_at(int dimx, int dimy, int nObst, const int32_t* obstXY, int sx, int sy, int gx, int gy, int nCI,
+                          const int32_t* ci, int startTime, int32_t* statesXYT, int cap, int64_t* expanded,
+                          int32_t* costFmin) {
   std::vector<uint8_t> mask(static_cast<std::size_t>(dimx) * dimy, 0);
   for (int i = 0; i < nObst; ++i) mask[obstXY[2 * i + 1] * dimx + obstXY[2 * i]] = 1;
   sipp::GridEnv env(dimx, dimy, mask, sipp::Cell{gx, gy});
@@ -284,8 +351,12 @@ int oracle_sipp_single(int dimx, int dimy, int nObst, const int32_t* obstXY, int
   }
   for (const auto& c : order) planner.setCollisionIntervals(c, byCell[c]);
   sipp::TimedPlan sol;
-  bool ok = planner.search(sipp::Cell{sx, sy}, sol);
+  bool ok = planner.search(sipp::Cell{sx, sy}, sol, startTime);
   if (expanded) *expanded = planner.expanded();
+  if (costFmin) {
+    costFmin[0] = sol.cost;
+    costFmin[1] = sol.fmin;
+  }
   if (!ok) return 0;
   int n = static_cast<int>(sol.states.size());
   for (int k = 0; k < n && k < cap; ++k) {

@@ -94,7 +94,7 @@ def bench_instances():
     sel = [("32x32_obst204", "map_32by32_obst204_agents%d_ex%d.yaml", n, range(cnt))
            for n, cnt in [(10, 100), (20, 10), (30, 10), (50, 20), (100, 10)]]
     sel += [("8x8_obst12", "map_8by8_obst12_agents%d_ex%d.yaml", n, range(cnt))
-            for n, cnt in [(2, 10), (4, 10), (5, 10), (6, 10), (8, 10), (10, 4)]]
+            for n, cnt in [(2, 10), (4, 10), (5, 10), (6, 10), (8, 10), (10, 4), (12, 4), (16, 4), (20, 4)]]
     for d, pat, n, rng in sel:
         for k in rng:
             name = pat % (n, k)

@@ -107,12 +107,17 @@ int mrp_ll_poll_any(mrp_ll_ctx* c, int32_t* tickets, int32_t cap, int32_t* n) {
 }
 int mrp_ll_wait(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
 int mrp_ll_sync_maps(mrp_ll_ctx*) { return MRP_LL_SUCCESS; }
+int mrp_ll_release_maps(mrp_ll_ctx* c) {
+  c->maps.clear();
+  return MRP_LL_SUCCESS;
+}
 int mrp_ll_configure_tiers(mrp_ll_ctx*, int32_t, int32_t, int32_t, int32_t* occ) {
   if (occ) *occ = 4;
   return MRP_LL_SUCCESS;
 }
 int mrp_ll_session_begin(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
 int mrp_ll_session_begin_sipp(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
+int mrp_ll_session_begin_algo(mrp_ll_ctx*, int32_t, int32_t) { return MRP_LL_SUCCESS; }
 int mrp_ll_session_end(mrp_ll_ctx*) { return MRP_LL_SUCCESS; }
 int mrp_ll_poll(mrp_ll_ctx*, int32_t, int32_t* done) {
   *done = 1;  // the mock runs every job synchronously inside mrp_ll_submit

@@ -75,11 +75,37 @@ def test_cbs_and_ecbs_8x8(solver, bench_instances, oracle_expected):
         assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
             hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"]), n
         assert _digest(r["paths"]) == e["digest"], n
-    res, _ = solver.solve([bench_instances[n] for n in names], algo=hl.ECBS, w=1.3)
+    # ECBS on every 8x8 fixture up to 20 agents, with the cap the vectors were produced with: instances the oracle could
+    # not finish must come back as CAP, the others exactly
+    res, _ = solver.solve([bench_instances[n] for n in names], algo=hl.ECBS, w=1.3, max_ll_expansions=300_000)
     for n, r in zip(names, res):
         e = oracle_expected[n]["ecbs_w1.3"]
-        assert (r["cost"], r["hl_expanded"], r["ll_expanded"], _digest(r["paths"])) == (
-            e["cost"], e["hl"], e["ll"], e["digest"]), n
+        if e["rc"] == 1:
+            assert (r["status"], r["cost"], r["hl_expanded"], r["ll_expanded"], _digest(r["paths"])) == (
+                hl.SOLVED, e["cost"], e["hl"], e["ll"], e["digest"]), n
+        else:
+            assert r["status"] == hl.CAP, n
+
+
+def test_cbs_8x8_up_to_20_agents(solver, bench_instances, oracle_expected):
+    """BASELINE.json configs[2]: CBS on benchmark/8x8_obst12 with agents up to 20, under the cap of the golden vectors
+    (300 000 low-level expansions per instance).  Solved on the CPU => identical on the GPU; capped there => CAP here."""
+    from libmultirobotplanning_amd import hl
+    names = [n for n in sorted(bench_instances) if "8by8" in n and
+             int(n.split("agents")[1].split("_")[0]) >= 10]
+    assert {int(n.split("agents")[1].split("_")[0]) for n in names} == {10, 12, 16, 20}
+    res, _ = solver.solve([bench_instances[n] for n in names], algo=hl.CBS, max_ll_expansions=300_000)
+    n_solved = 0
+    for n, r in zip(names, res):
+        e = oracle_expected[n]["cbs"]
+        if e["rc"] == 1:
+            n_solved += 1
+            assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"], _digest(r["paths"])) == (
+                hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"], e["digest"]), n
+        else:
+            assert r["status"] == hl.CAP, n
+            assert r["ll_expanded"] > 300_000
+    assert n_solved >= 5
 
 
 def test_caps_are_reported(solver, bench_instances, oracle_expected):

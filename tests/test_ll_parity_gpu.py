@@ -385,3 +385,139 @@ def test_sipp_reference_case_and_random_jobs(engine, oracle_mod, ref_tests):
 def test_stats_report_kernel_time(engine):
     st = engine.stats()
     assert st["launches"] > 0 and st["kernel_ms"] > 0 and st["expansions"] > 0
+
+
+def test_initial_cost_and_start_time(engine, oracle_mod, ref_tests):
+    """The fork's extra search arguments: AStar::search(..., initialCost) (a_star.hpp:63-64,78,100) and
+    SIPP::search(..., startTime) (sipp.hpp:92-103), against the oracle's restatement of both."""
+    import random
+    from libmultirobotplanning_amd import ll
+    rng = random.Random(11)
+    dim = 12
+    obst = [list(c) for c in {(rng.randrange(dim), rng.randrange(dim)) for _ in range(25)}]
+    m = dict(dimx=dim, dimy=dim, obstacles=obst)
+    mid = engine.upload_map(dim, dim, obst)
+    free = [[x, y] for x in range(dim) for y in range(dim) if [x, y] not in obst]
+    jobs, specs = [], []
+    for case in range(60):
+        st = rng.choice(free)
+        go = st if case % 10 == 0 else rng.choice(free)   # a start that already is the goal keeps fmin = h(start)
+        c0 = rng.choice([0, 1, 7, 100])
+        vcs = [[rng.randrange(0, 12), *rng.choice(free)] for _ in range(rng.randrange(0, 6))]
+        specs.append((st, go, c0, vcs))
+        jobs.append(ll.LLJob(map_id=mid, algo=ll.ASTAR, start=st, goal=go, vertex_constraints=vcs, initial_cost=c0,
+                             max_expansions=20000))
+    res = engine.search_batch(jobs)
+    n_ok = 0
+    for (st, go, c0, vcs), r in zip(specs, res):
+        o = oracle_mod.ll_search(oracle_mod.ASTAR, m, 0, st, go, vertex_constraints=vcs, initial_cost=c0,
+                                 cap_expansions=20000)
+        if o["rc"] == -1:
+            assert r.status == ll.CAP_EXPANSIONS
+            continue
+        assert r.success == o["success"] and r.expanded == o["expanded"], (st, go, c0)
+        if r.success:
+            n_ok += 1
+            assert (r.cost, r.fmin) == (o["cost"], o["fmin"]), (st, go, c0)
+            assert r.states == o["states"]
+    assert n_ok > 30
+    # A*-epsilon has no such argument: rejected, not ignored
+    bad = engine.search_batch([ll.LLJob(map_id=mid, algo=ll.ASTAR_EPS, start=free[0], goal=free[1], w=1.3, initial_cost=3)])
+    assert bad[0].status == ll.BAD_JOB
+
+    # SIPP start times
+    jobs, specs = [], []
+    for case in range(80):
+        st, go = rng.choice(free), rng.choice(free)
+        cis = []
+        for c in rng.sample(free, rng.randrange(0, 25)):
+            t = rng.randrange(0, 30)
+            for _ in range(rng.randrange(1, 3)):
+                a = t + rng.randrange(0, 6)
+                b = a + rng.randrange(0, 5)
+                cis.append([c[0], c[1], a, b])
+                t = b + 2
+        t0 = rng.choice([0, 0, 3, 11, 40])
+        specs.append((st, go, cis, t0))
+        jobs.append(ll.LLJob(map_id=mid, algo=ll.SIPP, start=st, goal=go, collision_intervals=cis, initial_cost=t0,
+                             max_expansions=20000))
+    res = engine.search_batch(jobs)
+    n_ok = 0
+    for (st, go, cis, t0), r in zip(specs, res):
+        o_states, o_exp, o_cost, o_fmin = oracle_mod.sipp_single_at(dim, dim, obst, st, go, cis, start_time=t0)
+        if r.status == ll.CAP_EXPANSIONS:
+            continue
+        assert r.success == (len(o_states) > 0), (st, go, t0)
+        if r.success:
+            n_ok += 1
+            assert [[x, y, t] for t, x, y in r.states] == o_states, (st, go, cis, t0)
+            assert (r.expanded, r.cost, r.fmin) == (o_exp, o_cost, o_fmin), (st, go, t0)
+    assert n_ok > 30
+
+
+def test_specialised_sessions_and_liveness(oracle_mod, bench_instances):
+    """mrp_ll_session_begin_algo: the per-algorithm resident kernels give the mixed kernel's results and reject the
+    other kind; a caller that keeps polling may pause between submits longer than the idle limit; a caller that goes
+    silent loses the resident kernel and is TOLD so (MRP_LL_E_DEVICE) instead of spinning."""
+    import ctypes
+    import os
+    import time
+    from libmultirobotplanning_amd import ll
+    name = "map_32by32_obst204_agents10_ex1"
+    inst = bench_instances[name]
+    _, calls = oracle_mod.mapf_record(oracle_mod.ECBS, inst, w=1.3)
+    _, calls_cbs = oracle_mod.mapf_record(oracle_mod.CBS, bench_instances["map_8by8_obst12_agents4_ex0"])
+    inst8 = bench_instances["map_8by8_obst12_agents4_ex0"]
+    os.environ["MRP_LL_IDLE_LIMIT_S"] = "1"
+    eng = ll.LowLevelEngine(device=0, n_tickets=1, slots=64)
+    try:
+        mid = eng.upload_map(inst["dimx"], inst["dimy"], inst["obstacles"])
+        mid8 = eng.upload_map(inst8["dimx"], inst8["dimy"], inst8["obstacles"])
+        eps_jobs = [ll.LLJob(map_id=mid, algo=ll.ASTAR_EPS, start=inst["starts"][c["agent"]], goal=inst["goals"][c["agent"]],
+                             agent_idx=c["agent"], w=1.3, vertex_constraints=c["vertex_constraints"],
+                             edge_constraints=c["edge_constraints"], ctx_paths=c["ctx_paths"]) for c in calls]
+        cbs_jobs = [ll.LLJob(map_id=mid8, algo=ll.ASTAR, start=inst8["starts"][c["agent"]], goal=inst8["goals"][c["agent"]],
+                             agent_idx=c["agent"], vertex_constraints=c["vertex_constraints"],
+                             edge_constraints=c["edge_constraints"]) for c in calls_cbs]
+
+        def check(res, cs):
+            for c, r in zip(cs, res):
+                assert (r.success, r.expanded) == (c["success"], c["expanded"])
+                if r.success:
+                    assert (r.cost, r.fmin, [s[1:] for s in r.states]) == (c["cost"], c["fmin"], c["states"])
+
+        eng.session_begin_algo(ll.ASTAR_EPS, 32)
+        try:
+            res = eng.search_batch(eps_jobs + cbs_jobs[:1])
+            assert res[-1].status == ll.BAD_JOB
+            check(res[:-1], calls)
+            # pause longer than the idle limit, but keep polling: the session stays alive
+            tk = (ctypes.c_int32 * 8)()
+            n = ctypes.c_int32(0)
+            t0 = time.time()
+            while time.time() - t0 < 2.5:
+                assert eng._lib.mrp_ll_poll_any(eng._h, tk, 8, ctypes.byref(n)) == 0
+                time.sleep(0.05)
+            check(eng.search_batch(eps_jobs), calls)
+        finally:
+            eng.session_end()
+        eng.session_begin_algo(ll.ASTAR, 32)
+        try:
+            res = eng.search_batch(cbs_jobs + eps_jobs[:1])
+            assert res[-1].status == ll.BAD_JOB
+            check(res[:-1], calls_cbs)
+            # go silent for longer than the idle limit: the resident kernel leaves, and the next wait says so
+            time.sleep(3.5)
+            with pytest.raises(RuntimeError):
+                eng.search_batch(cbs_jobs)
+        finally:
+            eng.session_end()
+        # the context is usable again afterwards
+        eng.session_begin_algo(ll.ASTAR, 32)
+        try:
+            check(eng.search_batch(cbs_jobs), calls_cbs)
+        finally:
+            eng.session_end()
+    finally:
+        del os.environ["MRP_LL_IDLE_LIMIT_S"]
+        eng.close()
