@@ -157,9 +157,9 @@ int mrp_ll_sync_maps(mrp_ll_ctx* ctx);
  * one context across many batches of instances.  MRP_LL_E_BUSY while a batch or a session is in flight. */
 int mrp_ll_release_maps(mrp_ll_ctx* ctx);
 
-/* Geometry of the LDS-resident fast tier for the launches / sessions that follow: node capacity, (time, cell) bitmap
- * rows and bytes of the focal path table kept in LDS per resident search (0 = keep the current value; lds_nodes < 0
- * disables the tier).  Smaller tiers let more searches share a CU (occupancy = 160 KiB / tier bytes) at the price of
+/* Geometry of the LDS-resident fast tier for the launches / sessions that follow: node capacity (at most 512), (time,
+ * cell) bitmap rows (at most 64) and bytes of the focal path table kept in LDS per resident search (0 = keep the
+ * current value; lds_nodes < 0 disables the tier).  Smaller tiers let more searches share a CU (occupancy = 160 KiB / tier bytes) at the price of
  * more searches overflowing into the HBM tier; results never depend on it.  *occupancy_out (may be NULL) receives the
  * resulting resident searches per CU.  MRP_LL_E_BUSY while a batch or a session is in flight. */
 int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t lds_nodes, int32_t lds_rows, int32_t lds_path_bytes,

@@ -682,9 +682,18 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   const int32_t agentsPad = (maxAgents + 15) & ~15;
   int32_t occupancy = 4;
   if (s->llOpt.lds_nodes == 0 && opt.mode != 1) {  // the caller did not choose a geometry: pick one for this batch
-    const int32_t pathBytes = opt.algo == MRP_HL_ECBS ? std::min(16384, std::max(2048, agentsPad * 2 * 64)) : 32;
+    int32_t pathBytes = opt.algo == MRP_HL_ECBS ? std::min(16384, std::max(2048, agentsPad * 2 * 64)) : 32;
+    int32_t tierNodes = 400, tierRows = 48;
+    if (const char* e = std::getenv("MRP_HL_TIER")) {  // tuning knob: "nodes,rows,pathBytes"
+      int a = 0, b = 0, c = 0;
+      if (std::sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
+        tierNodes = a;
+        tierRows = b;
+        if (opt.algo == MRP_HL_ECBS) pathBytes = c;
+      }
+    }
     for (int32_t t = 0; t < nThreads; ++t)
-      if (mrp_ll_configure_tiers(s->engines[t], 400, 48, pathBytes, &occupancy) != MRP_LL_SUCCESS) {
+      if (mrp_ll_configure_tiers(s->engines[t], tierNodes, tierRows, pathBytes, &occupancy) != MRP_LL_SUCCESS) {
         s->err = std::string("mrp_ll_configure_tiers: ") + mrp_ll_last_error(s->engines[t]);
         return MRP_LL_E_DEVICE;
       }

@@ -68,32 +68,129 @@ DEVI uint64_t rfl64(uint64_t v) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-// ---- entry packing ---------------------------------------------------------------------------------------------
-DEVI uint64_t packEntry(uint32_t fh, uint32_t f, uint32_t g, uint32_t id) {
-  const uint32_t key = ((kFhMax - fh) << (kGBits + kFBits)) | ((kFMax - f) << kGBits) | g;
-  return ((uint64_t)key << 32) | id;
+DEVI uint32_t waveShr1(uint32_t v) {  // lane i receives lane i-1's value (lane 0 keeps its own)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);
 }
-DEVI uint32_t entryKey(uint64_t e) { return (uint32_t)(e >> 32); }
-DEVI int32_t entryF(uint64_t e) { return (int32_t)(kFMax - ((entryKey(e) >> kGBits) & kFMax)); }
-DEVI uint32_t entryId(uint64_t e) { return (uint32_t)e; }
-DEVI uint32_t openKey(uint64_t e) { return entryKey(e) & kOpenKeyMask; }
 
-// ---- memory tiers ----------------------------------------------------------------------------------------------
-// AS = 3: LDS, AS = 1: global (HBM arena).  Heap arrays are stored with a one-element bias so that the two children
-// (2i+1, 2i+2) of any node form one 16-byte aligned pair -> a single ds_read_b128 / global_load_dwordx4.
-template <int AS>
+// ---- memory tiers and their record formats ---------------------------------------------------------------------
+// A heap entry carries its sort key and the node id.  A larger key is a BETTER node in the reference's orders:
+//   open  (a_star_epsilon.hpp:312-323, a_star.hpp:168-179): lowest f, then highest g      -> keyOpen
+//   focal (a_star_epsilon.hpp:346-366): lowest focalH, then lowest f, then highest g      -> keyFocal
+// Entries with equal keys compare EQUAL (the id never takes part), exactly like the reference's comparators; which of
+// two equal entries comes out first is decided by the heap layout, which the kernels replay verbatim.
+//
+// TierHbm (global memory, the search's arena slot; also what SIPP uses): 64-bit entries as laid out in ll_device.h,
+//   16-byte node records {x | y<<8 | t<<16 | action<<27, parent id, focalH, position in the open array}.
+// TierLds (LDS, the fast tier): everything a small search needs in ~11 KB so that twelve searches share a CU:
+//   32-bit entries  [31:22] 1023 - focalH   [21:15] 127 - f   [14:9] g   [8:0] node id
+//   one word per node  x | y<<8 | parent<<16,  plus a halfword per node for its position in the open array
+//   (focalH, f and g of a node are read from its heap entry, never from the node).
+//   A search stays in this tier while it has <= 512 nodes, <= 256 open entries, t < 64, f < 128 and focalH < 1024;
+//   beyond any of these it migrates to TierHbm (runJob), records converted one to one.
+// Heap arrays are stored with a one-element bias so that the two children (2i+1, 2i+2) of any node form one naturally
+// aligned pair -> a single ds_read_b64 / global_load_dwordx4.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct TierHbm {
+  static constexpr int AS = 1;
+  typedef uint64_t E;
+  typedef u64x2 Pair;
+  static constexpr uint32_t kFhCap = kFhMax;
+  DEVI static E pack(uint32_t fh, uint32_t f, uint32_t g, uint32_t id) {
+    const uint32_t key = ((kFhMax - fh) << (kGBits + kFBits)) | ((kFMax - f) << kGBits) | g;
+    return ((uint64_t)key << 32) | id;
+  }
+  DEVI static uint32_t keyFocal(E e) { return (uint32_t)(e >> 32); }
+  DEVI static uint32_t keyOpen(E e) { return (uint32_t)(e >> 32) & kOpenKeyMask; }
+  DEVI static uint32_t id(E e) { return (uint32_t)e; }
+  DEVI static uint32_t f(E e) { return kFMax - ((keyFocal(e) >> kGBits) & kFMax); }
+  DEVI static uint32_t g(E e) { return keyFocal(e) & kGMask; }
+  DEVI static uint32_t fh(E e) { return kFhMax - (keyFocal(e) >> (kGBits + kFBits)); }
+  // walk-queue entry of the ordered walk: the open key of an open-array element and its index
+  DEVI static E aux(uint32_t openKey, uint32_t idx) { return ((uint64_t)openKey << 32) | idx; }
+  DEVI static uint32_t auxIdx(E e) { return (uint32_t)e; }
+  DEVI static E first(E v) { return rfl64(v); }
+  DEVI static E fromLane(E v, uint32_t srcLane) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, srcLane);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), srcLane);
+    return ((uint64_t)hi << 32) | lo;
+  }
+  DEVI static E shr1(E v) { return ((uint64_t)waveShr1((uint32_t)(v >> 32)) << 32) | waveShr1((uint32_t)v); }
+};
+
+struct TierLds {
+  static constexpr int AS = 3;
+  typedef uint32_t E;
+  typedef u32x2 Pair;
+  static constexpr uint32_t kIdBits = 9, kGB = 6, kFB = 7, kFhB = 10;
+  static constexpr uint32_t kMaxNodes = 1u << kIdBits, kMaxRows = 1u << kGB, kFCap = (1u << kFB) - 1;
+  static constexpr uint32_t kFhCap = (1u << kFhB) - 1;
+  DEVI static E pack(uint32_t fh, uint32_t f, uint32_t g, uint32_t id) {
+    return ((kFhCap - fh) << (kIdBits + kGB + kFB)) | ((kFCap - f) << (kIdBits + kGB)) | (g << kIdBits) | id;
+  }
+  DEVI static uint32_t keyFocal(E e) { return e >> kIdBits; }
+  DEVI static uint32_t keyOpen(E e) { return (e >> kIdBits) & ((1u << (kGB + kFB)) - 1u); }
+  DEVI static uint32_t id(E e) { return e & (kMaxNodes - 1u); }
+  DEVI static uint32_t f(E e) { return kFCap - ((e >> (kIdBits + kGB)) & kFCap); }
+  DEVI static uint32_t g(E e) { return (e >> kIdBits) & (kMaxRows - 1u); }
+  DEVI static uint32_t fh(E e) { return kFhCap - (e >> (kIdBits + kGB + kFB)); }
+  DEVI static E aux(uint32_t openKey, uint32_t idx) { return (openKey << kIdBits) | idx; }  // idx < 256
+  DEVI static uint32_t auxIdx(E e) { return e & (kMaxNodes - 1u); }
+  DEVI static E first(E v) { return rfl(v); }
+  DEVI static E fromLane(E v, uint32_t srcLane) { return __builtin_amdgcn_readlane(v, srcLane); }
+  DEVI static E shr1(E v) { return waveShr1(v); }
+};
+
+template <class T>
 struct Mem {
-  typedef __attribute__((address_space(AS))) uint64_t* P64;
-  typedef __attribute__((address_space(AS))) uint32_t* P32;
-  typedef __attribute__((address_space(AS))) u32x4* PNode;
-  typedef __attribute__((address_space(AS))) u64x2* PPair;
-  PNode nodes;   // x | y<<8 | t<<16 | act<<27 ; parent id ; focalH ; position in the open array
-  P64 open;      // biased: element i at open[i] (pointer already includes the +1 bias)
-  P64 focal;
-  P64 aux;       // std::priority_queue of the ordered walk: (openKey << 32) | open index
+  typedef typename T::E E;
+  typedef __attribute__((address_space(T::AS))) E* PE;
+  typedef __attribute__((address_space(T::AS))) typename T::Pair* PPair;
+  typedef __attribute__((address_space(T::AS))) uint32_t* P32;
+  typedef __attribute__((address_space(T::AS))) uint16_t* P16;
+  typedef __attribute__((address_space(T::AS))) u32x4* PNode4;
+  P32 nodes;     // TierLds: one word per node; TierHbm: four words per node
+  P16 pos;       // TierLds only: position of the node's entry in the open array
+  PE open;       // biased: element i at open[i] (the pointer already includes the +1 bias)
+  PE focal;
+  PE aux;        // std::priority_queue of the ordered walk
   P32 bits;      // (time, cell) bitmap: 1 = obstacle | vertex constraint | already discovered
   uint32_t capNodes, capHeap, capRows, rowWords;  // capHeap: entries per heap array (open / focal / walk queue)
 };
+
+template <class T>
+DEVI void setPos(Mem<T>& m, uint32_t id, uint32_t idx) {
+  if constexpr (T::AS == 3)
+    m.pos[id] = (uint16_t)idx;
+  else
+    m.nodes[id * 4 + 3] = idx;
+}
+// x | y << 8 of a node and the position of its entry in the open array (both wave-uniform)
+template <class T>
+DEVI void nodeXyPos(Mem<T>& m, uint32_t id, uint32_t& xy, uint32_t& pos) {
+  if constexpr (T::AS == 3) {
+    const uint32_t w = m.nodes[id];
+    const uint32_t p = m.pos[id];
+    xy = rfl(w) & 0xFFFFu;
+    pos = rfl(p);
+  } else {
+    const u32x4 nd = ((typename Mem<T>::PNode4)m.nodes)[id];
+    xy = rfl(nd.x) & 0xFFFFu;
+    pos = rfl(nd.w);
+  }
+}
+template <class T>
+DEVI void nodeXyParent(Mem<T>& m, uint32_t id, uint32_t& xy, uint32_t& parent) {
+  if constexpr (T::AS == 3) {
+    const uint32_t w = rfl(m.nodes[id]);
+    xy = w & 0xFFFFu;
+    parent = w >> 16;
+  } else {
+    const u32x4 nd = ((typename Mem<T>::PNode4)m.nodes)[id];
+    xy = rfl(nd.x) & 0xFFFFu;
+    parent = rfl(nd.y);
+  }
+}
 
 struct Ctx {  // wave-uniform job context
   uint32_t dimx, dimy, wpr, gx, gy, sx, sy;
@@ -119,14 +216,14 @@ struct SState {  // wave-uniform search state (kept in SGPRs by construction)
 enum : int { RUN_MIGRATE_NODES = -1, RUN_MIGRATE_ROWS = -2 };
 constexpr int32_t ST_CAP_FOCAL = 7;
 
-template <int AS>
-DEVI uint64_t ld64(typename Mem<AS>::P64 p, uint32_t i) { return rfl64(p[i]); }
+template <class T>
+DEVI typename T::E ldU(typename Mem<T>::PE p, uint32_t i) { return T::first(p[i]); }
 
-template <int AS>
-DEVI void ldPair(typename Mem<AS>::P64 p, uint32_t i, uint64_t& a, uint64_t& b) {  // i odd -> 16-byte aligned
-  u64x2 v = *(typename Mem<AS>::PPair)(p + i);
-  a = rfl64(v.x);
-  b = rfl64(v.y);
+template <class T>
+DEVI void ldPair(typename Mem<T>::PE p, uint32_t i, typename T::E& a, typename T::E& b) {  // i odd -> aligned pair
+  const typename T::Pair v = *(typename Mem<T>::PPair)(p + i);
+  a = T::first(v.x);
+  b = T::first(v.y);
 }
 
 // ---- heap primitives ------------------------------------------------------------------------------------------
@@ -137,47 +234,43 @@ DEVI void ldPair(typename Mem<AS>::P64 p, uint32_t i, uint64_t& a, uint64_t& b) 
 //                    the ancestors below that point move down one level in a single parallel store.
 //   * sift-down    : which child is "the larger one" does not depend on the element being sifted, so 63 lanes load
 //                    the child pairs of a whole 6-level subtree in one instruction and the path is then followed with
-//                    scalar bit tests / v_readlane (no further memory latency); repeated per 6 levels.
+//                    scalar bit tests (no further memory latency); repeated per 6 levels.
 //   * erase        : the unconditional bubble-to-root is a one-level shift of the ancestor chain (parallel).
-// KEY selects the comparator: 0 = open (f asc, g desc), 1 = focal (focalH, f asc, g desc), 2 = walk queue (open key
-// kept in the high word).  POS=true maintains handle -> position inside the node record (open list only).
-template <int KEY>
-DEVI bool kLess(uint64_t a, uint64_t b) {  // the reference's "operator<": a is WORSE than b
-  if (KEY == 0) return openKey(a) < openKey(b);
-  return entryKey(a) < entryKey(b);  // focal: whole key word; walk queue: the open key stored as its key word
+// KEY selects the comparator: 0 = open (f asc, g desc), 1 = focal (focalH, f asc, g desc), 2 = walk queue (an open key
+// in the entry's key field).  POS=true maintains handle -> position for the node (open list only).
+template <class T, int KEY>
+DEVI uint32_t keyOf(typename T::E e) { return KEY == 0 ? T::keyOpen(e) : T::keyFocal(e); }
+template <class T, int KEY>
+DEVI bool kLess(typename T::E a, typename T::E b) {  // the reference's "operator<": a is WORSE than b
+  return keyOf<T, KEY>(a) < keyOf<T, KEY>(b);
 }
 
-template <int AS, bool POS>
-DEVI void heapStore(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx, uint64_t e) {
+template <class T, bool POS>
+DEVI void heapStore(Mem<T>& m, typename Mem<T>::PE heap, uint32_t idx, typename T::E e) {
   heap[idx] = e;
-  if (POS) ((typename Mem<AS>::P32)m.nodes)[entryId(e) * 4 + 3] = idx;
-}
-
-DEVI uint64_t readlane64(uint64_t v, uint32_t srcLane) {
-  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, srcLane);
-  uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), srcLane);
-  return ((uint64_t)hi << 32) | lo;
+  if (POS) setPos<T>(m, T::id(e), idx);
 }
 
 // boost siftup / libstdc++ __push_heap from position idx: while less(parent, e) the parent moves down.
-template <int AS, int KEY, bool POS>
-DEVI void siftUp(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx, uint64_t e) {
+template <class T, int KEY, bool POS>
+DEVI void siftUp(Mem<T>& m, typename Mem<T>::PE heap, uint32_t idx, typename T::E e) {
+  typedef typename T::E E;
   const uint32_t lane = threadIdx.x;
   const uint32_t depth = 31u - (uint32_t)__builtin_clz(idx + 1);  // number of ancestors of idx
   uint32_t stop = 0;
   if (depth != 0) {
     const bool act = lane < depth;
     const uint32_t anc = act ? ((idx + 1) >> (lane + 1)) - 1 : 0;     // lane k: k-th ancestor
-    const uint64_t ae = heap[anc];
-    const uint64_t worse = ballot64(act && kLess<KEY>(ae, e));
+    const E ae = heap[anc];
+    const uint64_t worse = ballot64(act && kLess<T, KEY>(ae, e));
     stop = (uint32_t)__builtin_ctzll(~worse);                          // first ancestor that is not worse than e
     if (lane < stop) {                                                 // ancestors 0..stop-1 move down one level
       const uint32_t dest = ((idx + 1) >> lane) - 1;
       heap[dest] = ae;
-      if (POS) ((typename Mem<AS>::P32)m.nodes)[entryId(ae) * 4 + 3] = dest;
+      if (POS) setPos<T>(m, T::id(ae), dest);
     }
   }
-  heapStore<AS, POS>(m, heap, ((idx + 1) >> stop) - 1, e);
+  heapStore<T, POS>(m, heap, ((idx + 1) >> stop) - 1, e);
 }
 
 // Moves the hole at `idx` down a heap of n elements.
@@ -185,27 +278,28 @@ DEVI void siftUp(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx, uint64_t 
 //             stored at the final hole.
 //   STL=true  (libstdc++ __adjust_heap): prefer the right child unless it is less than the left one; always descend
 //             to a leaf; the final hole index is returned (the caller then sifts its value up from there).
-// Per 6 levels: one 16-byte load per lane (63 lanes = the whole subtree below the hole), two ballots, a scalar walk
+// Per 6 levels: one pair load per lane (63 lanes = the whole subtree below the hole), two ballots, a scalar walk
 // over the two bit masks, and ONE predicated store in which every node on the path pulls its chosen child up.
-template <int AS, int KEY, bool POS, bool STL>
-DEVI uint32_t descend(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t n, uint32_t idx, uint64_t x) {
+template <class T, int KEY, bool POS, bool STL>
+DEVI uint32_t descend(Mem<T>& m, typename Mem<T>::PE heap, uint32_t n, uint32_t idx, typename T::E x) {
+  typedef typename T::E E;
   const uint32_t lane = threadIdx.x;
   const uint32_t lv = 31u - (uint32_t)__builtin_clz(lane + 1);  // level of this lane inside a 6-level subtree
   const uint32_t off = (lane + 1) - (1u << lv);                 // position inside that level
-  const uint32_t xk = KEY == 0 ? openKey(x) : entryKey(x);
+  const uint32_t xk = keyOf<T, KEY>(x);
   for (;;) {
     const uint32_t node = ((idx + 1) << lv) - 1 + off;          // lane l < 63 owns this node of the subtree
     const uint32_t c = 2 * node + 1;
     const bool has = (lane < 63) && (c < n);
-    u64x2 pr;
+    typename T::Pair pr;
     pr.x = 0;
     pr.y = 0;
-    if (has) pr = *(typename Mem<AS>::PPair)(heap + c);         // children (c, c+1): one aligned 16-byte load
-    const uint32_t kl = KEY == 0 ? openKey(pr.x) : entryKey(pr.x);
-    const uint32_t kr = KEY == 0 ? openKey(pr.y) : entryKey(pr.y);
+    if (has) pr = *(typename Mem<T>::PPair)(heap + c);          // children (c, c+1): one aligned load
+    const uint32_t kl = keyOf<T, KEY>(pr.x);
+    const uint32_t kr = keyOf<T, KEY>(pr.y);
     const bool hasR = has && (c + 1 < n);
     const bool right = hasR && (STL ? !(kr < kl) : (kl < kr));
-    const uint64_t pe = right ? pr.y : pr.x;
+    const E pe = right ? pr.y : pr.x;
     const uint32_t pk = right ? kr : kl;
     const bool go = has && (STL || !(pk < xk));                 // the hole moves below this node
     const uint64_t goMask = ballot64(go);
@@ -220,40 +314,22 @@ DEVI uint32_t descend(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t n, uint32
     }
     if ((pathMask >> lane) & 1ull) {                            // every node on the path pulls its chosen child up
       heap[node] = pe;
-      if (POS) ((typename Mem<AS>::P32)m.nodes)[entryId(pe) * 4 + 3] = node;
+      if (POS) setPos<T>(m, T::id(pe), node);
     }
     idx = ((idx + 1) << steps) - 1 + (rel + 1 - (1u << steps)); // absolute index of the new hole
     if (steps < 6) break;
   }
-  if (!STL) heapStore<AS, POS>(m, heap, idx, x);
+  if (!STL) heapStore<T, POS>(m, heap, idx, x);
   return idx;
 }
 
 // boost pop: swap(front, back), drop back, siftdown(0)
-template <int AS, int KEY, bool POS>
-DEVI void heapPop(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t& n) {
+template <class T, int KEY, bool POS>
+DEVI void heapPop(Mem<T>& m, typename Mem<T>::PE heap, uint32_t& n) {
   n -= 1;
   if (n == 0) return;
-  const uint64_t last = ld64<AS>(heap, n);
-  descend<AS, KEY, POS, false>(m, heap, n, 0, last);
-}
-
-// boost erase(handle): swap the element up to the root unconditionally, then pop
-template <int AS>
-DEVI void openErase(Mem<AS>& m, uint32_t& n, uint32_t idx) {
-  const uint32_t lane = threadIdx.x;
-  const uint32_t depth = 31u - (uint32_t)__builtin_clz(idx + 1);
-  if (depth != 0) {  // every ancestor moves down one level along the path to idx
-    const bool act = lane < depth;
-    const uint32_t anc = act ? ((idx + 1) >> (lane + 1)) - 1 : 0;
-    const uint64_t ae = m.open[anc];
-    if (act) {
-      const uint32_t dest = ((idx + 1) >> lane) - 1;
-      m.open[dest] = ae;
-      ((typename Mem<AS>::P32)m.nodes)[entryId(ae) * 4 + 3] = dest;
-    }
-  }
-  heapPop<AS, 0, true>(m, m.open, n);
+  const typename T::E last = ldU<T>(heap, n);
+  descend<T, KEY, POS, false>(m, heap, n, 0, last);
 }
 
 // ---- batched operations of one expansion ------------------------------------------------------------------------
@@ -268,21 +344,15 @@ DEVI void openErase(Mem<AS>& m, uint32_t& n, uint32_t idx) {
 //     (DPP wave_shr:1).  Five pushes into two heaps cost one round trip.
 //   * pops: the loads of the focal and the open sift-down (which child is the larger one does not depend on the
 //     element being sifted) are issued together, and the moved "last" elements are fetched with them.
-DEVI uint32_t waveShr1(uint32_t v) {  // lane i receives lane i-1's value (lane 0 keeps its own)
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);
-}
-DEVI uint64_t waveShr1_64(uint64_t v) {
-  return ((uint64_t)waveShr1((uint32_t)(v >> 32)) << 32) | waveShr1((uint32_t)v);
-}
-
 constexpr uint32_t kNoPos = 0xFFFFFFFFu;
 
-template <int AS>
+template <class T>
 struct PushChains {          // sift-up chains of the (up to five) pushes of one expansion into one heap
+  typedef typename T::E E;
   uint32_t pos[5];           // lane L: heap position of the chain's node at level L (kNoPos: none)
-  uint64_t val[5];           // lane L: the entry there before any of these pushes
+  E val[5];                  // lane L: the entry there before any of these pushes
   // `mask` bit k: successor k is pushed; pushed elements take positions n0, n0+1, ... in ascending k
-  DEVI void load(typename Mem<AS>::P64 heap, uint32_t n0, uint32_t mask) {
+  DEVI void load(typename Mem<T>::PE heap, uint32_t n0, uint32_t mask) {
     const uint32_t lane = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -299,27 +369,27 @@ struct PushChains {          // sift-up chains of the (up to five) pushes of one
   // boost siftup / libstdc++ __push_heap of e[k] at its position, for k ascending — the same stores a one-at-a-time
   // replay ends with (positions written twice are written in push order).
   template <int KEY, bool POS>
-  DEVI void resolve(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t n0, uint32_t mask, const uint64_t (&e)[5]) {
+  DEVI void resolve(Mem<T>& m, typename Mem<T>::PE heap, uint32_t n0, uint32_t mask, const E (&e)[5]) {
     const uint32_t lane = threadIdx.x;
-    uint64_t nv[5];
+    E nv[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
       nv[k] = 0;
       if ((mask >> k) & 1u) {
         const uint32_t p = n0 + (uint32_t)__builtin_popcount(mask & ((1u << k) - 1u));
         const uint32_t d = 31u - (uint32_t)__builtin_clz(p + 1);
-        uint64_t v = val[k];
+        E v = val[k];
 #pragma unroll
         for (int j = 0; j < k; ++j)  // what earlier pushes of this expansion left on this chain
           if (((mask >> j) & 1u) && pos[j] == pos[k] && pos[k] != kNoPos) v = nv[j];
-        const uint64_t worse = ballot64(lane < d && kLess<KEY>(v, e[k]));
+        const uint64_t worse = ballot64(lane < d && kLess<T, KEY>(v, e[k]));
         const uint64_t notWorse = ~worse & ((1ull << d) - 1ull);
         const int32_t sLvl = notWorse ? 63 - (int32_t)__builtin_clzll(notWorse) : -1;  // deepest ancestor that stays
-        const uint64_t sh = waveShr1_64(v);
-        const uint64_t nk = (int32_t)lane <= sLvl ? v : ((int32_t)lane == sLvl + 1 ? e[k] : sh);
+        const E sh = T::shr1(v);
+        const E nk = (int32_t)lane <= sLvl ? v : ((int32_t)lane == sLvl + 1 ? e[k] : sh);
         if ((int32_t)lane > sLvl && lane <= d) {
           heap[pos[k]] = nk;
-          if (POS) ((typename Mem<AS>::P32)m.nodes)[entryId(nk) * 4 + 3] = pos[k];
+          if (POS) setPos<T>(m, T::id(nk), pos[k]);
         }
         nv[k] = nk;
       }
@@ -329,14 +399,15 @@ struct PushChains {          // sift-up chains of the (up to five) pushes of one
 
 // One 6-level block of a sift-down whose child pairs have been loaded (see descend): follows the path, pulls the
 // chosen children up, returns the new hole; `more` = the block was left through its bottom.
-template <int AS, int KEY, bool POS>
-DEVI uint32_t descendBlock(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx, uint32_t xk, u64x2 pr, uint32_t node,
-                           bool has, bool hasR, bool full, bool& more) {
+template <class T, int KEY, bool POS>
+DEVI uint32_t descendBlock(Mem<T>& m, typename Mem<T>::PE heap, uint32_t idx, uint32_t xk, typename T::Pair pr,
+                           uint32_t node, bool has, bool hasR, bool full, bool& more) {
+  typedef typename T::E E;
   const uint32_t lane = threadIdx.x;
-  const uint32_t kl = KEY == 0 ? openKey(pr.x) : entryKey(pr.x);
-  const uint32_t kr = KEY == 0 ? openKey(pr.y) : entryKey(pr.y);
+  const uint32_t kl = keyOf<T, KEY>(pr.x);
+  const uint32_t kr = keyOf<T, KEY>(pr.y);
   const bool right = hasR && (kl < kr);
-  const uint64_t pe = right ? pr.y : pr.x;
+  const E pe = right ? pr.y : pr.x;
   const uint32_t pk = right ? kr : kl;
   const bool go = has && !(pk < xk);
   const uint64_t goMask = ballot64(go);
@@ -364,7 +435,7 @@ DEVI uint32_t descendBlock(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx,
   }
   if ((pathMask >> lane) & 1ull) {
     heap[node] = pe;
-    if (POS) ((typename Mem<AS>::P32)m.nodes)[entryId(pe) * 4 + 3] = node;
+    if (POS) setPos<T>(m, T::id(pe), node);
   }
   more = steps == 6;
   return ((idx + 1) << steps) - 1 + (rel + 1 - (1u << steps));
@@ -372,8 +443,10 @@ DEVI uint32_t descendBlock(Mem<AS>& m, typename Mem<AS>::P64 heap, uint32_t idx,
 
 // a_star_epsilon.hpp:191-192 of one expansion: focalSet.pop() and openSet.erase(handle of the same node), with the
 // memory traffic of the two heaps overlapped.  curPos = position of the popped node in the open array.
-template <int AS>
-DEVI void popFocalEraseOpen(Mem<AS>& m, uint32_t& nFocal, uint32_t& nOpen, uint32_t curPos) {
+template <class T>
+DEVI void popFocalEraseOpen(Mem<T>& m, uint32_t& nFocal, uint32_t& nOpen, uint32_t curPos) {
+  typedef typename T::E E;
+  typedef typename T::Pair Pair;
   const uint32_t lane = threadIdx.x;
   const uint32_t lv = 31u - (uint32_t)__builtin_clz(lane + 1);
   const uint32_t off = (lane + 1) - (1u << lv);
@@ -381,81 +454,82 @@ DEVI void popFocalEraseOpen(Mem<AS>& m, uint32_t& nFocal, uint32_t& nOpen, uint3
   nFocal -= 1;
   const uint32_t nOld = nOpen;
   nOpen -= 1;
-  uint64_t lastFv = 0, lastOv = 0;
+  E lastFv = 0, lastOv = 0;
   if (nFocal > 0) lastFv = m.focal[nFocal];
   if (nOpen > 0) lastOv = m.open[nOld - 1];
   const uint32_t depth = 31u - (uint32_t)__builtin_clz(curPos + 1);
   const bool act = lane < depth;
   const uint32_t anc = act ? ((curPos + 1) >> (lane + 1)) - 1 : 0;
-  uint64_t ae = 0;
+  E ae = 0;
   if (depth != 0) ae = m.open[anc];
   // first block of the focal sift-down: does not depend on the element being sifted
   uint32_t idxF = 0, idxO = 0;
   bool moreF = nFocal > 0, moreO = nOpen > 0;
-  u64x2 prF;
+  Pair prF;
   prF.x = 0; prF.y = 0;
   const uint32_t nodeF0 = (1u << lv) - 1 + off;
   const bool hasF0 = moreF && lane < 63 && (2 * nodeF0 + 1 < nFocal);
-  if (hasF0) prF = *(typename Mem<AS>::PPair)(m.focal + 2 * nodeF0 + 1);
+  if (hasF0) prF = *(typename Mem<T>::PPair)(m.focal + 2 * nodeF0 + 1);
   // ---- open: every ancestor of curPos moves down one level (boost erase = bubble to the root, then pop)
   if (act) {
     const uint32_t dest = ((curPos + 1) >> lane) - 1;
     m.open[dest] = ae;
-    ((typename Mem<AS>::P32)m.nodes)[entryId(ae) * 4 + 3] = dest;
+    setPos<T>(m, T::id(ae), dest);
   }
   // the element that pop() moves to the root: the last one — which the shift above has just overwritten if the erased
   // node WAS the last one (then it is the erased node's parent)
-  uint64_t lastO = rfl64(lastOv);
-  if (curPos == nOld - 1 && depth != 0) lastO = readlane64(ae, 0);
-  const uint64_t lastF = rfl64(lastFv);
-  const uint32_t xkF = entryKey(lastF), xkO = openKey(lastO);
+  E lastO = T::first(lastOv);
+  if (curPos == nOld - 1 && depth != 0) lastO = T::fromLane(ae, 0);
+  const E lastF = T::first(lastFv);
+  const uint32_t xkF = T::keyFocal(lastF), xkO = T::keyOpen(lastO);
   // ---- sift-downs, block by block, both heaps per round trip
   bool firstF = true;
   for (;;) {
-
-    u64x2 prO;
+    Pair prO;
     prO.x = 0; prO.y = 0;
     const uint32_t nodeO = ((idxO + 1) << lv) - 1 + off;
     const bool hasO = moreO && lane < 63 && (2 * nodeO + 1 < nOpen);
-    if (hasO) prO = *(typename Mem<AS>::PPair)(m.open + 2 * nodeO + 1);
+    if (hasO) prO = *(typename Mem<T>::PPair)(m.open + 2 * nodeO + 1);
     uint32_t nodeF = nodeF0;
     bool hasF = hasF0;
     if (!firstF) {
       nodeF = ((idxF + 1) << lv) - 1 + off;
       hasF = moreF && lane < 63 && (2 * nodeF + 1 < nFocal);
       prF.x = 0; prF.y = 0;
-      if (hasF) prF = *(typename Mem<AS>::PPair)(m.focal + 2 * nodeF + 1);
+      if (hasF) prF = *(typename Mem<T>::PPair)(m.focal + 2 * nodeF + 1);
     }
     firstF = false;
     // "full": the leftmost descendant six levels below the hole exists
     if (moreF)
-      idxF = descendBlock<AS, 1, false>(m, m.focal, idxF, xkF, prF, nodeF, hasF, hasF && (2 * nodeF + 2 < nFocal),
-                                        ((idxF + 1) << 6) - 1 < nFocal, moreF);
+      idxF = descendBlock<T, 1, false>(m, m.focal, idxF, xkF, prF, nodeF, hasF, hasF && (2 * nodeF + 2 < nFocal),
+                                       ((idxF + 1) << 6) - 1 < nFocal, moreF);
     if (moreO)
-      idxO = descendBlock<AS, 0, true>(m, m.open, idxO, xkO, prO, nodeO, hasO, hasO && (2 * nodeO + 2 < nOpen),
-                                       ((idxO + 1) << 6) - 1 < nOpen, moreO);
+      idxO = descendBlock<T, 0, true>(m, m.open, idxO, xkO, prO, nodeO, hasO, hasO && (2 * nodeO + 2 < nOpen),
+                                      ((idxO + 1) << 6) - 1 < nOpen, moreO);
     if (!moreF && !moreO) break;
   }
   if (nFocal > 0) m.focal[idxF] = lastF;
-  if (nOpen > 0) heapStore<AS, true>(m, m.open, idxO, lastO);
+  if (nOpen > 0) heapStore<T, true>(m, m.open, idxO, lastO);
 }
 
 // ---- ordered walk (open.ordered_begin(), a_star_epsilon.hpp:141-152) ----------------------------------------
 // libstdc++ std::priority_queue<…> restated: push = __push_heap, pop = __pop_heap/__adjust_heap (bits/stl_heap.h).
-template <int AS>
-DEVI uint64_t auxPop(Mem<AS>& m, uint32_t& npq) {
-  const uint64_t result = ld64<AS>(m.aux, 0);
+template <class T>
+DEVI typename T::E auxPop(Mem<T>& m, uint32_t& npq) {
+  typedef typename T::E E;
+  const E result = ldU<T>(m.aux, 0);
   npq -= 1;
   if (npq > 0) {
-    const uint64_t value = ld64<AS>(m.aux, npq);  // *(last - 1)
-    const uint32_t hole = descend<AS, 2, false, true>(m, m.aux, npq, 0, value);
-    siftUp<AS, 2, false>(m, m.aux, hole, value);
+    const E value = ldU<T>(m.aux, npq);  // *(last - 1)
+    const uint32_t hole = descend<T, 2, false, true>(m, m.aux, npq, 0, value);
+    siftUp<T, 2, false>(m, m.aux, hole, value);
   }
-  return result;  // (open key << 32) | index into the open array
+  return result;  // open key and index into the open array
 }
 
-template <int AS>
-DEVI void orderedWalk(Mem<AS>& m, SState& s, const Ctx& c, int32_t oldBest, DevResult& res) {
+template <class T>
+DEVI void orderedWalk(Mem<T>& m, SState& s, const Ctx& c, int32_t oldBest, DevResult& res) {
+  typedef typename T::E E;
   // int * float products in binary32, no contraction (a_star_epsilon.hpp:145,149)
   const float lo = __fmul_rn((float)oldBest, c.w);
   const float hi = __fmul_rn((float)s.bestF, c.w);
@@ -463,41 +537,40 @@ DEVI void orderedWalk(Mem<AS>& m, SState& s, const Ctx& c, int32_t oldBest, DevR
   // the two children are pushed with one round trip (PushChains).  In a long search the walks are most of the time
   // (every bestF increase visits every open node with f <= hi), so a round trip per visited node matters.
   uint32_t npq = 0;
-  uint64_t curA = (uint64_t)openKey(ld64<AS>(m.open, 0)) << 32;  // index 0
+  E curA = T::aux(T::keyOpen(ldU<T>(m.open, 0)), 0);  // index 0
   for (;;) {
-    const uint32_t cur = (uint32_t)curA;
+    const uint32_t cur = T::auxIdx(curA);
     const uint32_t first = 2 * cur + 1;
     if (first < s.nOpen) {
-      uint64_t e1, e2;
-      ldPair<AS>(m.open, first, e1, e2);
-      uint64_t ee[5];
-      ee[0] = ((uint64_t)openKey(e1) << 32) | first;
-      ee[1] = ((uint64_t)openKey(e2) << 32) | (first + 1);
+      E e1, e2;
+      ldPair<T>(m.open, first, e1, e2);
+      E ee[5];
+      ee[0] = T::aux(T::keyOpen(e1), first);
+      ee[1] = T::aux(T::keyOpen(e2), first + 1);
       ee[2] = ee[3] = ee[4] = 0;
       const uint32_t pm = first + 1 < s.nOpen ? 3u : 1u;
-      PushChains<AS> pc;
+      PushChains<T> pc;
       pc.load(m.aux, npq, pm);
       pc.template resolve<2, false>(m, m.aux, npq, pm, ee);  // == __push_heap of the children in index order
       npq += pm == 3u ? 2u : 1u;
     }
     PROF_INC(res, 7, 1);
 
-    const float fv = (float)entryF(curA);
+    const float fv = (float)(int32_t)T::f(curA);
     if (fv > lo && fv <= hi) {
-      const uint64_t e = ld64<AS>(m.open, cur);
-      siftUp<AS, 1, false>(m, m.focal, s.nFocal, e);
+      const E e = ldU<T>(m.open, cur);
+      siftUp<T, 1, false>(m, m.focal, s.nFocal, e);
       s.nFocal += 1;
     }
     if (fv > hi) break;
     if (npq == 0) break;
-    curA = auxPop<AS>(m, npq);
+    curA = auxPop<T>(m, npq);
   }
 }
 
 // ---- lazy bitmap rows: row t = obstacles | vertex constraints at time t | states already discovered --------
-template <int AS>
-DEVI void ensureRows(Mem<AS>& m, SState& s, const Ctx& c, uint32_t t1, const uint32_t* obstGlobal,
-                     typename Mem<AS>::P32 obstLocal, bool useLocal) {
+template <class T>
+DEVI void ensureRows(Mem<T>& m, SState& s, const Ctx& c, uint32_t t1, typename Mem<T>::P32 obstLocal, bool useLocal) {
   if (t1 < s.rowsReady) return;
   const uint32_t lane = threadIdx.x;
   uint32_t r0 = s.rowsReady;
@@ -505,23 +578,22 @@ DEVI void ensureRows(Mem<AS>& m, SState& s, const Ctx& c, uint32_t t1, const uin
   if (r1 > m.capRows) r1 = m.capRows;
   for (uint32_t r = r0; r < r1; ++r)
     for (uint32_t wd = lane; wd < c.wpr; wd += 64)
-      m.bits[r * m.rowWords + wd] = useLocal ? obstLocal[wd] : obstGlobal[wd];
+      m.bits[r * m.rowWords + wd] = useLocal ? obstLocal[wd] : c.obst[wd];
   __syncthreads();
   for (uint32_t j = lane; j < c.nVc; j += 64) {
     uint32_t v = c.vc[j];
     uint32_t tt = v >> 16, cell = v & 0xFFFFu;
-    if (tt >= r0 && tt < r1) {
-      uint32_t* p = (uint32_t*)(m.bits + tt * m.rowWords + (cell >> 5));
-      atomicOr(p, 1u << (cell & 31));
-    }
+    if (tt >= r0 && tt < r1)
+      __hip_atomic_fetch_or(m.bits + tt * m.rowWords + (cell >> 5), 1u << (cell & 31), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();
   s.rowsReady = r1;
 }
 
 // ---- one search in one tier ------------------------------------------------------------------------------------
-template <int AS, bool EPS>
-DEVI void initSearch(Mem<AS>& m, SState& s, const Ctx& c) {
+template <class T, bool EPS>
+DEVI void initSearch(Mem<T>& m, SState& s, const Ctx& c) {
   uint32_t h0 = (c.sx > c.gx ? c.sx - c.gx : c.gx - c.sx) + (c.sy > c.gy ? c.sy - c.gy : c.gy - c.sy);
   s.nNodes = 1;
   s.nOpen = 1;
@@ -529,63 +601,75 @@ DEVI void initSearch(Mem<AS>& m, SState& s, const Ctx& c) {
   s.rowsReady = 0;
   s.bestF = (int32_t)h0;
   s.expansions = 0;
-  u32x4 n0;
-  n0.x = c.sx | (c.sy << 8) | (0u << 16) | (7u << 27);
-  n0.y = kNoParent;
-  n0.z = 0;
-  n0.w = 0;
-  m.nodes[0] = n0;
-  uint64_t e0 = packEntry(0, h0, 0, 0);
+  if constexpr (T::AS == 3) {
+    m.nodes[0] = c.sx | (c.sy << 8) | (0xFFFFu << 16);
+    m.pos[0] = 0;
+  } else {
+    u32x4 n0;
+    n0.x = c.sx | (c.sy << 8) | (0u << 16) | (7u << 27);
+    n0.y = kNoParent;
+    n0.z = 0;
+    n0.w = 0;
+    ((typename Mem<T>::PNode4)m.nodes)[0] = n0;
+  }
+  const typename T::E e0 = T::pack(0, h0, 0, 0);
   m.open[0] = e0;
   if (EPS) m.focal[0] = e0;
 }
 
 // Returns a status (>= 0) when the search ended, or RUN_MIGRATE_* when this tier is too small to continue.
-template <int AS, bool EPS>
-DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 obstLocal,
-                   typename Mem<AS>::P32 ecLocal, bool useLocal, DevResult& res, uint16_t* outPath) {
+template <class T, bool EPS>
+DEVI int runSearch(Mem<T>& m, SState& s, const Ctx& c, typename Mem<T>::P32 obstLocal, bool useLocal, DevResult& res,
+                   uint16_t* outPath) {
+  typedef typename T::E E;
   const uint32_t lane = threadIdx.x;
   uint32_t dbgIter = 0;
   // edge-constraint keys, one per lane (lists longer than a wave keep their tail in memory)
   const uint32_t ecReg = lane < c.nEc ? c.ec[lane] : 0xFFFFFFFFu;
+  // successor of this lane in the reference's order Wait, Left, Right, Up, Down (ecbs.cpp:365-398) on lanes 0..4
+  const int32_t dx = (lane == 2) - (lane == 1);
+  const int32_t dy = (lane == 3) - (lane == 4);
   for (;;) {
     DBG(c, 5, ++dbgIter);
     PROF_MARK(profTop);
     if (s.nOpen == 0) return ST_NO_SOLUTION;
-    uint64_t topE = ld64<AS>(m.open, 0);
-    uint64_t curE = topE;
+    const E topE = ldU<T>(m.open, 0);
+    E curE = topE;
     if (EPS) {
-      int32_t oldBest = s.bestF;
-      s.bestF = entryF(topE);
+      const int32_t oldBest = s.bestF;
+      s.bestF = (int32_t)T::f(topE);
       if (s.bestF > oldBest) {
         PROF_T0();
-        orderedWalk<AS>(m, s, c, oldBest, res);
+        orderedWalk<T>(m, s, c, oldBest, res);
         PROF_ADD(res, 0);
         PROF_INC(res, 6, 1);
-
       }
-      curE = ld64<AS>(m.focal, 0);
+      curE = ldU<T>(m.focal, 0);
     }
-    const uint32_t curId = entryId(curE);
-    u32x4 nd = m.nodes[curId];
-    const uint32_t xyt = rfl(nd.x);
-    const uint32_t x = xyt & 0xFF, y = (xyt >> 8) & 0xFF, t = (xyt >> 16) & 0x7FF;
-    const uint32_t curFh = rfl(nd.z);
-    const uint32_t curPos = rfl(nd.w);
+    // f, g (== time: every action costs 1) and focalH of the popped node are in its entry
+    const uint32_t curId = T::id(curE);
+    const uint32_t t = T::g(curE);
+    const uint32_t curFh = T::fh(curE);
+    uint32_t xy, curPos;
+    nodeXyPos<T>(m, curId, xy, curPos);
+    const uint32_t x = xy & 0xFF, y = xy >> 8;
     const bool isGoal = (x == c.gx) && (y == c.gy) && ((int32_t)t > c.lastGoal);
-    DBG(c, 6, xyt);
+    DBG(c, 6, xy | (t << 16));
     DBG(c, 7, isGoal ? 1 : 2);
     if (!isGoal) {
       if (s.nNodes + 5 > m.capNodes || s.nOpen + 5 > m.capHeap) return RUN_MIGRATE_NODES;
       if (t + 1 >= m.capRows) return RUN_MIGRATE_ROWS;
+      // a successor adds at most two conflicts per other agent to focalH: leave the compact tier before its field can
+      // overflow (TierHbm reports ST_CAP_FOCAL below instead)
+      if (T::AS == 3 && curFh + 2 * c.nAgentsPad > T::kFhCap) return RUN_MIGRATE_NODES;
     }
     // other agents' positions at t and t+1 (issued early; consumed after the heap pops)
     uint32_t a0 = kEmptyCell, b0 = kEmptyCell, a1 = kEmptyCell, b1 = kEmptyCell;
     const uint16_t* rowA = nullptr;
     const uint16_t* rowB = nullptr;
     if (EPS && c.nAgentsPad && !isGoal) {
-      uint32_t ra = t < c.tPad ? t : c.tPad - 1;
-      uint32_t rb = (t + 1) < c.tPad ? (t + 1) : c.tPad - 1;
+      const uint32_t ra = t < c.tPad ? t : c.tPad - 1;
+      const uint32_t rb = (t + 1) < c.tPad ? (t + 1) : c.tPad - 1;
       rowA = c.paths + (size_t)ra * c.nAgentsPad;
       rowB = c.paths + (size_t)rb * c.nAgentsPad;
       if (c.pathsLds) {  // the usual case: LDS reads proper, not flat loads through the LDS aperture
@@ -614,25 +698,24 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
 
     if (isGoal) {
       res.cost = (int32_t)t;
-      res.fmin = EPS ? entryF(topE) : entryF(curE);
+      res.fmin = (int32_t)(EPS ? T::f(topE) : T::f(curE));
       res.n_states = (int32_t)t + 1;
       uint32_t nid = curId;
       for (int32_t k = (int32_t)t; k >= 0; --k) {  // follow cameFrom (a_star_epsilon.hpp:198-208)
-        u32x4 pn = m.nodes[nid];
-        outPath[k] = (uint16_t)(rfl(pn.x) & 0xFFFF);  // all lanes, same address, same value
-        nid = rfl(pn.y);
+        uint32_t pxy, par;
+        nodeXyParent<T>(m, nid, pxy, par);
+        outPath[k] = (uint16_t)pxy;  // all lanes, same address, same value
+        nid = par;
       }
       DBG(c, 8, 77);
       return ST_OK;
     }
 
     const uint32_t t1 = t + 1;
-    ensureRows<AS>(m, s, c, t1, c.obst, obstLocal, useLocal);
+    ensureRows<T>(m, s, c, t1, obstLocal, useLocal);
     PROF_SINCE(res, 4, profTop);  // loop top -> pops, minus the ordered walk (slot 0)
-    // successors in the reference's order Wait, Left, Right, Up, Down (ecbs.cpp:365-398) on lanes 0..4; the bitmap
-    // words are requested before the pops below so that their latency is hidden behind them
-    const int32_t dx = (lane == 2) - (lane == 1);
-    const int32_t dy = (lane == 3) - (lane == 4);
+    // the five successor probes: bounds, then ONE bit of the (time, cell) bitmap = obstacle | vertex constraint |
+    // already discovered; the words are requested before the pops below so that their latency hides behind them
     const uint32_t nx = x + (uint32_t)dx, ny = y + (uint32_t)dy;
     const bool inb = (lane < 5) && (nx < c.dimx) && (ny < c.dimy);
     const uint32_t ncell = inb ? ny * c.dimx + nx : 0;
@@ -643,93 +726,94 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
     {
       PROF_T0();
       if (EPS) {
-        popFocalEraseOpen<AS>(m, s.nFocal, s.nOpen, curPos);
+        popFocalEraseOpen<T>(m, s.nFocal, s.nOpen, curPos);
       } else {
-        heapPop<AS, 0, true>(m, m.open, s.nOpen);
+        heapPop<T, 0, true>(m, m.open, s.nOpen);
       }
       PROF_ADD(res, 1);
     }
-    bool ok = inb && !((word >> (ncell & 31)) & 1u);
+    const bool ok = inb && !((word >> (ncell & 31)) & 1u);
     uint32_t mask = (uint32_t)(ballot64(ok) & 0x1Full);
     if (c.nEc) {  // transitionValid (ecbs.cpp:505-510): lane j holds edge-constraint key j = t << 19 | cell << 3 | action
       const uint32_t base = (t << 19) | (curCell << 3);
       const uint32_t d = ecReg - base;
-      uint32_t blocked = 0;
+      if (ballot64(d < 5u)) {  // rare: some constraint names a move out of this very state
+        uint32_t blocked = 0;
 #pragma unroll
-      for (uint32_t k = 0; k < 5; ++k) blocked |= ballot64(d == k) ? (1u << k) : 0u;
-      for (uint32_t j = 64; j < c.nEc; ++j) {  // lists longer than a wave: the rest one by one
-        const uint32_t dd = rfl(c.ec[j]) - base;
-        if (dd < 5) blocked |= 1u << dd;
+        for (uint32_t k = 0; k < 5; ++k) blocked |= ballot64(d == k) ? (1u << k) : 0u;
+        mask &= ~blocked;
       }
-      mask &= ~blocked;
+      if (c.nEc > 64) {
+        uint32_t blocked = 0;
+        for (uint32_t j = 64; j < c.nEc; ++j) {  // lists longer than a wave: the rest one by one
+          const uint32_t dd = rfl(c.ec[j]) - base;
+          if (dd < 5) blocked |= 1u << dd;
+        }
+        mask &= ~blocked;
+      }
     }
     if (mask == 0) continue;
     PROF_MARK(profEnt);
 
-    // ---- the successors' entries (order-independent part: heuristics, node records, discovered marks)
-    uint64_t e[5];
-    uint32_t maskF = 0;
-    const float bound = __fmul_rn((float)s.bestF, c.w);  // a_star_epsilon.hpp:240, binary32
+    // ---- the successors' entries, one per lane 0..4 (order-independent part: heuristics, node records, discovered marks)
+    const bool mine = (lane < 5) && ((mask >> lane) & 1u);
     const uint32_t nBase = s.nNodes;
-#pragma unroll
-    for (uint32_t k = 0; k < 5; ++k) {
-      e[k] = 0;
-      if ((mask >> k) & 1u) {
-        const uint32_t cx = __builtin_amdgcn_readlane(nx, k);
-        const uint32_t cy = __builtin_amdgcn_readlane(ny, k);
+    const uint32_t nid = nBase + (uint32_t)__builtin_popcount(mask & ((1u << lane) - 1u));
+    const uint32_t h = (nx > c.gx ? nx - c.gx : c.gx - nx) + (ny > c.gy ? ny - c.gy : c.gy - ny);
+    const uint32_t f = t1 + h;
+    uint32_t fh = curFh;
+    if (EPS && c.nAgentsPad) {
+      // focalStateHeuristic (ecbs.cpp:282-295) + focalTransitionHeuristic (ecbs.cpp:298-312): lanes hold the other
+      // agents' cells at t (a) and t+1 (b); an agent counts once if it stands on the successor's cell at t+1 and once
+      // more if it swaps places with this agent
+      const uint64_t swap0 = ballot64(b0 == curCell);
+      const uint64_t swap1 = c.nAgentsPad > 64 ? ballot64(b1 == curCell) : 0ull;
+      for (uint32_t mm = mask; mm; mm &= mm - 1) {
+        const uint32_t k = (uint32_t)__builtin_ctz(mm);
         const uint32_t cc = __builtin_amdgcn_readlane(ncell, k);
-        uint32_t fh = curFh;
-        if (EPS && c.nAgentsPad) {
-          // focalStateHeuristic (ecbs.cpp:282-295) + focalTransitionHeuristic (ecbs.cpp:298-312)
-          uint32_t cnt = __popcll(ballot64(b0 == cc)) + __popcll(ballot64(a0 == cc && b0 == curCell));
-          if (c.nAgentsPad > 64) {
-            cnt += __popcll(ballot64(b1 == cc)) + __popcll(ballot64(a1 == cc && b1 == curCell));
-            for (uint32_t base = 128; base < c.nAgentsPad; base += 64) {
-              uint32_t av = kEmptyCell, bv = kEmptyCell;
-              if (base + lane < c.nAgentsPad) {
-                av = rowA[base + lane];
-                bv = rowB[base + lane];
-              }
-              cnt += __popcll(ballot64(bv == cc)) + __popcll(ballot64(av == cc && bv == curCell));
+        uint32_t cnt = (uint32_t)__popcll(ballot64(b0 == cc)) + (uint32_t)__popcll(ballot64(a0 == cc) & swap0);
+        if (c.nAgentsPad > 64) {
+          cnt += (uint32_t)__popcll(ballot64(b1 == cc)) + (uint32_t)__popcll(ballot64(a1 == cc) & swap1);
+          for (uint32_t base = 128; base < c.nAgentsPad; base += 64) {
+            uint32_t av = kEmptyCell, bv = kEmptyCell;
+            if (base + lane < c.nAgentsPad) {
+              av = rowA[base + lane];
+              bv = rowB[base + lane];
             }
+            cnt += (uint32_t)__popcll(ballot64(bv == cc)) + (uint32_t)__popcll(ballot64(av == cc && bv == curCell));
           }
-          fh += cnt;
-          if (fh > kFhMax) return ST_CAP_FOCAL;
         }
-        const uint32_t h = (cx > c.gx ? cx - c.gx : c.gx - cx) + (cy > c.gy ? cy - c.gy : c.gy - cy);
-        const uint32_t f = t1 + h;
-        const uint32_t nid = nBase + (uint32_t)__builtin_popcount(mask & ((1u << k) - 1u));
+        fh = lane == k ? curFh + cnt : fh;
+      }
+      if (T::AS != 3 && ballot64(mine && fh > T::kFhCap)) return ST_CAP_FOCAL;
+    }
+    const E eMine = T::pack(fh, f, t1, nid);
+    const float bound = __fmul_rn((float)s.bestF, c.w);  // a_star_epsilon.hpp:240, binary32
+    const uint32_t maskF = EPS ? (uint32_t)(ballot64(mine && (float)(int32_t)f <= bound) & 0x1Full) : 0u;
+    if (mine) {
+      if constexpr (T::AS == 3) {
+        m.nodes[nid] = nx | (ny << 8) | (curId << 16);
+      } else {
         u32x4 nn;
-        nn.x = cx | (cy << 8) | (t1 << 16) | (k << 27);
+        nn.x = nx | (ny << 8) | (t1 << 16) | (lane << 27);
         nn.y = curId;
         nn.z = fh;
         nn.w = 0;
-        m.nodes[nid] = nn;
-        e[k] = packEntry(fh, f, t1, nid);
-        if (EPS && (float)(int32_t)f <= bound) maskF |= 1u << k;
+        ((typename Mem<T>::PNode4)m.nodes)[nid] = nn;
       }
+      // mark (t1, cell) discovered: stands for stateToHeap / closedSet membership (a_star_epsilon.hpp:224-227); the
+      // successors of one expansion are distinct cells, so marking them together changes nothing
+      __hip_atomic_fetch_or(m.bits + bitIdx, 1u << (ncell & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     s.nNodes = nBase + (uint32_t)__builtin_popcount(mask);
-    // mark (t1, cell) discovered: stands for stateToHeap / closedSet membership (a_star_epsilon.hpp:224-227); the
-    // successors of one expansion are distinct cells, so marking them together changes nothing
-    {
-      const bool mine = lane < 5 && ((mask >> lane) & 1u);
-      const uint32_t myBit = mine ? 1u << (ncell & 31) : 0u;
-      uint32_t merged = word;  // successors that share a bitmap word all store the same merged word
+    E e[5];
 #pragma unroll
-      for (uint32_t k = 0; k < 5; ++k) {
-        const uint32_t oi = __builtin_amdgcn_readlane(bitIdx, k);
-        const uint32_t ob = __builtin_amdgcn_readlane(myBit, k);
-        merged |= oi == bitIdx ? ob : 0u;
-      }
-      if (mine) m.bits[bitIdx] = merged;
-    }
-
+    for (uint32_t k = 0; k < 5; ++k) e[k] = T::fromLane(eMine, k);
     PROF_SINCE(res, 3, profEnt);  // successors' entries: heuristics, node records, discovered marks
     // ---- pushes: openSet.push for every successor, focalSet.push for those within the bound, in successor order
     {
       PROF_T0();
-      PushChains<AS> po, pf;
+      PushChains<T> po, pf;
       po.load(m.open, s.nOpen, mask);
       if (EPS) pf.load(m.focal, s.nFocal, maskF);
       po.template resolve<0, true>(m, m.open, s.nOpen, mask, e);
@@ -745,11 +829,13 @@ DEVI int runSearch(Mem<AS>& m, SState& s, const Ctx& c, typename Mem<AS>::P32 ob
 
 // ---- LDS layout ------------------------------------------------------------------------------------------------
 constexpr uint32_t kEcLocal = 64;
+__host__ __device__ inline uint32_t ldsHeapBytes(uint32_t capNodes) { return (capNodes / 2) * 4 + 16; }
 __host__ __device__ inline uint32_t ldsBytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes) {
-  // nodes 16 B; three biased heaps of capNodes / 2 entries of 8 B (+16 B bias pad each) — most nodes of a search are
-  // closed, so the open list outgrowing half the node capacity is rare and simply migrates like a full node array;
-  // bitmap rows, obstacle row, edge constraints, path table
-  return capNodes * 16 + 3 * ((capNodes / 2) * 8 + 16) + rows * rowWords * 4 + rowWords * 4 + kEcLocal * 4 + pathBytes;
+  // TierLds: node words, position halfwords, three biased heaps of capNodes / 2 32-bit entries (+16 B bias pad each) —
+  // most nodes of a search are closed, so the open list outgrowing half the node capacity is rare and simply
+  // migrates like a full node array; bitmap rows, obstacle row, edge constraints, path table
+  return capNodes * 4 + ((capNodes * 2 + 15u) & ~15u) + 3 * ldsHeapBytes(capNodes) + rows * rowWords * 4 + rowWords * 4 +
+         kEcLocal * 4 + pathBytes;
 }
 
 template <bool EPS>
@@ -808,55 +894,72 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   res.tier = 0;
 
   // HBM tier view of this workgroup's arena slot
-  Mem<1> g;
+  Mem<TierHbm> g;
   {
     uint8_t* p = arenaSlot;
-    g.nodes = (Mem<1>::PNode)p;                  p += (size_t)P.arena_nodes * 16;
-    g.open = (Mem<1>::P64)(p + 8);               p += (size_t)P.arena_nodes * 8 + 16;
-    g.focal = (Mem<1>::P64)(p + 8);              p += (size_t)P.arena_nodes * 8 + 16;
-    g.aux = (Mem<1>::P64)(p + 8);                p += (size_t)P.arena_nodes * 8 + 16;
-    g.bits = (Mem<1>::P32)p;
+    g.nodes = (Mem<TierHbm>::P32)p;              p += (size_t)P.arena_nodes * 16;
+    g.pos = nullptr;
+    g.open = (Mem<TierHbm>::PE)(p + 8);          p += (size_t)P.arena_nodes * 8 + 16;
+    g.focal = (Mem<TierHbm>::PE)(p + 8);         p += (size_t)P.arena_nodes * 8 + 16;
+    g.aux = (Mem<TierHbm>::PE)(p + 8);           p += (size_t)P.arena_nodes * 8 + 16;
+    g.bits = (Mem<TierHbm>::P32)p;
     g.capNodes = P.arena_nodes; g.capHeap = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
   }
 
-  const bool ldsOk = P.lds_nodes != 0 && c.wpr <= P.lds_row_words;
+  // the compact tier holds f in 7 bits: every f a search can reach inside its rows must fit
+  const bool ldsOk = P.lds_nodes != 0 && c.wpr <= P.lds_row_words &&
+                     (P.lds_rows - 1) + (c.dimx - 1) + (c.dimy - 1) <= TierLds::kFCap;
   if (ldsOk) {
-    Mem<3> m;
+    Mem<TierLds> m;
     uint8_t* p = smem;
-    m.nodes = (Mem<3>::PNode)p;                  p += P.lds_nodes * 16;
-    const uint32_t heapBytes = (P.lds_nodes / 2) * 8 + 16;
-    m.open = (Mem<3>::P64)(p + 8);               p += heapBytes;
-    m.focal = (Mem<3>::P64)(p + 8);              p += heapBytes;
-    m.aux = (Mem<3>::P64)(p + 8);                p += heapBytes;
-    m.bits = (Mem<3>::P32)p;                     p += P.lds_rows * P.lds_row_words * 4;
-    Mem<3>::P32 obstLocal = (Mem<3>::P32)p;      p += P.lds_row_words * 4;
-    Mem<3>::P32 ecLocal = (Mem<3>::P32)p;
+    m.nodes = (Mem<TierLds>::P32)p;              p += P.lds_nodes * 4;
+    m.pos = (Mem<TierLds>::P16)p;                p += (P.lds_nodes * 2 + 15u) & ~15u;
+    const uint32_t heapBytes = ldsHeapBytes(P.lds_nodes);
+    m.open = (Mem<TierLds>::PE)(p + 4);          p += heapBytes;
+    m.focal = (Mem<TierLds>::PE)(p + 4);         p += heapBytes;
+    m.aux = (Mem<TierLds>::PE)(p + 4);           p += heapBytes;
+    m.bits = (Mem<TierLds>::P32)p;               p += P.lds_rows * P.lds_row_words * 4;
+    Mem<TierLds>::P32 obstLocal = (Mem<TierLds>::P32)p;
     m.capNodes = P.lds_nodes; m.capHeap = P.lds_nodes / 2; m.capRows = P.lds_rows; m.rowWords = P.lds_row_words;
 
     __syncthreads();  // previous job's LDS reads are done
     for (uint32_t wd = lane; wd < c.wpr; wd += 64) obstLocal[wd] = c.obst[wd];
-    if (lane < kEcLocal && lane < c.nEc) ecLocal[lane] = c.ec[lane];
     __syncthreads();
 
-    initSearch<3, EPS>(m, s, c);
-    rc = runSearch<3, EPS>(m, s, c, obstLocal, ecLocal, true, res, outPath);
+    initSearch<TierLds, EPS>(m, s, c);
+    rc = runSearch<TierLds, EPS>(m, s, c, obstLocal, true, res, outPath);
     if (rc == RUN_MIGRATE_NODES || rc == RUN_MIGRATE_ROWS) {
-      // migrate the whole search state to the HBM arena and continue with the same code on global pointers
+      // migrate the whole search state to the HBM arena (records converted to that tier's formats) and continue with
+      // the same code on global pointers.  A migration happens at the top of an expansion, before anything was popped.
       res.tier = 1;
       __syncthreads();
-      for (uint32_t i = lane; i < s.nNodes; i += 64) g.nodes[i] = m.nodes[i];
-      for (uint32_t i = lane; i < s.nOpen; i += 64) g.open[i] = m.open[i];
-      for (uint32_t i = lane; i < s.nFocal; i += 64) g.focal[i] = m.focal[i];
+      for (uint32_t i = lane; i < s.nNodes; i += 64) {
+        const uint32_t w = m.nodes[i];
+        u32x4 nn;
+        nn.x = w & 0xFFFFu;
+        nn.y = w >> 16;
+        nn.z = 0;
+        nn.w = m.pos[i];
+        ((Mem<TierHbm>::PNode4)g.nodes)[i] = nn;
+      }
+      for (uint32_t i = lane; i < s.nOpen; i += 64) {
+        const uint32_t e = m.open[i];
+        g.open[i] = TierHbm::pack(TierLds::fh(e), TierLds::f(e), TierLds::g(e), TierLds::id(e));
+      }
+      for (uint32_t i = lane; i < s.nFocal; i += 64) {
+        const uint32_t e = m.focal[i];
+        g.focal[i] = TierHbm::pack(TierLds::fh(e), TierLds::f(e), TierLds::g(e), TierLds::id(e));
+      }
       for (uint32_t r = 0; r < s.rowsReady; ++r)
         for (uint32_t wd = lane; wd < c.wpr; wd += 64) g.bits[r * g.rowWords + wd] = m.bits[r * m.rowWords + wd];
       __syncthreads();
-      rc = runSearch<1, EPS>(g, s, c, (Mem<1>::P32)c.obst, (Mem<1>::P32)c.ec, false, res, outPath);
+      rc = runSearch<TierHbm, EPS>(g, s, c, (Mem<TierHbm>::P32)c.obst, false, res, outPath);
     }
   } else {
     res.tier = 1;
-    initSearch<1, EPS>(g, s, c);
+    initSearch<TierHbm, EPS>(g, s, c);
     __syncthreads();
-    rc = runSearch<1, EPS>(g, s, c, (Mem<1>::P32)c.obst, (Mem<1>::P32)c.ec, false, res, outPath);
+    rc = runSearch<TierHbm, EPS>(g, s, c, (Mem<TierHbm>::P32)c.obst, false, res, outPath);
   }
   if (rc == RUN_MIGRATE_NODES) rc = ST_CAP_NODES;
   if (rc == RUN_MIGRATE_ROWS) rc = ST_CAP_HORIZON;
@@ -885,14 +988,18 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
   const uint32_t gx = J.gx, gy = J.gy;
   const int64_t maxExp = J.max_expansions;
   const uint32_t* obst = P.maps + J.map_word_off;
-  Mem<1> g;
+  typedef TierHbm T;
+  Mem<T> g;
+  Mem<T>::PNode4 gNodes;
   {
     uint8_t* p = arenaSlot;
-    g.nodes = (Mem<1>::PNode)p;                  p += (size_t)P.arena_nodes * 16;
-    g.open = (Mem<1>::P64)(p + 8);               p += (size_t)P.arena_nodes * 8 + 16;
-    g.focal = (Mem<1>::P64)(p + 8);              p += (size_t)P.arena_nodes * 8 + 16;
-    g.aux = (Mem<1>::P64)(p + 8);                p += (size_t)P.arena_nodes * 8 + 16;
-    g.bits = (Mem<1>::P32)p;
+    g.nodes = (Mem<T>::P32)p;
+    gNodes = (Mem<T>::PNode4)p;                  p += (size_t)P.arena_nodes * 16;
+    g.pos = nullptr;
+    g.open = (Mem<T>::PE)(p + 8);                p += (size_t)P.arena_nodes * 8 + 16;
+    g.focal = (Mem<T>::PE)(p + 8);               p += (size_t)P.arena_nodes * 8 + 16;
+    g.aux = (Mem<T>::PE)(p + 8);                 p += (size_t)P.arena_nodes * 8 + 16;
+    g.bits = (Mem<T>::P32)p;
     g.capNodes = P.arena_nodes; g.capHeap = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
   }
   uint8_t* scratch = arenaSlot + P.arena_scratch_off;
@@ -932,8 +1039,8 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
     const uint32_t startTime = (uint32_t)J.last_goal_constraint;
     n0.z = startTime;
     n0.w = 0;
-    g.nodes[0] = n0;
-    g.open[0] = packEntry(0, h0, startTime, 0);
+    gNodes[0] = n0;
+    g.open[0] = T::pack(0, h0, startTime, 0);
     const uint32_t k = rfl(cellIdx[sc]);
     const uint32_t sid = k ? cells + rfl(specFirst[k - 1]) + si : sc;
     g.bits[sid] = 1;
@@ -943,9 +1050,9 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
       res.status = ST_NO_SOLUTION;
       break;
     }
-    const uint64_t curE = ld64<1>(g.open, 0);
-    const uint32_t curId = entryId(curE);
-    const u32x4 nd = g.nodes[curId];
+    const uint64_t curE = ldU<T>(g.open, 0);
+    const uint32_t curId = T::id(curE);
+    const u32x4 nd = gNodes[curId];
     const uint32_t cw = rfl(nd.x);
     const uint32_t cell = cw & 0xFFFF, iv = cw >> 16;
     const uint32_t gcur = rfl(nd.z);
@@ -966,7 +1073,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
     if (cx == gx && cy == gy && endT == kIntMax) {
       // raw A* solution: (cell, g) per state; the host inserts the explicit Wait actions (sipp.hpp:105-128)
       uint32_t len = 0;
-      for (uint32_t nid = curId; nid != kNoParent; nid = rfl(g.nodes[nid].y)) len += 1;
+      for (uint32_t nid = curId; nid != kNoParent; nid = rfl(gNodes[nid].y)) len += 1;
       if (len * 2 > P.out_stride) {
         res.status = ST_CAP_HORIZON;
         break;
@@ -974,17 +1081,17 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
       uint32_t* out32 = (uint32_t*)outPath;
       uint32_t nid = curId;
       for (int32_t k = (int32_t)len - 1; k >= 0; --k) {
-        const u32x4 pn = g.nodes[nid];
+        const u32x4 pn = gNodes[nid];
         out32[k] = (rfl(pn.x) & 0xFFFF) | (rfl(pn.z) << 16);
         nid = rfl(pn.y);
       }
       res.status = ST_OK;
       res.cost = (int32_t)gcur;
-      res.fmin = entryF(curE);
+      res.fmin = (int32_t)T::f(curE);
       res.n_states = (int32_t)len;
       break;
     }
-    heapPop<1, 0, true>(g, g.open, nOpen);
+    heapPop<T, 0, true>(g, g.open, nOpen);
     g.bits[curSid] = kStClosed;
     const uint32_t startT = gcur + 1;
     if (startT > kGMask) {
@@ -1077,13 +1184,13 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
               nn.y = curId;
               nn.z = t;
               nn.w = 0;
-              g.nodes[nid] = nn;
+              gNodes[nid] = nn;
               g.bits[sid] = nid + 1;
-              e[k] = packEntry(0, t + hN, t, nid);
+              e[k] = T::pack(0, t + hN, t, nid);
             }
           }
           const uint32_t pm = (1u << nNew) - 1u;
-          PushChains<1> pc;
+          PushChains<T> pc;
           pc.load(g.open, nOpen, pm);
           pc.template resolve<0, true>(g, g.open, nOpen, pm, e);
           nNodes += nNew;
@@ -1112,19 +1219,19 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
             nn.y = curId;
             nn.z = t;
             nn.w = 0;
-            g.nodes[nid] = nn;
+            gNodes[nid] = nn;
             g.bits[sid] = nid + 1;
-            siftUp<1, 0, true>(g, g.open, nOpen, packEntry(0, t + hN, t, nid));
+            siftUp<T, 0, true>(g, g.open, nOpen, T::pack(0, t + hN, t, nid));
             nOpen += 1;
           } else {                                         // already in open (a_star.hpp:130-146)
             const uint32_t nid = st - 1;
-            const u32x4 on = g.nodes[nid];
+            const u32x4 on = gNodes[nid];
             if (t >= rfl(on.z)) continue;
             u32x4 nn = on;
             nn.y = curId;
             nn.z = t;
-            g.nodes[nid] = nn;                             // cameFrom update + new g
-            siftUp<1, 0, true>(g, g.open, rfl(on.w), packEntry(0, t + hN, t, nid));  // increase(handle)
+            gNodes[nid] = nn;                             // cameFrom update + new g
+            siftUp<T, 0, true>(g, g.open, rfl(on.w), T::pack(0, t + hN, t, nid));  // increase(handle)
           }
         }
       }
@@ -1178,19 +1285,19 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
               nn.y = curId;
               nn.z = t;
               nn.w = 0;
-              g.nodes[nid] = nn;
+              gNodes[nid] = nn;
               g.bits[sid] = nid + 1;
-              siftUp<1, 0, true>(g, g.open, nOpen, packEntry(0, t + hN, t, nid));
+              siftUp<T, 0, true>(g, g.open, nOpen, T::pack(0, t + hN, t, nid));
               nOpen += 1;
             } else {                                         // already in open (a_star.hpp:130-146)
               const uint32_t nid = st - 1;
-              const u32x4 on = g.nodes[nid];
+              const u32x4 on = gNodes[nid];
               if (t >= rfl(on.z)) continue;
               u32x4 nn = on;
               nn.y = curId;
               nn.z = t;
-              g.nodes[nid] = nn;                             // cameFrom update + new g
-              siftUp<1, 0, true>(g, g.open, rfl(on.w), packEntry(0, t + hN, t, nid));  // increase(handle)
+              gNodes[nid] = nn;                             // cameFrom update + new g
+              siftUp<T, 0, true>(g, g.open, rfl(on.w), T::pack(0, t + hN, t, nid));  // increase(handle)
             }
           }
         }

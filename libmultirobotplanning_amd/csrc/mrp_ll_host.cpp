@@ -140,6 +140,13 @@ struct Ring {
   bool active = false;
   uint32_t grid = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // Optional second resident launch of the same session (MRP_LL_EXTRA_HBM_WGS): workgroups WITHOUT an LDS tier (their
+  // searches live in the HBM arena / L2 from the start) on a stream of their own.  They take tickets from the same
+  // rings; the LDS tier caps the first launch at floor(160 KiB / tier bytes) workgroups per CU, these fill SIMD issue
+  // slots beyond that.
+  uint32_t grid2 = 0;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev2 = nullptr;
   // SIPP sessions (mrp_ll_session_begin_sipp): the jobs' safe-interval tables are far larger than a slot's constraint
   // area, so they get their own pinned buffer, and only the first kSippSlots job slots are used
   static constexpr uint32_t kSippSlots = 512;
@@ -172,6 +179,7 @@ struct mrp_ll_ctx {
   size_t mapsDevCap = 0;
   bool mapsDirty = false;
   uint32_t maxWpr = 1;
+  uint32_t extraHbmWgs = 0;       // session mode: additional resident workgroups without an LDS tier (see Ring::grid2)
   uint32_t tierRows = 64, tierPathBytes = 4096;  // LDS tier geometry (mrp_ll_configure_tiers); nodes live in opt.lds_nodes
   uint32_t sessionRowWords = 0;   // LDS bitmap row width the resident kernel was launched with
   uint32_t arenaRowWords = 0;
@@ -544,7 +552,7 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
     if (fixed + 16 * rowWords * 4 <= budget) {
       uint32_t rowsWanted = ctx->tierRows;
       if (const char* e = std::getenv("MRP_LL_LDS_ROWS")) rowsWanted = std::max(8, std::atoi(e));  // tuning knob
-      rows = std::min<uint32_t>(rowsWanted, (budget - fixed) / (rowWords * 4));
+      rows = std::min<uint32_t>(std::min<uint32_t>(rowsWanted, 64u), (budget - fixed) / (rowWords * 4));
       rows = std::min<uint32_t>(rows, static_cast<uint32_t>(ctx->opt.max_horizon));
       ldsBytes = mrp_ll_lds_bytes(ldsNodes, rows, rowWords, ldsPaths);
     } else {
@@ -687,7 +695,8 @@ int mrp_ll_create(const mrp_ll_options* optIn, mrp_ll_ctx** out) {
   if (o.max_cells > 255 * 255) o.max_cells = 255 * 255;
   if (o.lds_nodes == 0) o.lds_nodes = 512;
   if (o.lds_nodes < 0) o.lds_nodes = 0;
-  o.lds_nodes &= ~3;  // heap arrays hold lds_nodes / 2 entries and stay 16-byte aligned
+  o.lds_nodes = std::min(o.lds_nodes, 512);  // 9-bit node ids in the compact tier's heap entries
+  o.lds_nodes &= ~3;  // heap arrays hold lds_nodes / 2 entries and stay 8-byte aligned
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || o.device < 0 || o.device >= ndev) {
@@ -735,6 +744,8 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
   if (ctx->ring.active) (void)mrp_ll_session_end(ctx);
   if (ctx->ring.ev0) (void)hipEventDestroy(ctx->ring.ev0);
   if (ctx->ring.ev1) (void)hipEventDestroy(ctx->ring.ev1);
+  if (ctx->ring.ev2) (void)hipEventDestroy(ctx->ring.ev2);
+  if (ctx->ring.stream2) (void)hipStreamDestroy(ctx->ring.stream2);
   if (ctx->ring.block) (void)hipHostFree(ctx->ring.block);
   if (ctx->ring.sippCons) (void)hipHostFree(ctx->ring.sippCons);
   if (ctx->ring.compCountDev) (void)hipFree(ctx->ring.compCountDev);
@@ -812,15 +823,16 @@ int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t ldsNodes, int32_t ldsRows, i
   for (const Ticket& t : ctx->tickets)
     if (t.inFlight) return MRP_LL_E_BUSY;
   if (ldsNodes < 0) ctx->opt.lds_nodes = 0;
-  if (ldsNodes > 0) ctx->opt.lds_nodes = std::max(8, std::min(ldsNodes, 8192) & ~3);
-  if (ldsRows > 0) ctx->tierRows = static_cast<uint32_t>(std::min(std::max(ldsRows, 8), 1024));
+  // the compact LDS tier addresses 512 nodes and 64 time steps (9-bit node ids and 6-bit g in its 32-bit heap entries)
+  if (ldsNodes > 0) ctx->opt.lds_nodes = std::max(8, std::min(ldsNodes, 512) & ~3);
+  if (ldsRows > 0) ctx->tierRows = static_cast<uint32_t>(std::min(std::max(ldsRows, 8), 64));
   if (ldsPathBytes > 0) ctx->tierPathBytes = static_cast<uint32_t>(std::min(ldsPathBytes, 65536)) & ~31u;
   if (occOut) {
     const uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
     const uint32_t bytes = ctx->opt.lds_nodes
                                ? mrp_ll_lds_bytes(static_cast<uint32_t>(ctx->opt.lds_nodes), ctx->tierRows, rowWords, ctx->tierPathBytes) + 256
                                : 0;
-    *occOut = bytes ? static_cast<int32_t>(std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / bytes))) : 8;
+    *occOut = bytes ? static_cast<int32_t>(std::max<uint32_t>(1, std::min<uint32_t>(16, (160u * 1024u) / bytes))) : 16;
   }
   return MRP_LL_SUCCESS;
 }
@@ -953,6 +965,29 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
   else
     HIPCHK(ctx, mrp_ll_launch_persistent(&P, g.grid, ldsBytes, kind, t.stream));
   g.kind = sipp ? 0 : kind;
+  g.grid2 = 0;
+  if (!sipp && ldsBytes != 0) {
+    uint32_t extra = ctx->extraHbmWgs;
+    if (const char* e = std::getenv("MRP_LL_EXTRA_HBM_WGS")) extra = static_cast<uint32_t>(std::max(0, std::atoi(e)));
+    extra = std::min<uint32_t>(extra, static_cast<uint32_t>(ctx->opt.slots) - g.grid);
+    if (extra) {
+      if (!g.stream2) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreate(&g.ev2));
+      }
+      mrp::LaunchParams P2 = P;
+      P2.lds_nodes = 0;
+      P2.lds_rows = 0;
+      P2.lds_paths_bytes = 0;
+      P2.arena = t.arena + static_cast<uint64_t>(g.grid) * ctx->arenaStride;  // arena slots behind the first launch's
+      // the counters the workgroups take tickets from are zeroed on t.stream: order this launch behind that
+      HIPCHK(ctx, hipStreamWaitEvent(g.stream2, g.ev0, 0));
+      HIPCHK(ctx, mrp_ll_launch_persistent(&P2, extra, 0, kind, g.stream2));
+      HIPCHK(ctx, hipEventRecord(g.ev2, g.stream2));
+      g.grid2 = extra;
+      ctx->stats.launches += 1;
+    }
+  }
   HIPCHK(ctx, hipEventRecord(g.ev1, t.stream));
   g.active = true;
   ctx->stats.launches += 1;
@@ -974,6 +1009,7 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   __atomic_store_n(g.stop, 1u, __ATOMIC_RELEASE);
   HIPCHK(ctx, hipEventSynchronize(g.ev1));
+  if (g.grid2) HIPCHK(ctx, hipEventSynchronize(g.ev2));
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) ctx->stats.kernel_ms += ms;
   {

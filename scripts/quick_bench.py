@@ -8,14 +8,14 @@ agents = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 threads = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 slots = int(sys.argv[4]) if len(sys.argv) > 4 else 512
 t0 = time.time()
-insts = [hl.generate_instance(1000 * agents + k, 32, 32, 204, agents) for k in range(n_inst)]
+insts = hl.generate_instances(1000 * agents, n_inst, 32, 32, 204, agents)
 print("generated %d instances in %.2fs" % (n_inst, time.time() - t0), flush=True)
 s = hl.BatchSolver(device=0, n_threads=threads, slots=slots, lds_nodes=int(os.environ.get('MRP_LDS_NODES', '0')),
                    _lib_path=os.environ.get('MRP_HL_LIB'))  # MRP_HL_LIB: A/B against another build of libmrp_hl.so
 print("solver created %.2fs" % (time.time() - t0), flush=True)
 cpu_n = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 mode = int(os.environ.get('MRP_HL_MODE', '0'))
-for rep in range(3):
+for rep in range(int(os.environ.get('MRP_REPS', '3'))):
     s.ll_stats(reset=True)
     res, st = s.solve(insts, algo=hl.ECBS, w=1.3, want_paths=False, max_ll_expansions=int(os.environ.get("MRP_CAP", "50000")), mode=mode)
     ls = s.ll_stats()
