@@ -70,10 +70,13 @@ typedef struct mrp_hl_batch_stats {
   double wall_seconds;            /* timed region: all conflict-tree searches of the batch, first submit to last result */
   int64_t rounds;                 /* mrp_ll_submit calls                                                          */
   int64_t ll_searches;
-  int64_t ll_expansions;          /* over every search that was run (== sum of solutions' low_level_expanded)     */
+  int64_t ll_expansions;          /* of the searches the conflict trees consumed (== sum of solutions' low_level_expanded) */
   int64_t solved;
   /* host-side time summed over worker threads (diagnostic): building jobs, inside mrp_ll_search_batch, consuming results */
   double build_seconds, ll_call_seconds, consume_seconds;
+  /* look-ahead of the conflict-tree machines (session mode; MRP_HL_SPEC): searches issued before their CT node was popped,
+   * and the expansions of searches that were run but whose node was never popped (work, not part of ll_expansions) */
+  int64_t speculative_searches, wasted_ll_expansions;
 } mrp_hl_batch_stats;
 
 /* One engine context per calling thread is created internally for every worker thread on `device`. */

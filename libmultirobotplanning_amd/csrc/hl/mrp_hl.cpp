@@ -51,20 +51,97 @@ constexpr int64_t kDeepHl = INT64_MAX;
 constexpr double kNoProgressLimitS = 600.0;
 
 struct GroupResult {
-  int64_t rounds = 0, searches = 0, expansions = 0;
+  int64_t rounds = 0, searches = 0, expansions = 0;  // expansions: of the searches the conflict trees CONSUMED
+  int64_t specSearches = 0, specWasted = 0;          // searches issued ahead of their node's pop; expansions that were run but never consumed
   double buildS = 0, llS = 0, consumeS = 0;
   std::string err;
 };
 
-// Drives instances idx[...] to completion on one engine.
+// One low-level job of the C-ABI for request `r` of instance `I`; the focal-context arrays go to the pools (pointers
+// are patched in by the caller once the pools have stopped growing).
+void fillJob(const Instance& I, const LLRequest& r, mrp_ll_job& j, std::vector<int32_t>& pathLenPool,
+             std::vector<const int32_t*>& pathPtrPool) {
+  std::memset(&j, 0, sizeof(j));
+  j.map_id = I.mapId();
+  j.algo = I.algo() == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR;
+  j.w = I.w();
+  j.agent_idx = r.agent;
+  j.start_x = I.start(r.agent)[0];
+  j.start_y = I.start(r.agent)[1];
+  j.goal_x = I.goal(r.agent)[0];
+  j.goal_y = I.goal(r.agent)[1];
+  j.n_vertex_constraints = static_cast<int32_t>(r.constraints->vertex.size() / 3);
+  j.vertex_constraints = r.constraints->vertex.data();
+  j.n_edge_constraints = static_cast<int32_t>(r.constraints->edge.size() / 5);
+  j.edge_constraints = r.constraints->edge.data();
+  j.max_expansions = I.remainingLL();
+  if (r.context) {
+    j.n_agents = static_cast<int32_t>(r.context->size());
+    for (const PathPtr& p : *r.context) {
+      pathLenPool.push_back(p->len());
+      pathPtrPool.push_back(p->xy.data());
+    }
+  }
+}
+
+LLAnswer answerOf(const mrp_ll_result& r) {
+  LLAnswer a;
+  a.status = r.status;
+  a.cost = r.cost;
+  a.fmin = r.fmin;
+  a.expanded = r.expanded;
+  if (r.status == MRP_LL_OK) {
+    auto p = std::make_shared<Path>();
+    p->xy.resize(static_cast<size_t>(r.n_states) * 2);
+    uint32_t orAll = 0;
+    for (int32_t s = 0; s < r.n_states; ++s) {
+      p->xy[2 * s] = r.states_txy[3 * s + 1];
+      p->xy[2 * s + 1] = r.states_txy[3 * s + 2];
+      orAll |= static_cast<uint32_t>(p->xy[2 * s]) | static_cast<uint32_t>(p->xy[2 * s + 1]);
+    }
+    p->fits8 = orAll < 256u;
+    p->cost = r.cost;
+    p->fmin = r.fmin;
+    a.path = p;
+  }
+  return a;
+}
+
+void writeSolution(const Instance& I, mrp_hl_solution& s) {
+  s.status = I.status();
+  s.n_ll_searches = I.llSearches();
+  s.high_level_expanded = I.hlExpanded();
+  s.low_level_expanded = I.llExpanded();
+  s.cost = 0;
+  s.makespan = 0;
+  if (I.status() == MRP_HL_SOLVED) {
+    const auto& sol = I.finalSolution();
+    for (int32_t a = 0; a < I.nAgents(); ++a) {
+      s.cost += sol[a]->cost;
+      s.makespan = std::max<int64_t>(s.makespan, sol[a]->cost);
+      if (s.path_len) s.path_len[a] = sol[a]->len();
+      if (s.paths_xy) {
+        int32_t m = std::min(sol[a]->len(), s.path_cap);
+        std::memcpy(s.paths_xy + static_cast<size_t>(a) * s.path_cap * 2, sol[a]->xy.data(), sizeof(int32_t) * 2 * m);
+      }
+    }
+  }
+}
+
+// Speculation width of the conflict-tree machines (ct_solver.hpp): MRP_HL_SPEC=k; default 4.
+int32_t specWidthSetting() {
+  if (const char* e = std::getenv("MRP_HL_SPEC")) return std::max(1, std::atoi(e));
+  return 4;
+}
+
+// Drives instances idx[...] to completion on one engine, one mrp_ll_search_batch per round of ready searches.
 void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance* instIn, mrp_hl_solution* sols,
               const std::vector<int32_t>& idx, const std::vector<int32_t>& mapIds, int32_t horizon, GroupResult& out) {
   const size_t n = idx.size();
   std::vector<std::unique_ptr<Instance>> inst(n);
   for (size_t k = 0; k < n; ++k) inst[k].reset(new Instance(instIn[idx[k]], mapIds[k], opt));
-  std::vector<std::vector<LLRequest>> req(n);
-  std::vector<std::vector<LLAnswer>> ans(n);
-  for (size_t k = 0; k < n; ++k) inst[k]->advance(ans[k], req[k]);
+  std::vector<std::vector<LLRequest>> req(n), nextReq(n);
+  for (size_t k = 0; k < n; ++k) inst[k]->start(req[k]);
 
   std::vector<mrp_ll_job> jobs;
   std::vector<mrp_ll_result> results;
@@ -73,7 +150,9 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
   std::vector<const int32_t*> pathPtrPool;
   std::vector<size_t> poolOff;
   std::vector<int32_t> statesPool;
+  std::vector<LLAnswer> ans;
   const int32_t cap = horizon;
+  int64_t ranExpansions = 0;
 
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -88,30 +167,9 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
     poolOff.clear();
     for (size_t k = 0; k < n; ++k) {
       for (const LLRequest& r : req[k]) {
-        const Instance& I = *inst[k];
         mrp_ll_job j;
-        std::memset(&j, 0, sizeof(j));
-        j.map_id = I.mapId();
-        j.algo = I.algo() == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR;
-        j.w = I.w();
-        j.agent_idx = r.agent;
-        j.start_x = I.start(r.agent)[0];
-        j.start_y = I.start(r.agent)[1];
-        j.goal_x = I.goal(r.agent)[0];
-        j.goal_y = I.goal(r.agent)[1];
-        j.n_vertex_constraints = static_cast<int32_t>(r.constraints->vertex.size() / 3);
-        j.vertex_constraints = r.constraints->vertex.data();
-        j.n_edge_constraints = static_cast<int32_t>(r.constraints->edge.size() / 5);
-        j.edge_constraints = r.constraints->edge.data();
-        j.max_expansions = I.remainingLL();
         poolOff.push_back(pathLenPool.size());
-        if (r.context) {
-          j.n_agents = static_cast<int32_t>(r.context->size());
-          for (const PathPtr& p : *r.context) {
-            pathLenPool.push_back(p->len());
-            pathPtrPool.push_back(p->xy.data());
-          }
-        }
+        fillJob(*inst[k], r, j, pathLenPool, pathPtrPool);
         jobs.push_back(j);
         owner.push_back(static_cast<int32_t>(k));
       }
@@ -140,34 +198,25 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
     }
     out.rounds += 1;
     out.searches += static_cast<int64_t>(jobs.size());
-    for (size_t k = 0; k < n; ++k) ans[k].clear();
-    for (size_t q = 0; q < jobs.size(); ++q) {
-      const mrp_ll_result& r = results[q];
-      LLAnswer a;
-      a.status = r.status;
-      a.cost = r.cost;
-      a.fmin = r.fmin;
-      a.expanded = r.expanded;
-      out.expansions += r.expanded;
-      if (r.status == MRP_LL_OK) {
-        auto p = std::make_shared<Path>();
-        p->xy.resize(static_cast<size_t>(r.n_states) * 2);
-        uint32_t orAll = 0;
-        for (int32_t s = 0; s < r.n_states; ++s) {
-          p->xy[2 * s] = r.states_txy[3 * s + 1];
-          p->xy[2 * s + 1] = r.states_txy[3 * s + 2];
-          orAll |= static_cast<uint32_t>(p->xy[2 * s]) | static_cast<uint32_t>(p->xy[2 * s + 1]);
-        }
-        p->fits8 = orAll < 256u;
-        p->cost = r.cost;
-        p->fmin = r.fmin;
-        a.path = p;
-      }
-      ans[owner[q]].push_back(a);
-    }
+    // answers go back group by group (the requests of one group are consecutive), in request order
+    size_t q = 0;
     for (size_t k = 0; k < n; ++k) {
-      if (req[k].empty()) continue;
-      inst[k]->advance(ans[k], req[k]);
+      nextReq[k].clear();
+      const std::vector<LLRequest>& rq = req[k];
+      for (size_t a = 0; a < rq.size();) {
+        size_t b = a;
+        ans.clear();
+        while (b < rq.size() && rq[b].group == rq[a].group) {
+          ranExpansions += results[q].expanded;
+          ans.push_back(answerOf(results[q]));
+          ++q;
+          ++b;
+        }
+        inst[k]->deliver(rq[a].group, ans, nextReq[k]);
+        a = b;
+      }
+      if (inst[k]->done()) nextReq[k].clear();  // requests of a finished instance point into freed CT nodes
+      req[k].swap(nextReq[k]);
     }
     auto tD = now();
     out.buildS += secs(tA, tB);
@@ -175,31 +224,18 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
     out.consumeS += secs(tC, tD);
   }
   for (size_t k = 0; k < n; ++k) {
-    const Instance& I = *inst[k];
-    mrp_hl_solution& s = sols[idx[k]];
-    s.status = I.status();
-    s.n_ll_searches = I.llSearches();
-    s.high_level_expanded = I.hlExpanded();
-    s.low_level_expanded = I.llExpanded();
-    s.cost = 0;
-    s.makespan = 0;
-    if (I.status() == MRP_HL_SOLVED) {
-      const auto& sol = I.finalSolution();
-      for (int32_t a = 0; a < I.nAgents(); ++a) {
-        s.cost += sol[a]->cost;
-        s.makespan = std::max<int64_t>(s.makespan, sol[a]->cost);
-        if (s.path_len) s.path_len[a] = sol[a]->len();
-        if (s.paths_xy) {
-          int32_t m = std::min(sol[a]->len(), s.path_cap);
-          std::memcpy(s.paths_xy + static_cast<size_t>(a) * s.path_cap * 2, sol[a]->xy.data(), sizeof(int32_t) * 2 * m);
-        }
-      }
-    }
+    writeSolution(*inst[k], sols[idx[k]]);
+    out.expansions += inst[k]->llExpanded();
+    out.specSearches += inst[k]->specSearches();
   }
+  out.specWasted += ranExpansions - out.expansions;
 }
 
-// Session mode: the engine keeps `workgroups` wavefronts resident (mrp_ll_session_begin) and every instance submits
-// its next searches the moment its previous ones have finished — no instance ever waits for another one's search.
+// Session mode: the engine keeps `workgroups` wavefronts resident (mrp_ll_session_begin_algo) and every instance submits
+// its next searches the moment the ones they depend on have finished — no instance ever waits for another one's search.
+// Every group of requests (the two children of one CT node, or a root step) is one ticket.  While fewer searches are
+// in flight than the engine has resident wavefronts, the conflict-tree machines look ahead (ct_solver.hpp,
+// "speculative expansion"): idle wavefronts pre-compute the children of the nodes that will probably be popped next.
 // `shared` != nullptr: the workers draw instances 0..nTotal-1 from one counter as their own active set drains, so a
 // worker whose instances turn out easy takes more of them (map id of instance k on this engine = mapBase + k);
 // otherwise the worker owns exactly idx[...].
@@ -211,99 +247,133 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   const size_t n = shared ? static_cast<size_t>(nTotal) : idx.size();
   struct Live {
     std::unique_ptr<Instance> inst;
-    std::vector<LLRequest> req;
-    std::vector<LLAnswer> ans;
+    std::vector<LLRequest> req;   // not submitted yet: req[reqHead..)
+    size_t reqHead = 0;
+    bool queued = false;          // in `backlog`
+    bool counted = false;         // its completion has been taken off nActive
+    double tAdmit = 0, tDone = 0;  // MRP_HL_TIMING only: seconds since the loop started
+  };
+  struct Pending {                // one ticket in flight
+    size_t live = 0;
+    int32_t group = 0;
     std::vector<mrp_ll_result> res;
     std::vector<int32_t> states;
-    int32_t ticket = -1;
-    bool waitingToSubmit = false;
-    double tAdmit = 0, tDone = 0;  // MRP_HL_TIMING only: seconds since the loop started
   };
   std::deque<Live> live;        // grows as instances are admitted; references stay valid
   std::vector<int32_t> gidx;    // live entry -> instance index
+  std::deque<Pending> pend;
+  std::vector<int32_t> pendFree;
+  std::vector<int32_t> ticketPend;  // session ticket id -> pend entry
   const int32_t cap = horizon;
   std::vector<mrp_ll_job> jobs;
   std::vector<int32_t> pathLenPool;
   std::vector<const int32_t*> pathPtrPool;
   std::vector<size_t> poolOff;
+  std::vector<LLAnswer> ans;
 
   const bool timing = std::getenv("MRP_HL_TIMING") != nullptr;
   int64_t deepHl = kDeepHl;
   if (const char* e = std::getenv("MRP_HL_DEEP")) deepHl = std::atoll(e);  // tuning knob
+  const int32_t specK = specWidthSetting();
   auto tg0 = std::chrono::steady_clock::now();
   if (mrp_ll_session_begin_algo(ctx, opt.algo == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR, workgroups) != MRP_LL_SUCCESS) {
     out.err = std::string("mrp_ll_session_begin_algo: ") + mrp_ll_last_error(ctx);
     return;
   }
-  // returns 1 submitted, 0 ring full (retry later), -1 error
-  auto trySubmit = [&](Live& L) -> int {
+  size_t ticketsOut = 0;
+  int64_t jobsOut = 0, ranExpansions = 0;
+  // Submits the first group of live[k]'s unsent requests.  Returns 1 submitted, 0 ring full (retry later), -1 error.
+  auto submitGroup = [&](size_t k) -> int {
+    Live& L = live[k];
     const Instance& I = *L.inst;
     jobs.clear();
     pathLenPool.clear();
     pathPtrPool.clear();
     poolOff.clear();
-    for (const LLRequest& r : L.req) {
+    const int32_t group = L.req[L.reqHead].group;
+    size_t end = L.reqHead;
+    while (end < L.req.size() && L.req[end].group == group) {
       mrp_ll_job j;
-      std::memset(&j, 0, sizeof(j));
-      j.map_id = I.mapId();
-      j.algo = I.algo() == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR;
-      j.w = I.w();
-      j.agent_idx = r.agent;
-      j.start_x = I.start(r.agent)[0];
-      j.start_y = I.start(r.agent)[1];
-      j.goal_x = I.goal(r.agent)[0];
-      j.goal_y = I.goal(r.agent)[1];
-      j.n_vertex_constraints = static_cast<int32_t>(r.constraints->vertex.size() / 3);
-      j.vertex_constraints = r.constraints->vertex.data();
-      j.n_edge_constraints = static_cast<int32_t>(r.constraints->edge.size() / 5);
-      j.edge_constraints = r.constraints->edge.data();
-      j.max_expansions = I.remainingLL();
       poolOff.push_back(pathLenPool.size());
-      if (r.context) {
-        j.n_agents = static_cast<int32_t>(r.context->size());
-        for (const PathPtr& p : *r.context) {
-          pathLenPool.push_back(p->len());
-          pathPtrPool.push_back(p->xy.data());
-        }
-      }
+      fillJob(I, L.req[end], j, pathLenPool, pathPtrPool);
       jobs.push_back(j);
+      ++end;
     }
     for (size_t q = 0; q < jobs.size(); ++q)
       if (jobs[q].n_agents > 0) {
         jobs[q].path_len = pathLenPool.data() + poolOff[q];
         jobs[q].path_xy = pathPtrPool.data() + poolOff[q];
       }
-    L.res.assign(jobs.size(), mrp_ll_result());
-    L.states.resize(jobs.size() * static_cast<size_t>(cap) * 3);
+    int32_t pi;
+    if (!pendFree.empty()) {
+      pi = pendFree.back();
+      pendFree.pop_back();
+    } else {
+      pend.emplace_back();
+      pi = static_cast<int32_t>(pend.size()) - 1;
+    }
+    Pending& P = pend[pi];
+    P.live = k;
+    P.group = group;
+    P.res.assign(jobs.size(), mrp_ll_result());
+    P.states.resize(jobs.size() * static_cast<size_t>(cap) * 3);
     for (size_t q = 0; q < jobs.size(); ++q) {
-      std::memset(&L.res[q], 0, sizeof(mrp_ll_result));
-      L.res[q].states_txy = L.states.data() + q * static_cast<size_t>(cap) * 3;
-      L.res[q].states_cap = cap;
+      std::memset(&P.res[q], 0, sizeof(mrp_ll_result));
+      P.res[q].states_txy = P.states.data() + q * static_cast<size_t>(cap) * 3;
+      P.res[q].states_cap = cap;
     }
     // an instance deep in its conflict tree is a long chain of dependent rounds: its searches take the priority lane,
     // which every workgroup serves before the bulk, so the chain advances alongside the bulk instead of after it
     const int32_t lane = I.hlExpanded() >= deepHl ? 1 : 0;
-    int rc = mrp_ll_submit_lane(ctx, lane, static_cast<int32_t>(jobs.size()), jobs.data(), L.res.data(), &L.ticket);
-    if (rc == MRP_LL_E_BUSY) return 0;
+    int32_t ticket = -1;
+    int rc = mrp_ll_submit_lane(ctx, lane, static_cast<int32_t>(jobs.size()), jobs.data(), P.res.data(), &ticket);
+    if (rc == MRP_LL_E_BUSY) {
+      pendFree.push_back(pi);
+      return 0;
+    }
     if (rc != MRP_LL_SUCCESS) {
       out.err = std::string("mrp_ll_submit: ") + mrp_ll_last_error(ctx);
       return -1;
     }
+    if (static_cast<size_t>(ticket) >= ticketPend.size()) ticketPend.resize(ticket + 1, -1);
+    ticketPend[ticket] = pi;
+    L.reqHead = end;
+    if (L.reqHead == L.req.size()) {
+      L.req.clear();
+      L.reqHead = 0;
+    }
+    ticketsOut += 1;
+    jobsOut += static_cast<int64_t>(jobs.size());
     out.rounds += 1;
     out.searches += static_cast<int64_t>(jobs.size());
     return 1;
   };
+  // Submits as many groups of live[k] as the ring takes; false on error.  Leaves it in the backlog if some remain.
+  std::vector<size_t> backlog;
+  auto submitAll = [&](size_t k) -> bool {
+    Live& L = live[k];
+    while (L.reqHead < L.req.size()) {
+      int r = submitGroup(k);
+      if (r < 0) return false;
+      if (r == 0) {
+        if (!L.queued) {
+          L.queued = true;
+          backlog.push_back(k);
+        }
+        return true;
+      }
+    }
+    return true;
+  };
 
   auto tg1 = std::chrono::steady_clock::now();
-  std::vector<size_t> backlog;
-  size_t nInflight = 0;
   std::vector<int32_t> doneTickets(64);  // small harvest chunks keep the latency of any one instance's chain low
-  std::vector<size_t> ticketOwner;  // session ticket id -> local instance
-  std::vector<size_t> doneOwners;
+  std::vector<int32_t> donePend;
   // Admission control (MRP_HL_ACTIVE_LIMIT): at most that many instances of this worker are active at a time; the rest
   // wait in the pool.  With the job slots recycled in completion order it costs nothing (measured 1536..3584 at the
   // bench shape: same step time as "everything at once"), and with a shared pool it is what lets the workers balance.
   size_t nextStatic = 0;
+  size_t nActive = 0;
   bool exhausted = false;
   // shared pool: no worker may hold more than its fair share at a time, or a small batch is drained by the first few
   size_t activeLimit =
@@ -333,50 +403,60 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     if (timing) live.back().tAdmit = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
     return true;
   };
+  // look ahead only while the engine has idle wavefronts: speculative searches must not queue in front of real ones
+  auto specNow = [&]() -> int32_t { return jobsOut < static_cast<int64_t>(workgroups) ? specK : 1; };
+  auto retire = [&](Live& L) {
+    if (!L.counted && L.inst->done()) {
+      L.counted = true;
+      nActive -= 1;
+      L.req.clear();  // requests of a finished instance point into freed CT nodes
+      L.reqHead = 0;
+      if (timing) L.tDone = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
+    }
+  };
   bool failed = false;
   auto t0 = std::chrono::steady_clock::now();
   auto tg2 = t0;
   uint64_t idleSpins = 0;
   bool sinceProgress = false;
   auto lastProgress = t0;
-  double tmSubmitOk = 0, tmSubmitBusy = 0, tmPollEmpty = 0, tmPollHit = 0, tmUnpack = 0, tmAdvance = 0;
-  uint64_t nSubmitBusy = 0, nPollEmpty = 0, nPollHit = 0;
+  double tmSubmit = 0, tmPollEmpty = 0, tmPollHit = 0, tmUnpack = 0, tmAdvance = 0;
+  uint64_t nPollEmpty = 0, nPollHit = 0;
   auto nowS = []() { return std::chrono::steady_clock::now(); };
   auto secsS = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double>(b - a).count();
   };
-  while (!failed && (nInflight != 0 || !backlog.empty() || !exhausted)) {
+  while (!failed && (ticketsOut != 0 || !backlog.empty() || !exhausted)) {
     bool progress = false;
     auto tA = nowS();
-    while (!exhausted && nInflight + backlog.size() < activeLimit && admit()) {
-      Live& L = live.back();
-      L.inst->advance(L.ans, L.req);
-      if (!L.req.empty()) backlog.push_back(live.size() - 1);
+    while (!exhausted && nActive < activeLimit && admit()) {
+      const size_t k = live.size() - 1;
+      Live& L = live[k];
+      nActive += 1;
+      L.inst->setSpecWidth(specNow());
+      L.inst->start(L.req);
+      retire(L);
+      if (!submitAll(k)) failed = true;
       progress = true;
+      if (failed) break;
     }
-    // publish as many waiting instances as the ring takes
+    if (failed) break;
+    // publish what the ring refused earlier
     while (!backlog.empty()) {
-      size_t k = backlog.back();
-      auto ts0 = nowS();
-      int r = trySubmit(live[k]);
-      if (r < 0) {
+      const size_t k = backlog.back();
+      backlog.pop_back();
+      live[k].queued = false;
+      const size_t before = ticketsOut;
+      if (!submitAll(k)) {
         failed = true;
         break;
       }
-      if (r == 0) {
-        tmSubmitBusy += secsS(ts0, nowS());
-        nSubmitBusy += 1;
-        break;
-      }
-      tmSubmitOk += secsS(ts0, nowS());
-      backlog.pop_back();
-      if (static_cast<size_t>(live[k].ticket) >= ticketOwner.size()) ticketOwner.resize(live[k].ticket + 1, 0);
-      ticketOwner[live[k].ticket] = k;
-      nInflight += 1;
-      progress = true;
+      if (ticketsOut != before) progress = true;
+      if (live[k].queued) break;  // the ring is still full
     }
     if (failed) break;
     auto tB = nowS();
+    tmSubmit += secsS(tA, tB);
     // harvest: one pass over the ring's completion words, whatever the number of instances in flight
     int32_t nDone = 0;
     if (mrp_ll_poll_any(ctx, doneTickets.data(), static_cast<int32_t>(doneTickets.size()), &nDone) != MRP_LL_SUCCESS) {
@@ -393,59 +473,34 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       nPollEmpty += 1;
     }
     // resolve the owners first: a ticket id freed by this harvest can be handed out again by a resubmission below
-    doneOwners.resize(nDone);
-    for (int32_t d = 0; d < nDone; ++d) doneOwners[d] = ticketOwner[doneTickets[d]];
+    donePend.resize(nDone);
+    for (int32_t d = 0; d < nDone; ++d) donePend[d] = ticketPend[doneTickets[d]];
     for (int32_t d = 0; d < nDone; ++d) {
-      const size_t k = doneOwners[d];
+      Pending& P = pend[donePend[d]];
+      const size_t k = P.live;
       Live& L = live[k];
       progress = true;
-      nInflight -= 1;
-      L.ans.clear();
+      ticketsOut -= 1;
+      jobsOut -= static_cast<int64_t>(P.res.size());
       auto tu0 = nowS();
-      for (const mrp_ll_result& r : L.res) {
-        LLAnswer a;
-        a.status = r.status;
-        a.cost = r.cost;
-        a.fmin = r.fmin;
-        a.expanded = r.expanded;
-        out.expansions += r.expanded;
-        if (r.status == MRP_LL_OK) {
-          auto p = std::make_shared<Path>();
-          p->xy.resize(static_cast<size_t>(r.n_states) * 2);
-          uint32_t orAll = 0;
-          for (int32_t s = 0; s < r.n_states; ++s) {
-            p->xy[2 * s] = r.states_txy[3 * s + 1];
-            p->xy[2 * s + 1] = r.states_txy[3 * s + 2];
-            orAll |= static_cast<uint32_t>(p->xy[2 * s]) | static_cast<uint32_t>(p->xy[2 * s + 1]);
-          }
-          p->fits8 = orAll < 256u;
-          p->cost = r.cost;
-          p->fmin = r.fmin;
-          a.path = p;
-        }
-        L.ans.push_back(a);
+      ans.clear();
+      for (const mrp_ll_result& r : P.res) {
+        ranExpansions += r.expanded;
+        ans.push_back(answerOf(r));
       }
+      const int32_t group = P.group;
+      pendFree.push_back(donePend[d]);
       auto tu1 = nowS();
-      L.inst->advance(L.ans, L.req);
+      L.inst->setSpecWidth(specNow());
+      L.inst->deliver(group, ans, L.req);
+      retire(L);
       auto tu2 = nowS();
-      if (timing && L.req.empty()) L.tDone = secsS(tg0, tu2);
       tmUnpack += secsS(tu0, tu1);
       tmAdvance += secsS(tu1, tu2);
-      if (!L.req.empty()) {
-        // publish the follow-up searches at once: a long conflict-tree chain must not wait for the rest of this pass
-        int r = backlog.empty() ? trySubmit(L) : 0;
-        if (r == 1) tmSubmitOk += secsS(tu2, nowS());
-        if (r < 0) {
-          failed = true;
-          break;
-        }
-        if (r == 1) {
-          if (static_cast<size_t>(L.ticket) >= ticketOwner.size()) ticketOwner.resize(L.ticket + 1, 0);
-          ticketOwner[L.ticket] = k;
-          nInflight += 1;
-        } else {
-          backlog.push_back(k);
-        }
+      // publish the follow-up searches at once: a long conflict-tree chain must not wait for the rest of this pass
+      if (L.reqHead < L.req.size() && !L.queued && !submitAll(k)) {
+        failed = true;
+        break;
       }
     }
     if (failed) break;
@@ -481,45 +536,27 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
                  "cumulative: active wgs %lld, busy %.0f ms, idle %.0f ms, searches %lld, expansions %lld\n", live.size(),
                  ms(tg0, tg1), ms(tg1, tg2), ms(tg2, tg3), ms(tg3, tg4), (long long)ls.session_active_wgs,
                  ls.session_busy_ms, ls.session_idle_ms, (long long)ls.jobs, (long long)ls.expansions);
-    std::fprintf(stderr, "[mrp_hl]   host ms: submit ok %.1f, submit busy %.1f (%llu), poll empty %.1f (%llu), poll hit %.1f (%llu), "
-                 "unpack %.1f, advance %.1f; rounds %lld searches %lld\n", tmSubmitOk * 1e3, tmSubmitBusy * 1e3,
-                 (unsigned long long)nSubmitBusy, tmPollEmpty * 1e3, (unsigned long long)nPollEmpty, tmPollHit * 1e3,
-                 (unsigned long long)nPollHit, tmUnpack * 1e3, tmAdvance * 1e3, (long long)out.rounds, (long long)out.searches);
-  }
-  if (timing) {  // the instances this worker finished last
-    std::vector<size_t> order(live.size());
+    std::fprintf(stderr, "[mrp_hl]   host ms: admit+submit %.1f, poll empty %.1f (%llu), poll hit %.1f (%llu), "
+                 "unpack %.1f, advance %.1f; tickets %lld searches %lld\n", tmSubmit * 1e3, tmPollEmpty * 1e3,
+                 (unsigned long long)nPollEmpty, tmPollHit * 1e3, (unsigned long long)nPollHit, tmUnpack * 1e3,
+                 tmAdvance * 1e3, (long long)out.rounds, (long long)out.searches);
+    std::vector<size_t> order(live.size());  // the instances this worker finished last
     for (size_t k = 0; k < order.size(); ++k) order[k] = k;
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return live[a].tDone > live[b].tDone; });
     for (size_t q = 0; q < std::min<size_t>(3, order.size()); ++q) {
       const Live& L = live[order[q]];
-      std::fprintf(stderr, "[mrp_hl]     last #%zu: instance %d admitted %.1f ms done %.1f ms, HL %lld, LL %lld, searches %d\n", q,
+      std::fprintf(stderr, "[mrp_hl]     last #%zu: instance %d admitted %.1f ms done %.1f ms, HL %lld, LL %lld, searches %d (+%lld ahead)\n", q,
                    gidx[order[q]], L.tAdmit * 1e3, L.tDone * 1e3, (long long)L.inst->hlExpanded(),
-                   (long long)L.inst->llExpanded(), L.inst->llSearches());
+                   (long long)L.inst->llExpanded(), L.inst->llSearches(), (long long)L.inst->specSearches());
     }
   }
   if (failed) return;
   for (size_t k = 0; k < live.size(); ++k) {
-    const Instance& I = *live[k].inst;
-    mrp_hl_solution& s = sols[gidx[k]];
-    s.status = I.status();
-    s.n_ll_searches = I.llSearches();
-    s.high_level_expanded = I.hlExpanded();
-    s.low_level_expanded = I.llExpanded();
-    s.cost = 0;
-    s.makespan = 0;
-    if (I.status() == MRP_HL_SOLVED) {
-      const auto& sol = I.finalSolution();
-      for (int32_t a = 0; a < I.nAgents(); ++a) {
-        s.cost += sol[a]->cost;
-        s.makespan = std::max<int64_t>(s.makespan, sol[a]->cost);
-        if (s.path_len) s.path_len[a] = sol[a]->len();
-        if (s.paths_xy) {
-          int32_t m = std::min(sol[a]->len(), s.path_cap);
-          std::memcpy(s.paths_xy + static_cast<size_t>(a) * s.path_cap * 2, sol[a]->xy.data(), sizeof(int32_t) * 2 * m);
-        }
-      }
-    }
+    writeSolution(*live[k].inst, sols[gidx[k]]);
+    out.expansions += live[k].inst->llExpanded();
+    out.specSearches += live[k].inst->specSearches();
   }
+  out.specWasted += ranExpansions - out.expansions;
 }
 
 }  // namespace
@@ -731,6 +768,8 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
     st.rounds += g.rounds;
     st.ll_searches += g.searches;
     st.ll_expansions += g.expansions;
+    st.speculative_searches += g.specSearches;
+    st.wasted_ll_expansions += g.specWasted;
     st.build_seconds += g.buildS;
     st.ll_call_seconds += g.llS;
     st.consume_seconds += g.consumeS;

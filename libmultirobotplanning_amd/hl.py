@@ -40,7 +40,8 @@ class mrp_hl_options(ctypes.Structure):
 class mrp_hl_batch_stats(ctypes.Structure):
     _fields_ = [("wall_seconds", ctypes.c_double), ("rounds", ctypes.c_int64), ("ll_searches", ctypes.c_int64),
                 ("ll_expansions", ctypes.c_int64), ("solved", ctypes.c_int64), ("build_seconds", ctypes.c_double),
-                ("ll_call_seconds", ctypes.c_double), ("consume_seconds", ctypes.c_double)]
+                ("ll_call_seconds", ctypes.c_double), ("consume_seconds", ctypes.c_double),
+                ("speculative_searches", ctypes.c_int64), ("wasted_ll_expansions", ctypes.c_int64)]
 
 
 class mrp_hl_sipp_solution(ctypes.Structure):
@@ -244,7 +245,8 @@ class BatchSolver:
                                f"{self._lib.mrp_hl_solver_last_error(self._h).decode()}")
         stats = dict(wall_seconds=st.wall_seconds, rounds=st.rounds, ll_searches=st.ll_searches,
                      ll_expansions=st.ll_expansions, solved=st.solved, build_seconds=st.build_seconds,
-                     ll_call_seconds=st.ll_call_seconds, consume_seconds=st.consume_seconds)
+                     ll_call_seconds=st.ll_call_seconds, consume_seconds=st.consume_seconds,
+                     speculative_searches=st.speculative_searches, wasted_ll_expansions=st.wasted_ll_expansions)
         return (None if raw else self.results_of(prep)), stats
 
     def results_of(self, prep) -> List[Dict]:

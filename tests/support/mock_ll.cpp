@@ -3,6 +3,7 @@
 // host-side conflict-tree drivers (csrc/hl/) can be exercised on a machine without a GPU (`-m "not gpu"` tests).
 // The product library has no such path: libmrp_ll.so fails with MRP_LL_E_DEVICE when no HIP device exists.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -96,8 +97,34 @@ int mrp_ll_submit(mrp_ll_ctx* c, int32_t n, const mrp_ll_job* jobs, mrp_ll_resul
 int mrp_ll_submit_lane(mrp_ll_ctx* c, int32_t, int32_t n, const mrp_ll_job* jobs, mrp_ll_result* res, int32_t* ticket) {
   return mrp_ll_submit(c, n, jobs, res, ticket);
 }
+// MRP_MOCK_SHUFFLE=<seed>: completed tickets are reported a few at a time in a pseudo-random order, so that the drivers
+// see the groups of one instance come back out of submission order (as they do on the GPU).
 int mrp_ll_poll_any(mrp_ll_ctx* c, int32_t* tickets, int32_t cap, int32_t* n) {
   int32_t k = 0;
+  const char* sh = std::getenv("MRP_MOCK_SHUFFLE");
+  if (sh) {
+    static thread_local uint64_t x = 0;
+    if (x == 0) x = 0x9E3779B97F4A7C15ull ^ static_cast<uint64_t>(std::atoll(sh) + 1) ^ reinterpret_cast<uintptr_t>(c);
+    auto rnd = [&]() {
+      x ^= x << 13;
+      x ^= x >> 7;
+      x ^= x << 17;
+      return x;
+    };
+    if (!c->doneTickets.empty() && (rnd() & 3) == 0) {  // sometimes report nothing: work stays in flight
+      *n = 0;
+      return MRP_LL_SUCCESS;
+    }
+    const int32_t lim = 1 + static_cast<int32_t>(rnd() % 3);
+    while (!c->doneTickets.empty() && k < cap && k < lim) {
+      const size_t i = rnd() % c->doneTickets.size();
+      tickets[k++] = c->doneTickets[i];
+      c->doneTickets[i] = c->doneTickets.back();
+      c->doneTickets.pop_back();
+    }
+    *n = k;
+    return MRP_LL_SUCCESS;
+  }
   while (!c->doneTickets.empty() && k < cap) {
     tickets[k++] = c->doneTickets.back();
     c->doneTickets.pop_back();

@@ -184,7 +184,7 @@ def test_configure_tiers_changes_nothing_but_the_tier(oracle_mod, bench_instance
             res = _run_and_compare(eng, cases, ll.ASTAR_EPS, 1.3)
             if geom[0] <= 64:
                 assert any(r.tier == 1 for r in res)
-        assert occ[0] == 8 and occ[2] < occ[0]
+        assert occ[0] >= 8 and occ[2] < occ[0]  # compact tier: ~13 KB per search -> 11-12 searches per CU
         eng.session_begin(64)
         try:
             with pytest.raises(RuntimeError):
