@@ -203,6 +203,25 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* done);
  * many tickets are in flight.  Writes at most `cap` ticket ids to `tickets`, their number to *n. */
 int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* n);
 
+/* ---- high-level conflict scans -----------------------------------------------------------
+ * Environment::getFirstConflict (example/ecbs.cpp:401-452, example/cbs.cpp identical) and Environment::focalHeuristic
+ * (example/ecbs.cpp:315-350) for a batch of solutions (conflict-tree nodes) in one kernel launch.
+ * Solution s owns agents set_first_agent[s] .. set_first_agent[s+1]-1 of the flattened agent list; agent a owns states
+ * path_first_state[a] .. path_first_state[a+1]-1 of states_xy ([total][2] = x, y at time 0, 1, 2, ...; every path has
+ * at least one state, coordinates 0..255).  out[s]: the first conflict in the reference's scan order (time ascending; at
+ * one time step vertex pairs before edge pairs; pairs (i, j), i < j, lexicographic; the last time step is never
+ * checked) and the number of all conflicts (= focalHeuristic). */
+typedef struct mrp_ll_conflict {
+  int32_t found;          /* getFirstConflict's return value                                                  */
+  int32_t time;           /* Conflict::time                                                                   */
+  int32_t agent1, agent2; /* Conflict::agent1 < Conflict::agent2 (indices inside the solution)                */
+  int32_t type;           /* 0 = Conflict::Vertex, 1 = Conflict::Edge                                         */
+  int32_t x1, y1, x2, y2; /* Vertex: the shared cell in x1, y1; Edge: agent1's move (x1,y1) -> (x2,y2)         */
+  int32_t count;          /* focalHeuristic(solution)                                                         */
+} mrp_ll_conflict;
+int mrp_ll_conflict_scan(mrp_ll_ctx* ctx, int32_t n_sets, const int32_t* set_first_agent,
+                         const int32_t* path_first_state, const int32_t* states_xy, mrp_ll_conflict* out);
+
 int mrp_ll_get_stats(const mrp_ll_ctx* ctx, mrp_ll_stats* out);
 int mrp_ll_reset_stats(mrp_ll_ctx* ctx);
 

@@ -23,6 +23,20 @@ extern "C" hipError_t mrp_ll_launch_sipp_persistent(const mrp::LaunchParams* P, 
 extern "C" hipError_t mrp_ll_launch_persistent(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, int kind,
                                                hipStream_t stream);
 
+namespace mrp {
+struct ConflictOut {
+  int32_t found, time, agent1, agent2, type, x1, y1, x2, y2, count;
+};
+struct ConflictParams {
+  const uint32_t* setFirstAgent;
+  const uint32_t* pathFirstState;
+  const uint16_t* states;
+  ConflictOut* out;
+  uint32_t nSets;
+};
+}  // namespace mrp
+extern "C" hipError_t mrp_ll_launch_conflict(const mrp::ConflictParams* P, hipStream_t stream);
+
 namespace {
 
 using mrp::DevJob;
@@ -193,6 +207,9 @@ struct mrp_ll_ctx {
   std::vector<SessTicket> sess;
   std::vector<int32_t> sessFree;   // free session-ticket ids (stack)
   void* sippScratch = nullptr;     // SippScratch, created on first use (packSipp)
+  uint8_t* scanDev = nullptr;      // mrp_ll_conflict_scan: device staging (grown on demand)
+  size_t scanDevCap = 0;
+  std::vector<uint16_t> scanStates;
 };
 
 namespace {
@@ -766,6 +783,7 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
     if (t.stream) (void)hipStreamDestroy(t.stream);
   }
   if (ctx->mapsDev) (void)hipFree(ctx->mapsDev);
+  if (ctx->scanDev) (void)hipFree(ctx->scanDev);
   delete ctx;
 }
 
@@ -1388,6 +1406,60 @@ int mrp_ll_search_batch(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, 
   int rc = mrp_ll_submit(ctx, nJobs, jobs, results, &ticket);
   if (rc != MRP_LL_SUCCESS) return rc;
   return mrp_ll_wait(ctx, ticket);
+}
+
+int mrp_ll_conflict_scan(mrp_ll_ctx* ctx, int32_t nSets, const int32_t* setFirstAgent, const int32_t* pathFirstState,
+                         const int32_t* statesXY, mrp_ll_conflict* out) {
+  static_assert(sizeof(mrp_ll_conflict) == sizeof(mrp::ConflictOut), "mrp_ll_conflict layout");
+  if (!ctx || nSets < 0 || (nSets > 0 && (!setFirstAgent || !pathFirstState || !out))) return MRP_LL_E_INVALID;
+  if (nSets == 0) return MRP_LL_SUCCESS;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int64_t nAgents = setFirstAgent[nSets];
+  if (setFirstAgent[0] != 0 || nAgents < 0) return MRP_LL_E_INVALID;
+  for (int32_t s = 0; s < nSets; ++s)
+    if (setFirstAgent[s + 1] < setFirstAgent[s] || setFirstAgent[s + 1] - setFirstAgent[s] > 65535) return MRP_LL_E_INVALID;
+  const int64_t nStates = nAgents ? pathFirstState[nAgents] : 0;
+  if (nAgents && (pathFirstState[0] != 0 || !statesXY)) return MRP_LL_E_INVALID;
+  for (int64_t a = 0; a < nAgents; ++a)
+    if (pathFirstState[a + 1] <= pathFirstState[a]) {  // getState asserts a non-empty path (ecbs.cpp:491)
+      ctx->err = "mrp_ll_conflict_scan: every path needs at least one state";
+      return MRP_LL_E_INVALID;
+    }
+  ctx->scanStates.resize(static_cast<size_t>(nStates));
+  for (int64_t k = 0; k < nStates; ++k) {
+    const int32_t x = statesXY[2 * k], y = statesXY[2 * k + 1];
+    if (x < 0 || x > 255 || y < 0 || y > 255) {
+      ctx->err = "mrp_ll_conflict_scan: coordinates must be 0..255";
+      return MRP_LL_E_INVALID;
+    }
+    ctx->scanStates[k] = static_cast<uint16_t>(x | (y << 8));
+  }
+  auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+  const size_t oSet = 0, oPath = al((nSets + 1) * 4), oStates = oPath + al((nAgents + 1) * 4),
+               oOut = oStates + al(static_cast<size_t>(nStates) * 2), total = oOut + al(sizeof(mrp_ll_conflict) * nSets);
+  if (total > ctx->scanDevCap) {
+    if (ctx->scanDev) HIPCHK(ctx, hipFree(ctx->scanDev));
+    ctx->scanDev = nullptr;
+    ctx->scanDevCap = 0;
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->scanDev), total * 2));
+    ctx->scanDevCap = total * 2;
+  }
+  hipStream_t st = ctx->tickets[0].stream;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->scanDev + oSet, setFirstAgent, (nSets + 1) * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->scanDev + oPath, pathFirstState, (nAgents + 1) * 4, hipMemcpyHostToDevice, st));
+  if (nStates)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->scanDev + oStates, ctx->scanStates.data(), static_cast<size_t>(nStates) * 2,
+                               hipMemcpyHostToDevice, st));
+  mrp::ConflictParams P;
+  P.setFirstAgent = reinterpret_cast<const uint32_t*>(ctx->scanDev + oSet);
+  P.pathFirstState = reinterpret_cast<const uint32_t*>(ctx->scanDev + oPath);
+  P.states = reinterpret_cast<const uint16_t*>(ctx->scanDev + oStates);
+  P.out = reinterpret_cast<mrp::ConflictOut*>(ctx->scanDev + oOut);
+  P.nSets = static_cast<uint32_t>(nSets);
+  HIPCHK(ctx, mrp_ll_launch_conflict(&P, st));
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->scanDev + oOut, sizeof(mrp_ll_conflict) * nSets, hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  return MRP_LL_SUCCESS;
 }
 
 int mrp_ll_get_stats(const mrp_ll_ctx* ctx, mrp_ll_stats* out) {

@@ -47,6 +47,10 @@ class mrp_ll_result(ctypes.Structure):
                 ("action_costs", I32P)]
 
 
+class mrp_ll_conflict(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ("found", "time", "agent1", "agent2", "type", "x1", "y1", "x2", "y2", "count")]
+
+
 class mrp_ll_stats(ctypes.Structure):
     _fields_ = [("launches", ctypes.c_int64), ("jobs", ctypes.c_int64), ("expansions", ctypes.c_int64),
                 ("nodes_created", ctypes.c_int64), ("migrated", ctypes.c_int64), ("kernel_ms", ctypes.c_double),
@@ -58,7 +62,7 @@ class mrp_ll_stats(ctypes.Structure):
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
            "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version",
            "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any", "mrp_ll_submit_lane", "mrp_ll_sync_maps",
-           "mrp_ll_configure_tiers", "mrp_ll_session_begin_sipp", "mrp_ll_release_maps", "mrp_ll_session_begin_algo"]
+           "mrp_ll_configure_tiers", "mrp_ll_session_begin_sipp", "mrp_ll_release_maps", "mrp_ll_session_begin_algo", "mrp_ll_conflict_scan"]
 
 _lib = None
 
@@ -110,6 +114,8 @@ def load_library(path: Optional[str] = None):
     lib.mrp_ll_sync_maps.argtypes = [ctypes.c_void_p]
     lib.mrp_ll_release_maps.restype = ctypes.c_int
     lib.mrp_ll_release_maps.argtypes = [ctypes.c_void_p]
+    lib.mrp_ll_conflict_scan.restype = ctypes.c_int
+    lib.mrp_ll_conflict_scan.argtypes = [ctypes.c_void_p, ctypes.c_int32, I32P, I32P, I32P, ctypes.POINTER(mrp_ll_conflict)]
     lib.mrp_ll_poll_any.restype = ctypes.c_int
     lib.mrp_ll_poll_any.argtypes = [ctypes.c_void_p, I32P, ctypes.c_int32, I32P]
     if path is None:
@@ -245,6 +251,25 @@ class LowLevelEngine:
                                 actions=actions[i, :max(m - 1, 0)].tolist(), tier=r.tier,
                                 action_costs=costs[i, :max(m - 1, 0)].tolist()))
         return out
+
+    def conflict_scan(self, solutions: Sequence[Sequence[Sequence[Sequence[int]]]]) -> List[dict]:
+        """getFirstConflict (example/ecbs.cpp:401-452) + focalHeuristic (:315-350) for a batch of solutions, each a list
+        of paths [[x, y], ...].  Returns per solution dict(found, time, agent1, agent2, type, x1, y1, x2, y2, count)."""
+        n = len(solutions)
+        set_first = np.zeros(n + 1, dtype=np.int32)
+        lens = []
+        for s, sol in enumerate(solutions):
+            set_first[s + 1] = set_first[s] + len(sol)
+            lens.extend(len(p) for p in sol)
+        path_first = np.zeros(len(lens) + 1, dtype=np.int32)
+        np.cumsum(np.asarray(lens, dtype=np.int64), out=path_first[1:])
+        flat = [xy for sol in solutions for p in sol for xy in p]
+        xy = np.ascontiguousarray(np.asarray(flat, dtype=np.int32).reshape(-1, 2))
+        out = (mrp_ll_conflict * max(n, 1))()
+        self._check(self._lib.mrp_ll_conflict_scan(self._h, n, set_first.ctypes.data_as(I32P),
+                                                   path_first.ctypes.data_as(I32P), xy.ctypes.data_as(I32P), out),
+                    "mrp_ll_conflict_scan")
+        return [{k: getattr(out[i], k) for k, _ in mrp_ll_conflict._fields_} for i in range(n)]
 
     def configure_tiers(self, lds_nodes: int = 0, lds_rows: int = 0, lds_path_bytes: int = 0) -> int:
         """Geometry of the LDS fast tier for the launches that follow (0 = keep); returns resident searches per CU."""

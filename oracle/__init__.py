@@ -48,6 +48,8 @@ def lib():
         _LIB.oracle_mapf_solve_batch.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_int, I32P, ctypes.c_int, I32P, I32P, ctypes.c_int64,
                                                  ctypes.c_int, I64P]
+        _LIB.oracle_conflict_scan.restype = None
+        _LIB.oracle_conflict_scan.argtypes = [ctypes.c_int, I32P, I32P, I32P]
         _LIB.oracle_ll_search.restype = ctypes.c_int
         _LIB.oracle_ll_search.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -240,3 +242,13 @@ def mapf_solve_batch(algo, dimx, dimy, obstacles, starts, goals, w=1.0, cap_tota
                                          st.ctypes.data_as(I32P), go.ctypes.data_as(I32P), cap_total, n_threads,
                                          out.ctypes.data_as(I64P))
     return out, wall / 1e9
+
+
+def conflict_scan(paths):
+    """getFirstConflict + focalHeuristic (ecbs.cpp:401-452, :315-350) of one solution: paths = [[[x, y], ...], ...]."""
+    lens, lens_p = _i32([len(p) for p in paths])
+    xy, xy_p = _i32(np.asarray([c for p in paths for c in p], dtype=np.int32).reshape(-1, 2))
+    out = np.zeros(10, dtype=np.int32)
+    lib().oracle_conflict_scan(len(paths), lens_p, xy_p, out.ctypes.data_as(I32P))
+    keys = ("found", "time", "agent1", "agent2", "type", "x1", "y1", "x2", "y2", "count")
+    return dict(zip(keys, (int(v) for v in out)))

@@ -121,6 +121,30 @@ int64_t oracle_mapf_solve_batch(int algo, float w, int n, int dimx, int dimy, in
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// getFirstConflict (ecbs.cpp:401-452) + focalHeuristic (:315-350) of one solution given as flattened paths.
+// out[0..9] = found, time, agent1, agent2, type (0 vertex / 1 edge), x1, y1, x2, y2, focalHeuristic
+void oracle_conflict_scan(int nAgents, const int32_t* pathLen, const int32_t* pathXY, int32_t* out) {
+  Environment env = makeEnv(256, 256, 0, nullptr, 0, nullptr);
+  std::vector<Plan> sol(nAgents);
+  int64_t off = 0;
+  for (int a = 0; a < nAgents; ++a)
+    for (int k = 0; k < pathLen[a]; ++k, ++off)
+      sol[a].states.push_back(std::make_pair(State(k, pathXY[2 * off], pathXY[2 * off + 1]), k));
+  Conflict c;
+  std::memset(&c, 0, sizeof(c));
+  const bool found = env.getFirstConflict(sol, c);
+  out[0] = found ? 1 : 0;
+  out[1] = found ? c.time : 0;
+  out[2] = found ? static_cast<int32_t>(c.agent1) : 0;
+  out[3] = found ? static_cast<int32_t>(c.agent2) : 0;
+  out[4] = found ? (c.type == Conflict::Edge ? 1 : 0) : 0;
+  out[5] = found ? c.x1 : 0;
+  out[6] = found ? c.y1 : 0;
+  out[7] = found && c.type == Conflict::Edge ? c.x2 : 0;
+  out[8] = found && c.type == Conflict::Edge ? c.y2 : 0;
+  out[9] = env.focalHeuristic(sol);
+}
+
 // One low-level search with everything explicit (the same information a mrp_ll_job carries).
 // algo 0 = AStar (CBS low level), 1 = AStarEpsilon (ECBS low level).
 // ctxLen[nCtx] = number of states of every agent's path in the CT node (0 = empty, skipped);

@@ -150,6 +150,9 @@ int mrp_ll_poll(mrp_ll_ctx*, int32_t, int32_t* done) {
   *done = 1;  // the mock runs every job synchronously inside mrp_ll_submit
   return MRP_LL_SUCCESS;
 }
+int mrp_ll_conflict_scan(mrp_ll_ctx*, int32_t, const int32_t*, const int32_t*, const int32_t*, mrp_ll_conflict*) {
+  return MRP_LL_E_DEVICE;  // the scan kernel has no stand-in: the host drivers do not call it
+}
 int mrp_ll_get_stats(const mrp_ll_ctx* c, mrp_ll_stats* out) {
   *out = c->stats;
   return MRP_LL_SUCCESS;
