@@ -12,6 +12,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <queue>
 #include <memory>
 #include <string>
 #include <thread>
@@ -128,10 +129,13 @@ void writeSolution(const Instance& I, mrp_hl_solution& s) {
   }
 }
 
-// Speculation width of the conflict-tree machines (ct_solver.hpp): MRP_HL_SPEC=k; default 4.
+// Speculation width of the conflict-tree machines (ct_solver.hpp): MRP_HL_SPEC=k.  Default 2: measured on the shipped
+// 8x8 CBS inputs (scripts/spec_probe.py) one node of look-ahead halves the time of a small batch (agents8 0.74 -> 0.37 s,
+// agents10-12 1.78 -> 0.91 s) and wider windows give it back (their searches queue in front of the popped node's own);
+// ECBS pops a fresh child next almost every time, so looking ahead buys it 0-6 %.
 int32_t specWidthSetting() {
   if (const char* e = std::getenv("MRP_HL_SPEC")) return std::max(1, std::atoi(e));
-  return 4;
+  return 2;
 }
 
 // Drives instances idx[...] to completion on one engine, one mrp_ll_search_batch per round of ready searches.
@@ -348,18 +352,37 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     out.searches += static_cast<int64_t>(jobs.size());
     return 1;
   };
-  // Submits as many groups of live[k] as the ring takes; false on error.  Leaves it in the backlog if some remain.
-  std::vector<size_t> backlog;
+  // Scheduling.  The device queue is kept SHALLOW — at most `ringTarget` searches published per engine, enough to hand
+  // every resident wavefront its next job the moment it finishes one — and everything else waits in a host-side
+  // priority queue ordered by how many low-level expansions the instance has consumed so far.  An instance deep in its
+  // conflict tree (or stuck with one huge search) is a long chain of dependent rounds; served first, each of its
+  // rounds starts within one job time instead of queueing behind thousands of searches of easy instances, so the
+  // chain costs its compute time and not rounds x queue length (that, not throughput, bounded a step before).  Fresh
+  // instances have priority 0 and are admitted only when nothing older is waiting.
+  int64_t ringTarget = std::max<int64_t>(2 * static_cast<int64_t>(workgroups), 32);
+  if (const char* e = std::getenv("MRP_HL_RING_DEPTH"))
+    if (std::atoll(e) > 0) ringTarget = std::atoll(e);  // tuning knob
+  typedef std::pair<int64_t, size_t> Waiting;  // (priority, live index)
+  std::priority_queue<Waiting> backlog;
+  auto enqueue = [&](size_t k) {
+    Live& L = live[k];
+    if (!L.queued) {
+      L.queued = true;
+      backlog.push(Waiting(L.inst->llExpanded(), k));
+    }
+  };
+  // Submits groups of live[k] while the device queue has room; false on error.  Leaves it in the backlog if some remain.
   auto submitAll = [&](size_t k) -> bool {
     Live& L = live[k];
     while (L.reqHead < L.req.size()) {
+      if (jobsOut >= ringTarget) {
+        enqueue(k);
+        return true;
+      }
       int r = submitGroup(k);
       if (r < 0) return false;
       if (r == 0) {
-        if (!L.queued) {
-          L.queued = true;
-          backlog.push_back(k);
-        }
+        enqueue(k);
         return true;
       }
     }
@@ -429,7 +452,22 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   while (!failed && (ticketsOut != 0 || !backlog.empty() || !exhausted)) {
     bool progress = false;
     auto tA = nowS();
-    while (!exhausted && nActive < activeLimit && admit()) {
+    // publish waiting searches, deepest instance first, while the device queue has room
+    while (!backlog.empty() && jobsOut < ringTarget) {
+      const size_t k = backlog.top().second;
+      backlog.pop();
+      live[k].queued = false;
+      const size_t before = ticketsOut;
+      if (!submitAll(k)) {
+        failed = true;
+        break;
+      }
+      if (ticketsOut != before) progress = true;
+      if (live[k].queued) break;  // the ring itself is full
+    }
+    if (failed) break;
+    // nothing older is waiting: start fresh instances
+    while (!exhausted && backlog.empty() && jobsOut < ringTarget && nActive < activeLimit && admit()) {
       const size_t k = live.size() - 1;
       Live& L = live[k];
       nActive += 1;
@@ -439,20 +477,6 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       if (!submitAll(k)) failed = true;
       progress = true;
       if (failed) break;
-    }
-    if (failed) break;
-    // publish what the ring refused earlier
-    while (!backlog.empty()) {
-      const size_t k = backlog.back();
-      backlog.pop_back();
-      live[k].queued = false;
-      const size_t before = ticketsOut;
-      if (!submitAll(k)) {
-        failed = true;
-        break;
-      }
-      if (ticketsOut != before) progress = true;
-      if (live[k].queued) break;  // the ring is still full
     }
     if (failed) break;
     auto tB = nowS();

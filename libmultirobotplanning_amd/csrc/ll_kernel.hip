@@ -233,8 +233,9 @@ DEVI void ldPair(typename Mem<T>::PE p, uint32_t i, typename T::E& a, typename T
 //   * sift-up      : lane k loads the k-th ancestor; one ballot finds where the sequential loop would have stopped;
 //                    the ancestors below that point move down one level in a single parallel store.
 //   * sift-down    : which child is "the larger one" does not depend on the element being sifted, so 63 lanes load
-//                    the child pairs of a whole 6-level subtree in one instruction and the path is then followed with
-//                    scalar bit tests (no further memory latency); repeated per 6 levels.
+//                    the child pairs of a whole 6-level subtree in one instruction and every lane then decides from
+//                    two ballots whether its node is on the path (followPath: no further memory latency, no scalar
+//                    walk); repeated per 6 levels.
 //   * erase        : the unconditional bubble-to-root is a one-level shift of the ancestor chain (parallel).
 // KEY selects the comparator: 0 = open (f asc, g desc), 1 = focal (focalH, f asc, g desc), 2 = walk queue (an open key
 // in the entry's key field).  POS=true maintains handle -> position for the node (open list only).
@@ -273,6 +274,48 @@ DEVI void siftUp(Mem<T>& m, typename Mem<T>::PE heap, uint32_t idx, typename T::
   heapStore<T, POS>(m, heap, ((idx + 1) >> stop) - 1, e);
 }
 
+// Which nodes of a 6-level block lie on the sift-down path, decided by all lanes at once instead of a scalar walk
+// over the masks: node l (lane l < 63; 1-based number n = l + 1) is reached iff every ancestor lets the hole pass
+// (`go`) and turned towards l (`right` bit == the matching digit of n).  The ancestors of a node of a 63-node tree are
+// among its first 31 nodes, so both tests are 32-bit masks that depend on the lane only.
+//   anc   : bit a set  <=>  node a is an ancestor of this lane's node
+//   needR : bit a set  <=>  ... and the path to this lane's node leaves a through its RIGHT child
+struct PathLanes {
+  uint32_t anc, needR;
+};
+DEVI PathLanes pathLanes() {
+  const uint32_t n = threadIdx.x + 1;
+  PathLanes pl;
+  pl.anc = 0;
+  pl.needR = 0;
+#pragma unroll
+  for (uint32_t k = 1; k <= 5; ++k) {
+    const uint32_t a = n >> k;  // 1-based number of the k-th ancestor (0: none)
+    if (a != 0 && n < 64) {
+      pl.anc |= 1u << (a - 1);
+      pl.needR |= ((n >> (k - 1)) & 1u) << (a - 1);
+    }
+  }
+  return pl;
+}
+// Follows the path of one block: `go` / `right` are this lane's answers for its node.  Returns the lanes on the path
+// (each pulls its chosen child up), the number of levels descended and the new hole relative to the block's root.
+DEVI bool followPath(const PathLanes& pl, bool go, bool right, uint32_t& steps, uint32_t& rel) {
+  const uint64_t goMask = ballot64(go);
+  const uint64_t rightMask = ballot64(right);
+  const uint32_t goLo = (uint32_t)goMask, rLo = (uint32_t)rightMask;
+  const bool reached = ((goLo & pl.anc) == pl.anc) && (((rLo ^ pl.needR) & pl.anc) == 0u);
+  const bool onPath = reached && go;
+  const uint64_t pathMask = ballot64(onPath);
+  steps = (uint32_t)__popcll(pathMask);
+  rel = 0;
+  if (pathMask) {
+    const uint32_t d = 63u - (uint32_t)__builtin_clzll(pathMask);  // deepest node on the path (levels are index-ordered)
+    rel = 2 * d + 1 + (uint32_t)((rightMask >> d) & 1ull);
+  }
+  return onPath;
+}
+
 // Moves the hole at `idx` down a heap of n elements.
 //   STL=false (boost siftdown): prefer the FIRST maximal child; stop in front of a child that is less than x; x is
 //             stored at the final hole.
@@ -287,6 +330,7 @@ DEVI uint32_t descend(Mem<T>& m, typename Mem<T>::PE heap, uint32_t n, uint32_t 
   const uint32_t lv = 31u - (uint32_t)__builtin_clz(lane + 1);  // level of this lane inside a 6-level subtree
   const uint32_t off = (lane + 1) - (1u << lv);                 // position inside that level
   const uint32_t xk = keyOf<T, KEY>(x);
+  const PathLanes pl = pathLanes();
   for (;;) {
     const uint32_t node = ((idx + 1) << lv) - 1 + off;          // lane l < 63 owns this node of the subtree
     const uint32_t c = 2 * node + 1;
@@ -302,17 +346,8 @@ DEVI uint32_t descend(Mem<T>& m, typename Mem<T>::PE heap, uint32_t n, uint32_t 
     const E pe = right ? pr.y : pr.x;
     const uint32_t pk = right ? kr : kl;
     const bool go = has && (STL || !(pk < xk));                 // the hole moves below this node
-    const uint64_t goMask = ballot64(go);
-    const uint64_t rightMask = ballot64(right);
-    uint64_t pathMask = 0;
-    uint32_t rel = 0, steps = 0;
-#pragma unroll 1
-    while (steps < 6 && ((goMask >> rel) & 1ull)) {
-      pathMask |= 1ull << rel;
-      rel = 2 * rel + 1 + (uint32_t)((rightMask >> rel) & 1ull);
-      steps += 1;
-    }
-    if ((pathMask >> lane) & 1ull) {                            // every node on the path pulls its chosen child up
+    uint32_t rel, steps;
+    if (followPath(pl, go, right, steps, rel)) {                // every node on the path pulls its chosen child up
       heap[node] = pe;
       if (POS) setPos<T>(m, T::id(pe), node);
     }
@@ -400,40 +435,17 @@ struct PushChains {          // sift-up chains of the (up to five) pushes of one
 // One 6-level block of a sift-down whose child pairs have been loaded (see descend): follows the path, pulls the
 // chosen children up, returns the new hole; `more` = the block was left through its bottom.
 template <class T, int KEY, bool POS>
-DEVI uint32_t descendBlock(Mem<T>& m, typename Mem<T>::PE heap, uint32_t idx, uint32_t xk, typename T::Pair pr,
-                           uint32_t node, bool has, bool hasR, bool full, bool& more) {
+DEVI uint32_t descendBlock(Mem<T>& m, typename Mem<T>::PE heap, const PathLanes& pl, uint32_t idx, uint32_t xk,
+                           typename T::Pair pr, uint32_t node, bool has, bool hasR, bool& more) {
   typedef typename T::E E;
-  const uint32_t lane = threadIdx.x;
   const uint32_t kl = keyOf<T, KEY>(pr.x);
   const uint32_t kr = keyOf<T, KEY>(pr.y);
   const bool right = hasR && (kl < kr);
   const E pe = right ? pr.y : pr.x;
   const uint32_t pk = right ? kr : kl;
   const bool go = has && !(pk < xk);
-  const uint64_t goMask = ballot64(go);
-  const uint64_t rightMask = ballot64(right);
-  uint64_t pathMask = 0;
-  uint32_t rel = 0, steps = 0;
-  if (full) {
-    // all six levels exist below the hole: six branch-free steps (a taken scalar branch costs about as much as six
-    // instructions; measured 504 vs 876 cycles per block, scripts/micro/descend_micro.hip)
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const uint32_t g = (uint32_t)((goMask >> rel) & 1ull);
-      const uint32_t r = (uint32_t)((rightMask >> rel) & 1ull);
-      pathMask |= (uint64_t)g << rel;
-      rel = g ? 2 * rel + 1 + r : rel;
-      steps += g;
-    }
-  } else {
-#pragma unroll 1
-    while (steps < 6 && ((goMask >> rel) & 1ull)) {
-      pathMask |= 1ull << rel;
-      rel = 2 * rel + 1 + (uint32_t)((rightMask >> rel) & 1ull);
-      steps += 1;
-    }
-  }
-  if ((pathMask >> lane) & 1ull) {
+  uint32_t rel, steps;
+  if (followPath(pl, go, right, steps, rel)) {
     heap[node] = pe;
     if (POS) setPos<T>(m, T::id(pe), node);
   }
@@ -450,6 +462,7 @@ DEVI void popFocalEraseOpen(Mem<T>& m, uint32_t& nFocal, uint32_t& nOpen, uint32
   const uint32_t lane = threadIdx.x;
   const uint32_t lv = 31u - (uint32_t)__builtin_clz(lane + 1);
   const uint32_t off = (lane + 1) - (1u << lv);
+  const PathLanes pl = pathLanes();
   // ---- loads that depend on nothing but the sizes
   nFocal -= 1;
   const uint32_t nOld = nOpen;
@@ -499,13 +512,10 @@ DEVI void popFocalEraseOpen(Mem<T>& m, uint32_t& nFocal, uint32_t& nOpen, uint32
       if (hasF) prF = *(typename Mem<T>::PPair)(m.focal + 2 * nodeF + 1);
     }
     firstF = false;
-    // "full": the leftmost descendant six levels below the hole exists
     if (moreF)
-      idxF = descendBlock<T, 1, false>(m, m.focal, idxF, xkF, prF, nodeF, hasF, hasF && (2 * nodeF + 2 < nFocal),
-                                       ((idxF + 1) << 6) - 1 < nFocal, moreF);
+      idxF = descendBlock<T, 1, false>(m, m.focal, pl, idxF, xkF, prF, nodeF, hasF, hasF && (2 * nodeF + 2 < nFocal), moreF);
     if (moreO)
-      idxO = descendBlock<T, 0, true>(m, m.open, idxO, xkO, prO, nodeO, hasO, hasO && (2 * nodeO + 2 < nOpen),
-                                      ((idxO + 1) << 6) - 1 < nOpen, moreO);
+      idxO = descendBlock<T, 0, true>(m, m.open, pl, idxO, xkO, prO, nodeO, hasO, hasO && (2 * nodeO + 2 < nOpen), moreO);
     if (!moreF && !moreO) break;
   }
   if (nFocal > 0) m.focal[idxF] = lastF;
