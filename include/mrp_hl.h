@@ -120,6 +120,14 @@ typedef struct mrp_hl_sipp_solution {
 int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t n_instances, const mrp_hl_instance* instances,
                                    mrp_hl_sipp_solution* solutions, mrp_hl_batch_stats* stats);
 
+/* BASELINE.json configs[0] — `./a_star` on a text map (example/a_star.cpp:72-125,190-191) — is host plumbing: a single
+ * 2-D A* (AStar::search a_star.hpp:63-161, neighbours Up, Down, Left, Right, unit costs, Manhattan heuristic), run on
+ * the CPU with the reference's heap tie-breaks.  obstacle_mask[y * dimx + x] != 0 = '#'.  Returns the number of states
+ * of the path (written to states_xy [cap][2] up to cap), 0 = "Planning NOT successful!", -1 = bad argument. */
+int32_t mrp_hl_astar_grid2d(int32_t dimx, int32_t dimy, const uint8_t* obstacle_mask, int32_t start_x, int32_t start_y,
+                            int32_t goal_x, int32_t goal_y, int32_t* states_xy, int32_t cap, int32_t* cost,
+                            int64_t* expanded);
+
 /* Seeded synthetic "32x32_obst204-shaped" instance: obstacles uniform without replacement, agents with
  * distinct starts and distinct goals, every goal in the start's 4-connected free component. splitmix64(seed).
  * Buffers: obstacles_xy [n_obstacles][2], starts_xy / goals_xy [n_agents][2]. Returns 0, or -1 if impossible. */

@@ -42,6 +42,9 @@ class ExactHeap {
     removeRoot();
   }
 
+  // boost increase(handle): the element's key got better — sift it up from where it is (a_star.hpp:143)
+  void increase(int32_t id) { up(static_cast<size_t>(where_[id])); }
+
   // visit(id) -> false stops the walk
   template <typename Visit>
   void walkOrdered(Visit visit) const {

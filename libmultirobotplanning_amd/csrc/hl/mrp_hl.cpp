@@ -20,6 +20,7 @@
 
 #include "../../../include/mrp_hl.h"
 #include "ct_solver.hpp"
+#include "grid2d_astar.hpp"
 #include "instance_io.hpp"
 
 using namespace mrp_hl;
@@ -1223,6 +1224,13 @@ int mrp_hl_solve_batch(int32_t device, const mrp_hl_options* opt, int32_t nInst,
   rc = mrp_hl_solver_solve(s, opt, nInst, instances, solutions, stats);
   mrp_hl_solver_destroy(s);
   return rc;
+}
+
+int32_t mrp_hl_astar_grid2d(int32_t dimx, int32_t dimy, const uint8_t* obstacle_mask, int32_t start_x, int32_t start_y,
+                            int32_t goal_x, int32_t goal_y, int32_t* states_xy, int32_t cap, int32_t* cost,
+                            int64_t* expanded) {
+  if (dimx <= 0 || dimy <= 0 || !obstacle_mask || !cost || !expanded || (cap > 0 && !states_xy)) return -1;
+  return astarGrid2d(dimx, dimy, obstacle_mask, start_x, start_y, goal_x, goal_y, states_xy, cap, cost, expanded);
 }
 
 int mrp_hl_generate_instance(uint64_t seed, int32_t dimx, int32_t dimy, int32_t nObst, int32_t nAgents,

@@ -52,7 +52,7 @@ class mrp_hl_sipp_solution(ctypes.Structure):
 
 EXPORTS = ["mrp_hl_solver_prioritized_sipp", "mrp_hl_solver_preload", "mrp_hl_solver_solve_preloaded",
            "mrp_hl_preloaded_free", "mrp_hl_solve_batch", "mrp_hl_solver_create", "mrp_hl_solver_destroy", "mrp_hl_solver_solve",
-           "mrp_hl_solver_ll_stats", "mrp_hl_solver_last_error", "mrp_hl_generate_instance", "mrp_hl_generate_instances"]
+           "mrp_hl_solver_ll_stats", "mrp_hl_solver_last_error", "mrp_hl_generate_instance", "mrp_hl_generate_instances", "mrp_hl_astar_grid2d"]
 
 _lib = None
 
@@ -98,6 +98,10 @@ def load_library(path: Optional[str] = None):
         lib.mrp_hl_generate_instance.restype = ctypes.c_int
         lib.mrp_hl_generate_instance.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int32, I32P, I32P, I32P]
+        lib.mrp_hl_astar_grid2d.restype = ctypes.c_int32
+        lib.mrp_hl_astar_grid2d.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, I32P, ctypes.c_int32, I32P,
+                                            ctypes.POINTER(ctypes.c_int64)]
         lib.mrp_hl_generate_instances.restype = ctypes.c_int
         lib.mrp_hl_generate_instances.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                   ctypes.c_int32, ctypes.c_int32, I32P, I32P, I32P]
@@ -118,6 +122,21 @@ def generate_instance(seed: int, dimx: int = 32, dimy: int = 32, n_obstacles: in
     if rc != 0:
         raise ValueError("instance generation failed")
     return dict(dimx=dimx, dimy=dimy, obstacles=ob.tolist(), starts=st.tolist(), goals=go.tolist())
+
+
+def astar_grid2d(dimx: int, dimy: int, mask, start: Sequence[int], goal: Sequence[int], cap: int = 65536):
+    """example/a_star.cpp on a [dimy][dimx] obstacle mask (host plumbing, BASELINE configs[0]): (states [[x, y]..] or [],
+    cost, expanded)."""
+    lib = load_library()
+    m = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8).reshape(dimy, dimx))
+    out = np.zeros((cap, 2), dtype=np.int32)
+    cost = ctypes.c_int32(0)
+    exp = ctypes.c_int64(0)
+    n = lib.mrp_hl_astar_grid2d(dimx, dimy, m.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), start[0], start[1], goal[0],
+                                goal[1], out.ctypes.data_as(I32P), cap, ctypes.byref(cost), ctypes.byref(exp))
+    if n < 0:
+        raise ValueError("mrp_hl_astar_grid2d: bad argument")
+    return out[:min(n, cap)].tolist(), cost.value, exp.value
 
 
 class InstanceArrays:
