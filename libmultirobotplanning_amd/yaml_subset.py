@@ -155,8 +155,8 @@ def _block(lines: List[Tuple[int, str]], i: int, indent: int) -> Tuple[Any, int]
                     item, i = _block(lines, i + 1, lines[i + 1][0])
                 else:
                     item, i = None, i + 1
-            elif _is_key_line(body):
-                # "- key: value" opens a mapping whose further keys are aligned with `key`
+            elif _is_key_line(body) or body.startswith("- ") or body == "-":
+                # "- key: value" opens a mapping whose further keys are aligned with `key`; "- - x" a nested sequence
                 col = indent + 1 + pad
                 sub = [(col, body)]
                 j = i + 1

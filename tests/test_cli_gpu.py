@@ -48,3 +48,43 @@ def test_cbs_cli(tmp_path, ref_tests):
     assert cli.main(["cbs", "-i", str(tmp_path / "c.yaml"), "-o", str(tmp_path / "c.out.yaml")]) == 0
     out = yaml.safe_load(open(tmp_path / "c.out.yaml"))
     assert out["statistics"]["cost"] == 4     # test/test_cbs.py:28-30
+
+
+def test_sipp_cli(tmp_path, ref_tests, capsys):
+    """example/sipp.cpp front-end on test/sipp_1.yaml's content (test/test_sipp.py:16-21: 6 states, last = (2, 3) at t = 9)."""
+    from libmultirobotplanning_amd import cli
+    s = ref_tests["sipp_1"]
+    by_loc = {}
+    for x, y, a, b in s["collision_intervals"]:
+        by_loc.setdefault((x, y), []).append([a, b])
+    doc = {"start": s["start"], "goal": s["goal"],
+           "environment": {"size": [s["dimx"], s["dimy"]], "obstacles": s["obstacles"],
+                           "collisionIntervals": [{"location": list(k), "intervals": v} for k, v in by_loc.items()]}}
+    with open(tmp_path / "s.yaml", "w") as f:
+        yaml.safe_dump(doc, f)
+    assert cli.main(["sipp", "-i", str(tmp_path / "s.yaml"), "-o", str(tmp_path / "s.out.yaml")]) == 0
+    out = yaml.safe_load(open(tmp_path / "s.out.yaml"))
+    steps = out["schedule"]["agent1"]
+    assert len(steps) == s["n_states"]
+    assert [steps[-1]["x"], steps[-1]["y"], steps[-1]["t"]] == s["last"]
+    printed = capsys.readouterr().out
+    assert "Planning successful! Total cost: 9" in printed and "->Wait(cost: 5)" in printed
+
+
+def test_mapf_prioritized_sipp_cli(tmp_path, ref_tests):
+    """example/mapf_prioritized_sipp.cpp front-end: statistics.cost of the reference's fixtures
+    (test/test_mapf_prioritized_sipp.py:24-52), "[]" for an agent that cannot be planned, several inputs as one batch."""
+    from libmultirobotplanning_amd import cli
+    want = ref_tests["prioritized_sipp"]["cost"]
+    args = ["mapf_prioritized_sipp"]
+    for n in want:
+        _write_input(tmp_path / (n + ".yaml"), ref_tests["mapf"][n])
+        args += ["-i", str(tmp_path / (n + ".yaml")), "-o", str(tmp_path / (n + ".out.yaml"))]
+    assert cli.main(args) == 0
+    for n, cost in want.items():
+        out = yaml.safe_load(open(tmp_path / (n + ".out.yaml")))
+        assert out["statistics"]["cost"] == cost, n
+        assert list(out.keys()) == ["schedule", "statistics"]
+    lens = ref_tests["prioritized_sipp"]["simple1b_lens"]
+    sched = yaml.safe_load(open(tmp_path / "mapf_simple1b.out.yaml"))["schedule"]
+    assert len(sched["agent0"]) == lens["agent0"] and sched["agent1"] == []
