@@ -169,6 +169,39 @@ def main():
     elapsed_max, (exp_all, solved_all, searches_all, inst_all) = sharding.reduce_totals(
         dist, "cpu" if rehearsal else "cuda", elapsed, [exp_total, solved_total, searches_total, K * B])
 
+    # N > 1 only: ONE heavy conflict tree with the searches of every round sharded over all ranks: the
+    # instance is broadcast from rank 0, each rank runs its share of a round on its own GPU, one all-gather per round
+    sharded_ct = None
+    if world > 1 and args.legs != "none":
+        from libmultirobotplanning_amd import ct_sharded
+        inst0 = None
+        exp0 = None
+        name0 = "map_32by32_obst204_agents100_ex0"
+        if rank == 0:
+            with open(os.path.join(ROOT, "tests", "golden", "bench_instances.json")) as f:
+                inst0 = json.load(f)[name0]
+            with open(os.path.join(ROOT, "tests", "golden", "oracle_expected.json")) as f:
+                exp0 = json.load(f)[name0]["ecbs_w1.3"]
+        dev = "cpu" if rehearsal else "cuda"
+        inst0 = ct_sharded.broadcast_instance(inst0, dist, dev)
+        run = ct_sharded.gpu_executor(inst0, device=local_rank)
+        try:
+            legs_ct = {}
+            for k in (1, world):  # look-ahead 1 = the plain loop (one node's two children per round), then one node per rank
+                barrier()
+                t1 = time.perf_counter()
+                r = ct_sharded.solve_sharded(inst0, run, dist, algo=hl.ECBS, w=1.3, spec_width=k, device=dev)
+                barrier()
+                legs_ct["spec_width_%d" % k] = {"seconds": time.perf_counter() - t1, "rounds": r["rounds"],
+                                                "searches_run_on_rank0": r["searches_run_here"]}
+            if rank == 0:
+                sharded_ct = {"workload": "ECBS w=1.3 on the shipped %s, every round's searches sharded over %d ranks" % (name0, world),
+                              "cost": r["cost"], "hl_expanded": r["hl_expanded"], "ll_expanded": r["ll_expanded"],
+                              "matches_golden": (r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
+                                  exp0["cost"], exp0["makespan"], exp0["hl"], exp0["ll"]), **legs_ct}
+        finally:
+            run.close()
+
     if rank == 0:
         kernel_s = lls["kernel_ms"] / 1e3
         achieved = ALGO_BYTES_PER_EXPANSION * lls["expansions"] / max(kernel_s, 1e-12) / 1e9
@@ -327,6 +360,8 @@ def main():
                                            "instances_per_s": len(insts) / max(t_cpu, 1e-12), "seconds": t_cpu}
                     leg["vs_cpu_port_1core"] = leg["value"] / max(leg["cpu_baseline"]["value"], 1e-12)
                 by[name] = leg
+        if sharded_ct is not None:
+            by["sharded_conflict_tree"] = sharded_ct
         out["by_workload"] = by
         print(json.dumps(out), flush=True)
     solver.close()

@@ -120,6 +120,25 @@ typedef struct mrp_hl_sipp_solution {
 int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t n_instances, const mrp_hl_instance* instances,
                                    mrp_hl_sipp_solution* solutions, mrp_hl_batch_stats* stats);
 
+/* ---- one conflict tree, stepped by the caller ------------------------------------------------------------------
+ * The same state machine the batch drivers run (CBS::search cbs.hpp:85-172 / ECBS::search ecbs.hpp:109-288 cut at the
+ * low-level calls), exposed so that a caller can decide WHERE each low-level search runs — e.g. the searches of one
+ * round sharded over several GPUs (libmultirobotplanning_amd/ct_sharded.py).  Pending requests come in
+ * groups (the root step, or the two children of one conflict-tree node; with spec_width > 1 also the children of the
+ * nodes that will probably be popped next); a group is answered as a whole, groups in any order.  Results do not depend
+ * on spec_width or on the order of delivery. */
+typedef struct mrp_hl_ct mrp_hl_ct;
+int mrp_hl_ct_create(const mrp_hl_instance* instance, const mrp_hl_options* opt, int32_t map_id, int32_t spec_width,
+                     mrp_hl_ct** out);
+void mrp_hl_ct_destroy(mrp_hl_ct* ct);
+int32_t mrp_hl_ct_n_requests(const mrp_hl_ct* ct);
+/* Request k as a low-level job (map_id as given to create; its arrays stay valid until the next mrp_hl_ct_deliver). */
+int mrp_hl_ct_request(const mrp_hl_ct* ct, int32_t k, mrp_ll_job* job, int32_t* group, int32_t* slot);
+/* The results of every request of `group`, in slot order (status, cost, fmin, expanded, n_states, states_txy). */
+int mrp_hl_ct_deliver(mrp_hl_ct* ct, int32_t group, int32_t n, const mrp_ll_result* results);
+int32_t mrp_hl_ct_done(const mrp_hl_ct* ct);
+int mrp_hl_ct_solution(const mrp_hl_ct* ct, mrp_hl_solution* out);
+
 /* BASELINE.json configs[0] — `./a_star` on a text map (example/a_star.cpp:72-125,190-191) — is host plumbing: a single
  * 2-D A* (AStar::search a_star.hpp:63-161, neighbours Up, Down, Left, Right, unit costs, Manhattan heuristic), run on
  * the CPU with the reference's heap tie-breaks.  obstacle_mask[y * dimx + x] != 0 = '#'.  Returns the number of states

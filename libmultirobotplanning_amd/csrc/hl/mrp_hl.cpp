@@ -1226,6 +1226,81 @@ int mrp_hl_solve_batch(int32_t device, const mrp_hl_options* opt, int32_t nInst,
   return rc;
 }
 
+// ---- one conflict tree, stepped by the caller (include/mrp_hl.h "mrp_hl_ct_*") ---------------------------------
+struct mrp_hl_ct {
+  std::unique_ptr<Instance> inst;
+  std::vector<LLRequest> req;
+  std::vector<int32_t> pathLenPool;
+  std::vector<const int32_t*> pathPtrPool;
+  std::vector<size_t> poolOff;
+  std::vector<mrp_ll_job> jobs;
+  void rebuild() {  // job views of the pending requests; arrays stay valid until the next deliver
+    pathLenPool.clear();
+    pathPtrPool.clear();
+    poolOff.clear();
+    jobs.resize(req.size());
+    for (size_t k = 0; k < req.size(); ++k) {
+      poolOff.push_back(pathLenPool.size());
+      fillJob(*inst, req[k], jobs[k], pathLenPool, pathPtrPool);
+    }
+    for (size_t k = 0; k < req.size(); ++k)
+      if (jobs[k].n_agents > 0) {
+        jobs[k].path_len = pathLenPool.data() + poolOff[k];
+        jobs[k].path_xy = pathPtrPool.data() + poolOff[k];
+      }
+  }
+};
+
+int mrp_hl_ct_create(const mrp_hl_instance* in, const mrp_hl_options* opt, int32_t mapId, int32_t specWidth,
+                     mrp_hl_ct** out) {
+  if (!in || !opt || !out || in->n_agents < 0) return MRP_LL_E_INVALID;
+  auto* c = new mrp_hl_ct();
+  c->inst.reset(new Instance(*in, mapId, *opt));
+  c->inst->setSpecWidth(specWidth);
+  c->inst->start(c->req);
+  if (c->inst->done()) c->req.clear();
+  c->rebuild();
+  *out = c;
+  return MRP_LL_SUCCESS;
+}
+
+void mrp_hl_ct_destroy(mrp_hl_ct* c) { delete c; }
+
+int32_t mrp_hl_ct_n_requests(const mrp_hl_ct* c) { return c ? static_cast<int32_t>(c->req.size()) : 0; }
+
+int mrp_hl_ct_request(const mrp_hl_ct* c, int32_t k, mrp_ll_job* job, int32_t* group, int32_t* slot) {
+  if (!c || k < 0 || k >= static_cast<int32_t>(c->req.size()) || !job) return MRP_LL_E_INVALID;
+  *job = c->jobs[k];
+  if (group) *group = c->req[k].group;
+  if (slot) *slot = c->req[k].slot;
+  return MRP_LL_SUCCESS;
+}
+
+int mrp_hl_ct_deliver(mrp_hl_ct* c, int32_t group, int32_t n, const mrp_ll_result* results) {
+  if (!c || n < 0 || (n > 0 && !results)) return MRP_LL_E_INVALID;
+  // the group's requests are consecutive in the pending list: take them out, keep the others
+  size_t a = 0;
+  while (a < c->req.size() && c->req[a].group != group) ++a;
+  size_t b = a;
+  while (b < c->req.size() && c->req[b].group == group) ++b;
+  if (a == c->req.size() || static_cast<int32_t>(b - a) != n) return MRP_LL_E_INVALID;
+  std::vector<LLAnswer> ans;
+  for (int32_t k = 0; k < n; ++k) ans.push_back(answerOf(results[k]));
+  c->req.erase(c->req.begin() + static_cast<std::ptrdiff_t>(a), c->req.begin() + static_cast<std::ptrdiff_t>(b));
+  c->inst->deliver(group, ans, c->req);
+  if (c->inst->done()) c->req.clear();  // requests of a finished instance point into freed CT nodes
+  c->rebuild();
+  return MRP_LL_SUCCESS;
+}
+
+int32_t mrp_hl_ct_done(const mrp_hl_ct* c) { return c && c->inst->done() ? 1 : 0; }
+
+int mrp_hl_ct_solution(const mrp_hl_ct* c, mrp_hl_solution* out) {
+  if (!c || !out || !c->inst->done()) return MRP_LL_E_INVALID;
+  writeSolution(*c->inst, *out);
+  return MRP_LL_SUCCESS;
+}
+
 int32_t mrp_hl_astar_grid2d(int32_t dimx, int32_t dimy, const uint8_t* obstacle_mask, int32_t start_x, int32_t start_y,
                             int32_t goal_x, int32_t goal_y, int32_t* states_xy, int32_t cap, int32_t* cost,
                             int64_t* expanded) {

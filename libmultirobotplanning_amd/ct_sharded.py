@@ -1,0 +1,135 @@
+"""ONE conflict tree whose low-level searches are sharded over the ranks of a torch.distributed job (SURVEY.md §8e,
+BASELINE.json north_star: "conflict-tree node batches shard one-per-GPU over RCCL/xGMI: broadcast of the static map,
+all-gather of incumbent costs").
+
+How it stays exact.  Every rank runs the same deterministic conflict-tree machine (hl.ConflictTree = the C++ state
+machine of csrc/hl/ct_solver.hpp: CBS::search cbs.hpp:85-172 / ECBS::search ecbs.hpp:109-288 cut at the low-level
+calls) with the same look-ahead width, so all ranks see the same list of pending request groups each round — the two
+children of the node that was popped plus, with spec_width > 1, the children of the nodes the loop will pop next.  Group
+j of a round is searched by rank j % world on its own GPU; one all-gather per round hands every rank every result, and
+all of them deliver the groups in the same order.  Children are committed strictly in the reference's pop order
+(ct_solver.hpp), so cost, makespan, highLevelExpanded, lowLevelExpanded and the paths equal the single-rank run's.
+
+Collectives (RCCL when the backend is "nccl", gloo on CPU): one broadcast of the instance (the static map, starts,
+goals) from rank 0, then one fixed-shape int32 all-gather per round — per result: group, slot, status, cost (the
+incumbent's contribution), fmin, expansions and the path.  Messages are a few KB: latency-bound, as SURVEY §8e expects.
+"""
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import hl
+
+_HDR = 8  # int32 words in front of the path: group, slot, status, cost, fmin, expanded lo, expanded hi, n_states
+
+
+def broadcast_instance(inst: Optional[Dict], dist, device: str = "cpu", src: int = 0) -> Dict:
+    """Rank `src` holds the instance; everybody returns the same dict (the "broadcast of the static map")."""
+    import torch
+    if dist is None or dist.get_world_size() == 1:
+        return inst
+    me = dist.get_rank()
+    hdr = torch.zeros(4, dtype=torch.int32, device=device)
+    if me == src:
+        hdr[:] = torch.tensor([inst["dimx"], inst["dimy"], len(inst["obstacles"]), len(inst["starts"])], dtype=torch.int32)
+    dist.broadcast(hdr, src=src)
+    dimx, dimy, n_ob, n_ag = (int(v) for v in hdr.tolist())
+    body = torch.zeros((n_ob + 2 * n_ag) * 2, dtype=torch.int32, device=device)
+    if me == src:
+        flat = [c for o in inst["obstacles"] for c in o] + [c for s in inst["starts"] for c in s] + \
+               [c for g in inst["goals"] for c in g]
+        body[:] = torch.tensor(flat, dtype=torch.int32)
+    dist.broadcast(body, src=src)
+    v = body.cpu().numpy().reshape(-1, 2)
+    return dict(dimx=dimx, dimy=dimy, obstacles=v[:n_ob].tolist(), starts=v[n_ob:n_ob + n_ag].tolist(),
+                goals=v[n_ob + n_ag:].tolist())
+
+
+def gpu_executor(inst: Dict, device: int = 0, max_horizon: int = 512) -> Callable[[Sequence[Dict]], List[Dict]]:
+    """The product executor: this rank's MI355X through the C-ABI (ll.LowLevelEngine); no CPU fallback."""
+    from . import ll
+    eng = ll.LowLevelEngine(device=device, n_tickets=1, slots=64, max_horizon=max_horizon)
+    mid = eng.upload_map(inst["dimx"], inst["dimy"], inst["obstacles"])
+
+    def run(reqs: Sequence[Dict]) -> List[Dict]:
+        jobs = [ll.LLJob(map_id=mid, algo=r["algo"], start=r["start"], goal=r["goal"], agent_idx=r["agent"], w=r["w"],
+                         vertex_constraints=r["vertex_constraints"], edge_constraints=r["edge_constraints"],
+                         ctx_paths=r["ctx_paths"], max_expansions=r["max_expansions"]) for r in reqs]
+        out = []
+        for r in (eng.search_batch(jobs) if jobs else []):
+            out.append(dict(status=r.status, cost=r.cost, fmin=r.fmin, expanded=r.expanded,
+                            states=[s[1:] for s in r.states]))
+        return out
+
+    run.close = eng.close
+    return run
+
+
+def solve_sharded(inst: Dict, executor: Callable[[Sequence[Dict]], List[Dict]], dist=None, algo: int = hl.ECBS,
+                  w: float = 1.3, spec_width: int = 0, max_ll_expansions: int = -1, max_hl_expansions: int = -1,
+                  device: str = "cpu", max_states: int = 512, _lib_path: Optional[str] = None) -> Dict:
+    """Solve `inst` (identical on all ranks: see broadcast_instance) with the searches of every round sharded over the
+    ranks of `dist`.  Returns the same dict on every rank: hl.ConflictTree.solution() + rounds / searches_run_here."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    me = dist.get_rank() if dist is not None else 0
+    if spec_width <= 0:
+        spec_width = max(1, world)  # one node's children per rank and round
+    ct = hl.ConflictTree(inst, algo=algo, w=w, map_id=0, spec_width=spec_width, max_ll_expansions=max_ll_expansions,
+                         max_hl_expansions=max_hl_expansions, _lib_path=_lib_path)
+    rounds = ran = 0
+    try:
+        while not ct.done():
+            reqs = ct.requests()
+            if not reqs:
+                raise RuntimeError("conflict tree is neither done nor asking for searches")
+            groups: List[int] = []
+            for r in reqs:
+                if not groups or groups[-1] != r["group"]:
+                    groups.append(r["group"])
+            owner = {g: j % world for j, g in enumerate(groups)}
+            mine = [r for r in reqs if owner[r["group"]] == me]
+            res = executor(mine)
+            ran += len(mine)
+            rounds += 1
+            if world == 1:
+                rows = [(r["group"], r["slot"], x) for r, x in zip(mine, res)]
+            else:
+                per_rank = max(sum(1 for r in reqs if owner[r["group"]] == k) for k in range(world))
+                buf = torch.zeros((per_rank, _HDR + max_states), dtype=torch.int32)
+                for i, (r, x) in enumerate(zip(mine, res)):
+                    n = len(x["states"])
+                    if n > max_states:
+                        raise RuntimeError("path longer than max_states")
+                    buf[i, :_HDR] = torch.tensor([r["group"], r["slot"], x["status"], x["cost"], x["fmin"],
+                                                  x["expanded"] & 0x7FFFFFFF, x["expanded"] >> 31, n], dtype=torch.int32)
+                    if n:
+                        buf[i, _HDR:_HDR + n] = torch.tensor([p[0] | (p[1] << 8) for p in x["states"]], dtype=torch.int32)
+                buf = buf.to(device)
+                gathered = [torch.zeros_like(buf) for _ in range(world)]
+                dist.all_gather(gathered, buf)
+                rows = []
+                for k in range(world):
+                    n_k = sum(1 for r in reqs if owner[r["group"]] == k)
+                    t = gathered[k].cpu().numpy()
+                    for i in range(n_k):
+                        h = t[i, :_HDR]
+                        n = int(h[7])
+                        cells = t[i, _HDR:_HDR + n]
+                        rows.append((int(h[0]), int(h[1]),
+                                     dict(status=int(h[2]), cost=int(h[3]), fmin=int(h[4]),
+                                          expanded=int(h[5]) | (int(h[6]) << 31),
+                                          states=[[int(c) & 0xFF, int(c) >> 8] for c in cells])))
+            by_group: Dict[int, List] = {}
+            for g, slot, x in rows:
+                by_group.setdefault(g, []).append((slot, x))
+            for g in groups:  # the same order on every rank
+                ct.deliver(g, [x for _, x in sorted(by_group[g], key=lambda v: v[0])])
+                if ct.done():
+                    break
+        out = ct.solution()
+    finally:
+        ct.close()
+    out["rounds"] = rounds
+    out["searches_run_here"] = ran
+    return out

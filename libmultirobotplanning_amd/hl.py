@@ -52,7 +52,9 @@ class mrp_hl_sipp_solution(ctypes.Structure):
 
 EXPORTS = ["mrp_hl_solver_prioritized_sipp", "mrp_hl_solver_preload", "mrp_hl_solver_solve_preloaded",
            "mrp_hl_preloaded_free", "mrp_hl_solve_batch", "mrp_hl_solver_create", "mrp_hl_solver_destroy", "mrp_hl_solver_solve",
-           "mrp_hl_solver_ll_stats", "mrp_hl_solver_last_error", "mrp_hl_generate_instance", "mrp_hl_generate_instances", "mrp_hl_astar_grid2d"]
+           "mrp_hl_solver_ll_stats", "mrp_hl_solver_last_error", "mrp_hl_generate_instance", "mrp_hl_generate_instances", "mrp_hl_astar_grid2d",
+           "mrp_hl_ct_create", "mrp_hl_ct_destroy", "mrp_hl_ct_n_requests", "mrp_hl_ct_request", "mrp_hl_ct_deliver",
+           "mrp_hl_ct_done", "mrp_hl_ct_solution"]
 
 _lib = None
 
@@ -102,6 +104,22 @@ def load_library(path: Optional[str] = None):
         lib.mrp_hl_astar_grid2d.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32,
                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, I32P, ctypes.c_int32, I32P,
                                             ctypes.POINTER(ctypes.c_int64)]
+        lib.mrp_hl_ct_create.restype = ctypes.c_int
+        lib.mrp_hl_ct_create.argtypes = [ctypes.POINTER(mrp_hl_instance), ctypes.POINTER(mrp_hl_options), ctypes.c_int32,
+                                         ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+        lib.mrp_hl_ct_destroy.restype = None
+        lib.mrp_hl_ct_destroy.argtypes = [ctypes.c_void_p]
+        lib.mrp_hl_ct_n_requests.restype = ctypes.c_int32
+        lib.mrp_hl_ct_n_requests.argtypes = [ctypes.c_void_p]
+        lib.mrp_hl_ct_request.restype = ctypes.c_int
+        lib.mrp_hl_ct_request.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(_ll.mrp_ll_job), I32P, I32P]
+        lib.mrp_hl_ct_deliver.restype = ctypes.c_int
+        lib.mrp_hl_ct_deliver.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.POINTER(_ll.mrp_ll_result)]
+        lib.mrp_hl_ct_done.restype = ctypes.c_int32
+        lib.mrp_hl_ct_done.argtypes = [ctypes.c_void_p]
+        lib.mrp_hl_ct_solution.restype = ctypes.c_int
+        lib.mrp_hl_ct_solution.argtypes = [ctypes.c_void_p, ctypes.POINTER(mrp_hl_solution)]
         lib.mrp_hl_generate_instances.restype = ctypes.c_int
         lib.mrp_hl_generate_instances.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                   ctypes.c_int32, ctypes.c_int32, I32P, I32P, I32P]
@@ -330,3 +348,92 @@ class BatchSolver:
         st = _ll.mrp_ll_stats()
         self._lib.mrp_hl_solver_ll_stats(self._h, ctypes.byref(st), 1 if reset else 0)
         return {k: (list(getattr(st, k)) if k == "prof" else getattr(st, k)) for k, _ in _ll.mrp_ll_stats._fields_}
+
+
+class ConflictTree:
+    """One conflict tree stepped by the caller (mrp_hl_ct_* of include/mrp_hl.h): `requests()` lists the low-level
+    searches that may run now, `deliver(group, results)` feeds back the answers of one group.  The caller decides where
+    each search runs (see ct_sharded.py)."""
+
+    def __init__(self, inst: Dict, algo: int = ECBS, w: float = 1.3, map_id: int = 0, spec_width: int = 1,
+                 max_ll_expansions: int = -1, max_hl_expansions: int = -1, _lib_path: Optional[str] = None):
+        self._lib = load_library(_lib_path)
+        self._keep = tuple(np.ascontiguousarray(np.asarray(inst[k], dtype=np.int32).reshape(-1, 2))
+                           for k in ("obstacles", "starts", "goals"))
+        ob, st, go = self._keep
+        cin = mrp_hl_instance(inst["dimx"], inst["dimy"], len(ob), ob.ctypes.data_as(I32P), len(st),
+                              st.ctypes.data_as(I32P), go.ctypes.data_as(I32P))
+        opt = mrp_hl_options(algo, w, max_ll_expansions, max_hl_expansions, 0, 0)
+        h = ctypes.c_void_p()
+        rc = self._lib.mrp_hl_ct_create(ctypes.byref(cin), ctypes.byref(opt), map_id, spec_width, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError("mrp_hl_ct_create failed rc=%d" % rc)
+        self._h = h
+        self.n_agents = len(st)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mrp_hl_ct_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def done(self) -> bool:
+        return bool(self._lib.mrp_hl_ct_done(self._h))
+
+    def requests(self) -> List[Dict]:
+        """Pending searches as plain dicts (group, slot, algo, w, agent, start, goal, vertex_constraints,
+        edge_constraints, ctx_paths, max_expansions), in the machine's order (groups are consecutive)."""
+        out = []
+        job = _ll.mrp_ll_job()
+        g, sl = ctypes.c_int32(0), ctypes.c_int32(0)
+        for k in range(self._lib.mrp_hl_ct_n_requests(self._h)):
+            rc = self._lib.mrp_hl_ct_request(self._h, k, ctypes.byref(job), ctypes.byref(g), ctypes.byref(sl))
+            assert rc == 0
+            vc = np.ctypeslib.as_array(job.vertex_constraints, (job.n_vertex_constraints, 3)).tolist() \
+                if job.n_vertex_constraints else []
+            ec = np.ctypeslib.as_array(job.edge_constraints, (job.n_edge_constraints, 5)).tolist() \
+                if job.n_edge_constraints else []
+            ctx = []
+            for a in range(job.n_agents):
+                n = job.path_len[a]
+                ctx.append(np.ctypeslib.as_array(job.path_xy[a], (n, 2)).tolist() if n else [])
+            out.append(dict(group=g.value, slot=sl.value, algo=job.algo, w=job.w, agent=job.agent_idx,
+                            start=[job.start_x, job.start_y], goal=[job.goal_x, job.goal_y], vertex_constraints=vc,
+                            edge_constraints=ec, ctx_paths=ctx, max_expansions=job.max_expansions))
+        return out
+
+    def deliver(self, group: int, results: Sequence[Dict]) -> None:
+        """results: per slot dict(status, cost, fmin, expanded, states=[[x, y], ...])."""
+        n = len(results)
+        cres = (_ll.mrp_ll_result * max(n, 1))()
+        keep = []
+        for i, r in enumerate(results):
+            st = np.zeros((max(len(r["states"]), 1), 3), dtype=np.int32)
+            for t, (x, y) in enumerate(r["states"]):
+                st[t] = (t, x, y)
+            keep.append(st)
+            cres[i].status, cres[i].cost, cres[i].fmin = r["status"], r["cost"], r["fmin"]
+            cres[i].expanded, cres[i].n_states = r["expanded"], len(r["states"])
+            cres[i].states_txy, cres[i].states_cap = st.ctypes.data_as(I32P), len(st)
+        rc = self._lib.mrp_hl_ct_deliver(self._h, group, n, cres)
+        if rc != 0:
+            raise RuntimeError("mrp_hl_ct_deliver(group=%d, n=%d) failed rc=%d" % (group, n, rc))
+
+    def solution(self, path_cap: int = 1024) -> Dict:
+        sol = mrp_hl_solution()
+        plen = np.zeros(max(self.n_agents, 1), dtype=np.int32)
+        pxy = np.zeros((max(self.n_agents, 1), path_cap, 2), dtype=np.int32)
+        sol.path_len, sol.paths_xy, sol.path_cap = plen.ctypes.data_as(I32P), pxy.ctypes.data_as(I32P), path_cap
+        rc = self._lib.mrp_hl_ct_solution(self._h, ctypes.byref(sol))
+        if rc != 0:
+            raise RuntimeError("mrp_hl_ct_solution failed rc=%d (not done yet?)" % rc)
+        rec = dict(status=sol.status, cost=sol.cost, makespan=sol.makespan, hl_expanded=sol.high_level_expanded,
+                   ll_expanded=sol.low_level_expanded, ll_searches=sol.n_ll_searches)
+        if sol.status == SOLVED:
+            rec["paths"] = [pxy[a, :plen[a]].tolist() for a in range(self.n_agents)]
+        return rec

@@ -214,3 +214,21 @@ def test_bench_scale_properties_and_determinism(solver):
             np.fill_diagonal(swap, False)
             assert not swap.any()
     assert n_solved >= 4090
+
+
+def test_caller_stepped_conflict_tree_on_the_gpu(bench_instances, oracle_expected):
+    """mrp_hl_ct_* + ct_sharded.solve_sharded with the product executor (this GPU through the C-ABI), world size 1: the
+    same results as the batch drivers and the oracle for look-ahead widths 1 and 4 (the multi-rank exchange itself is
+    covered by tests/test_sharding_gloo.py)."""
+    from libmultirobotplanning_amd import ct_sharded, hl
+    for n, algo, key in (("map_32by32_obst204_agents50_ex1", hl.ECBS, "ecbs_w1.3"), ("map_8by8_obst12_agents8_ex3", hl.CBS, "cbs")):
+        inst = bench_instances[n]
+        run = ct_sharded.gpu_executor(inst, device=0)
+        try:
+            for k in (1, 4):
+                r = ct_sharded.solve_sharded(inst, run, None, algo=algo, w=1.3, spec_width=k)
+                e = oracle_expected[n][key]
+                assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"], _digest(r["paths"])) == (
+                    hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"], e["digest"]), (n, k)
+        finally:
+            run.close()

@@ -31,19 +31,28 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.timeout(300)
-def test_two_ranks_gloo(oracle_mod, tmp_path):
-    from libmultirobotplanning_amd import hl, sharding
-    import test_host_drivers_cpu as hd  # builds the CPU driver library
-    os.makedirs(hd.BUILD, exist_ok=True)
-    lib = os.path.join(hd.BUILD, "libmrp_hl_cpu.so")
-    if not os.path.exists(lib):
-        srcs = [os.path.join(ROOT, "libmultirobotplanning_amd", "csrc", "hl", "mrp_hl.cpp"),
-                os.path.join(ROOT, "tests", "support", "mock_ll.cpp")]
+def _cpu_driver_lib():
+    """The host drivers built against the oracle-backed mock low level (tests/support/mock_ll.cpp); rebuilt when stale."""
+    build = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(build, exist_ok=True)
+    lib = os.path.join(build, "libmrp_hl_cpu.so")
+    srcs = [os.path.join(ROOT, "libmultirobotplanning_amd", "csrc", "hl", "mrp_hl.cpp"),
+            os.path.join(ROOT, "tests", "support", "mock_ll.cpp")]
+    deps = srcs + [os.path.join(ROOT, "libmultirobotplanning_amd", "csrc", "hl", f) for f in
+                   ("ct_solver.hpp", "grid_mapf.hpp", "exact_heap.hpp", "grid2d_astar.hpp", "instance_io.hpp")] + \
+        [os.path.join(ROOT, "include", "mrp_hl.h"), os.path.join(ROOT, "include", "mrp_ll.h")]
+    if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-I",
                                os.path.join(ROOT, "include"), "-o", lib] + srcs +
                               ["-L", os.path.join(ROOT, "oracle"), "-loracle",
                                "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    return lib
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_gloo(oracle_mod, tmp_path):
+    from libmultirobotplanning_amd import hl, sharding
+    lib = _cpu_driver_lib()
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, lib=lib))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
@@ -66,3 +75,74 @@ def test_two_ranks_gloo(oracle_mod, tmp_path):
     assert got["elapsed"] == 2.0          # max over ranks
     assert got["idx"] == [0, 2, 4, 6, 8]
     assert sharding.shard_indices(10, 1, 2) == [1, 3, 5, 7, 9]
+
+
+CT_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+import oracle                      # TEST executor only: the product executor is ct_sharded.gpu_executor (one MI355X per rank)
+from libmultirobotplanning_amd import hl, ct_sharded
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+cases = json.load(open({cases!r}))
+out = []
+for case in cases:
+    # rank 0 owns the input; the static map and the agents reach the other rank by broadcast
+    inst = ct_sharded.broadcast_instance(case["inst"] if rank == 0 else None, dist, "cpu")
+    m = dict(dimx=inst["dimx"], dimy=inst["dimy"], obstacles=inst["obstacles"])
+    def run(reqs):
+        res = []
+        for r in reqs:
+            o = oracle.ll_search(r["algo"], m, r["agent"], r["start"], r["goal"], r["vertex_constraints"],
+                                 r["edge_constraints"], r["ctx_paths"], w=r["w"], cap_expansions=r["max_expansions"])
+            res.append(dict(status=2 if o["rc"] == -1 else (0 if o["success"] else 1), cost=o["cost"], fmin=o["fmin"],
+                            expanded=o["expanded"], states=[s[1:] for s in o["states"]]))
+        return res
+    r = ct_sharded.solve_sharded(inst, run, dist, algo=case["algo"], w=1.3, spec_width=case["spec"], device="cpu",
+                                 max_ll_expansions=case.get("cap", -1), _lib_path={lib!r})
+    out.append(r)
+print("RANK%d " % rank + json.dumps(out))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(600)
+def test_one_conflict_tree_sharded_over_two_ranks(oracle_mod, bench_instances, oracle_expected, tmp_path):
+    """SURVEY.md §8e / north_star: ONE heavy instance, the searches of every round split over two ranks (gloo here, RCCL
+    on GPUs): broadcast of the instance, one all-gather of the results per round, children committed in the reference's
+    pop order.  Both ranks must end with the single-rank result — (cost, makespan, HL, LL, paths) of the oracle — and both
+    must have run searches."""
+    from libmultirobotplanning_amd import hl
+    lib = _cpu_driver_lib()
+    picks = [("map_32by32_obst204_agents50_ex1", hl.ECBS, "ecbs_w1.3", 2), ("map_32by32_obst204_agents30_ex2", hl.ECBS, "ecbs_w1.3", 4),
+             ("map_8by8_obst12_agents6_ex1", hl.CBS, "cbs", 2), ("map_8by8_obst12_agents8_ex3", hl.CBS, "cbs", 4)]
+    cases = [dict(inst=bench_instances[n], algo=a, spec=k) for n, a, _, k in picks]
+    cases.append(dict(inst=bench_instances["map_8by8_obst12_agents8_ex0"], algo=hl.CBS, spec=2, cap=20000))  # capped
+    cfile = tmp_path / "cases.json"
+    cfile.write_text(json.dumps(cases))
+    script = tmp_path / "ct_worker.py"
+    script.write_text(CT_WORKER.format(root=ROOT, lib=lib, cases=str(cfile)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29579")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29579", str(script)],
+                         env=env, capture_output=True, text=True, timeout=560)
+    assert out.returncode == 0, out.stderr[-3000:]
+    per_rank = {}
+    for l in out.stdout.splitlines():
+        if l.startswith("RANK"):
+            per_rank[int(l[4])] = json.loads(l[6:])
+    assert sorted(per_rank) == [0, 1]
+    for i, (n, _, key, _) in enumerate(picks):
+        e = oracle_expected[n][key]
+        for rank in (0, 1):
+            r = per_rank[rank][i]
+            assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
+                hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"]), (n, rank)
+            assert r["searches_run_here"] > 0
+        assert per_rank[0][i]["paths"] == per_rank[1][i]["paths"]
+        assert per_rank[0][i]["rounds"] == per_rank[1][i]["rounds"]
+        # the two ranks split the work: together they ran every consumed search (plus any look-ahead that was not)
+        assert per_rank[0][i]["searches_run_here"] + per_rank[1][i]["searches_run_here"] >= per_rank[0][i]["ll_searches"]
+        assert per_rank[0][i]["rounds"] < per_rank[0][i]["ll_searches"]
+    assert per_rank[0][-1]["status"] == hl.CAP and per_rank[1][-1]["status"] == hl.CAP
