@@ -214,7 +214,6 @@ struct SState {  // wave-uniform search state (kept in SGPRs by construction)
 };
 
 enum : int { RUN_MIGRATE_NODES = -1, RUN_MIGRATE_ROWS = -2 };
-constexpr int64_t kLongSearchExpansions = 1500;  // about the mean of a whole agents10 INSTANCE
 constexpr int32_t ST_CAP_FOCAL = 7;
 
 template <class T>
@@ -706,10 +705,6 @@ DEVI int runSearch(Mem<T>& m, SState& s, const Ctx& c, typename Mem<T>::P32 obst
 
     s.expansions += 1;  // onExpandNode (a_star_epsilon.hpp:193 / a_star.hpp:87) — counts the goal pop too
     if (c.maxExp >= 0 && s.expansions > c.maxExp) return ST_CAP_EXP;
-    // A search that has run this long is the tail of its batch: one wavefront, strictly sequential, and everything else
-    // of its instance waits for it.  Raise its issue priority over the wavefronts it shares the SIMD with (their searches
-    // are short and plentiful); processJob drops it again.  Scheduling only: results cannot depend on it.
-    if (s.expansions == kLongSearchExpansions) __builtin_amdgcn_s_setprio(3);
 
     if (isGoal) {
       res.cost = (int32_t)t;
@@ -1358,7 +1353,6 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
   } else {
     if (algo == 0) runJob<false>(P, J, smem, arenaSlot, res, outPath);
   }
-  __builtin_amdgcn_s_setprio(0);
   PROF_ADD(res, 5);
   DBG(P, 2, res.status + 100);
   // result + path back to host memory with lane-parallel stores

@@ -50,6 +50,9 @@ def lib():
                                                  ctypes.c_int, I64P]
         _LIB.oracle_conflict_scan.restype = None
         _LIB.oracle_conflict_scan.argtypes = [ctypes.c_int, I32P, I32P, I32P]
+        _LIB.oracle_prioritized_sipp_batch.restype = ctypes.c_int64
+        _LIB.oracle_prioritized_sipp_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P,
+                                                       ctypes.c_int, I32P, I32P, ctypes.c_int, I64P]
         _LIB.oracle_ll_search.restype = ctypes.c_int
         _LIB.oracle_ll_search.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -252,3 +255,16 @@ def conflict_scan(paths):
     lib().oracle_conflict_scan(len(paths), lens_p, xy_p, out.ctypes.data_as(I32P))
     keys = ("found", "time", "agent1", "agent2", "type", "x1", "y1", "x2", "y2", "count")
     return dict(zip(keys, (int(v) for v in out)))
+
+
+def prioritized_sipp_batch(dimx, dimy, obstacles, starts, goals, n_threads=1):
+    """n instances of one shape; returns (int64 array [n][4] = n_planned, cost, expanded, elapsed_ns ; pool wall seconds)."""
+    ob = np.ascontiguousarray(obstacles, dtype=np.int32)
+    st = np.ascontiguousarray(starts, dtype=np.int32)
+    go = np.ascontiguousarray(goals, dtype=np.int32)
+    n = len(st)
+    out = np.zeros((n, 4), dtype=np.int64)
+    wall = lib().oracle_prioritized_sipp_batch(n, dimx, dimy, ob.shape[1], ob.ctypes.data_as(I32P), st.shape[1],
+                                               st.ctypes.data_as(I32P), go.ctypes.data_as(I32P), n_threads,
+                                               out.ctypes.data_as(I64P))
+    return out, wall / 1e9

@@ -348,6 +348,41 @@ int oracle_prioritized_sipp(int dimx, int dimy, int nObst, const int32_t* obstXY
                                statesXYT, cap);
 }
 
+// The same for n instances of one shape, one instance per thread on `nThreads` threads; timed inside (no wrapper).
+// perInst[k][0..3] = n_planned, cost, expanded, elapsed_ns.  Returns the wall-clock nanoseconds of the pool.
+int64_t oracle_prioritized_sipp_batch(int n, int dimx, int dimy, int nObst, const int32_t* obstXY, int nAgents,
+                                      const int32_t* startsXY, const int32_t* goalsXY, int nThreads, int64_t* perInst) {
+  std::atomic<int> next(0);
+  auto t0 = std::chrono::steady_clock::now();
+  auto work = [&]() {
+    std::vector<int32_t> planned(nAgents), nStates(nAgents);
+    for (;;) {
+      const int k = next.fetch_add(1, std::memory_order_relaxed);
+      if (k >= n) return;
+      int64_t st[4] = {0, 0, 0, 0};
+      auto a = std::chrono::steady_clock::now();
+      const int np = sipp::prioritizedPlan(dimx, dimy, nObst, obstXY + static_cast<int64_t>(k) * nObst * 2, nAgents,
+                                           startsXY + static_cast<int64_t>(k) * nAgents * 2,
+                                           goalsXY + static_cast<int64_t>(k) * nAgents * 2, st, planned.data(),
+                                           nStates.data(), nullptr, 0);
+      auto b = std::chrono::steady_clock::now();
+      int64_t* o = perInst + static_cast<int64_t>(k) * 4;
+      o[0] = np;
+      o[1] = st[0];
+      o[2] = st[1];
+      o[3] = std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
+    }
+  };
+  if (nThreads <= 1) {
+    work();
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nThreads; ++t) th.emplace_back(work);
+    for (auto& x : th) x.join();
+  }
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+}
+
 // ---- example/sipp.cpp: one agent, collision intervals given as [n][4] = x, y, start, end ----------------
 // `startTime`: SIPP::search's fourth argument (sipp.hpp:92); costFmin[0..1] receive solution.cost / solution.fmin.
 int oracle_sipp_single_at(int dimx, int dimy, int nObst, const int32_t* obstXY, int sx, int sy, int gx, int gy, int nCI,

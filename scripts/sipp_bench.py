@@ -10,7 +10,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 threads = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 cpu_n = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 s = hl.BatchSolver(device=0, n_threads=threads, slots=512)
-insts = [hl.generate_instance(640000 + 1000 * agents + k, 64, 64, 410, agents) for k in range(n)]
+ia = hl.generate_instances(640000 + 1000 * agents, n, 64, 64, 410, agents)
+insts = list(ia)
 s.prioritized_sipp(insts[:64])
 for rep in range(2):
     s.ll_stats(reset=True)
@@ -22,11 +23,9 @@ for rep in range(2):
     print("rep %d: %d instances x %d agents: wall %.3f s, %.3e exp/s, %.1f inst/s, rounds %d searches %d planned-all %d" % (
         rep, n, agents, st["wall_seconds"], st["ll_expansions"] / st["wall_seconds"], n / st["wall_seconds"], st["rounds"],
         st["ll_searches"], st["solved"]), flush=True)
-t = 0.0; e = 0; mism = 0
-for inst, r in zip(insts[:cpu_n], res[:cpu_n]):
-    t0 = time.perf_counter()
-    o = oracle.prioritized_sipp(inst)
-    t += time.perf_counter() - t0
-    e += o["expanded"]
-    mism += (o["cost"], o["planned"], o["expanded"]) != (r["cost"], r["planned"], r["expanded"])
-print("cpu oracle on first %d: %.3e exp/s, %.2f inst/s (incl. python wrapper), mismatches %d" % (cpu_n, e / t, cpu_n / t, mism))
+cpu_n = min(max(cpu_n, 512), n)
+per, wall = oracle.prioritized_sipp_batch(64, 64, ia.obstacles[:cpu_n], ia.starts[:cpu_n], ia.goals[:cpu_n], n_threads=1)
+mism = sum((int(p[1]), int(p[0]), int(p[2])) != (r["cost"], r["n_planned"], r["expanded"]) for p, r in zip(per, res[:cpu_n]))
+secs = per[:, 3].sum() / 1e9
+print("cpu port (1 thread, timed inside the oracle) on the first %d instances: %.3e exp/s, %.2f inst/s, mismatches %d" % (
+    cpu_n, per[:, 2].sum() / secs, cpu_n / secs, mism))
