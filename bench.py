@@ -290,8 +290,10 @@ def main():
                                          "instances": int(inst_all), "capped": capped_first,
                                          "cap_per_instance": args.max_ll_expansions, "see": "top-level fields"}}
         leg_specs = {  # name -> (agents, instances, cap per instance, CPU sample)
-            "agents50": (50, 8192, 400000, 192),
-            "agents100": (100, 2048, 2000000, 24),
+            # batches large enough that the one-wavefront chains of the few pathological instances (the capped ones run
+            # for seconds) do not leave the chip idle for most of the step
+            "agents50": (50, 16384, 400000, 192),
+            "agents100": (100, 4096, 2000000, 24),
         }
         for name in [x for x in legs.split(",") if x and x != "none"]:
             if name in leg_specs:

@@ -111,6 +111,9 @@ typedef struct mrp_ll_job {
    *   MRP_LL_ASTAR_EPS : AStarEpsilon::search has no such argument: a non-zero value is rejected (MRP_LL_BAD_JOB) */
   int32_t initial_cost;
   int32_t reserved;
+  /* MRP_LL_SIPP only, optional: an incrementally maintained table (mrp_ll_sipp_table_*) instead of the collision_*
+   * arrays above (which are then ignored).  The table must stay unchanged until the job has been submitted. */
+  const struct mrp_ll_sipp_table* sipp_table;
 } mrp_ll_job;
 
 typedef struct mrp_ll_result {
@@ -153,6 +156,17 @@ int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t n_obs
 /* Copies every map uploaded so far to the device now (otherwise done lazily by the next submit / session_begin). */
 int mrp_ll_sync_maps(mrp_ll_ctx* ctx);
 
+/* ---- incrementally maintained SIPP tables --------------------------------------------------------------------
+ * The state SIPP::setCollisionIntervals (sipp.hpp:245-284) builds up, kept by the engine so that a planner which adds a
+ * few collision intervals between two searches (example/mapf_prioritized_sipp.cpp:237-246) does not have to hand over —
+ * and the engine re-derive — every interval of every location for every job.  mrp_ll_sipp_table_add(t, x, y, s, e)
+ * appends [s, e] to that location's collision list and is equivalent to calling setCollisionIntervals(location, list)
+ * with the extended list.  A table belongs to one map (its dimensions); it is not thread-safe. */
+typedef struct mrp_ll_sipp_table mrp_ll_sipp_table;
+int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t map_id, mrp_ll_sipp_table** out);
+int mrp_ll_sipp_table_add(mrp_ll_sipp_table* t, int32_t x, int32_t y, int32_t start, int32_t end);
+void mrp_ll_sipp_table_destroy(mrp_ll_sipp_table* t);
+
 /* Forgets every uploaded map (host copy and device buffer contents; map ids start again at 0).  For callers that keep
  * one context across many batches of instances.  MRP_LL_E_BUSY while a batch or a session is in flight. */
 int mrp_ll_release_maps(mrp_ll_ctx* ctx);
@@ -192,9 +206,10 @@ int mrp_ll_session_begin_sipp(mrp_ll_ctx* ctx, int32_t workgroups);
  * jobs of another algorithm come back as MRP_LL_BAD_JOB.  What the conflict-tree drivers use. */
 int mrp_ll_session_begin_algo(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups);
 int mrp_ll_session_end(mrp_ll_ctx* ctx);
-/* Session mode: `lane` 0 = the bulk ring (first in, first out), 1 = the priority ring: every resident wavefront looks
- * there before it takes its next bulk job, so a lane-1 search starts within one job time however long the bulk queue is
- * (use it for the searches of a long chain of dependent rounds).  mrp_ll_submit == lane 0. */
+/* Session mode: the same as mrp_ll_submit.  There is one device queue and it is first in, first out; which search
+ * starts next is decided by the ORDER in which the caller publishes — keep the queue shallow (about two searches per
+ * resident wavefront) and publish the searches of the longest dependent chains first, as the conflict-tree drivers do.
+ * `lane` (0 or 1) is accepted for source compatibility with round 1's two-ring design and otherwise ignored. */
 int mrp_ll_submit_lane(mrp_ll_ctx* ctx, int32_t lane, int32_t n_jobs, const mrp_ll_job* jobs, mrp_ll_result* results,
                        int32_t* ticket);
 int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* done);

@@ -44,10 +44,6 @@ struct mrp_hl_solver {
 
 namespace {
 
-// Conflict-tree expansions after which an instance's searches take the engine's priority lane (MRP_HL_DEEP).  Off by
-// default: with the job slots recycled in completion order the bulk lane no longer starves long chains (measured
-// neutral for ECBS at the bench shape), and for CBS — where nearly every instance is deep — it only adds contention.
-constexpr int64_t kDeepHl = INT64_MAX;
 // A session loop gives up when nothing at all has come back for this long (a dead resident kernel is reported much
 // sooner by mrp_ll_poll_any's own liveness check).
 constexpr double kNoProgressLimitS = 600.0;
@@ -277,8 +273,6 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   std::vector<LLAnswer> ans;
 
   const bool timing = std::getenv("MRP_HL_TIMING") != nullptr;
-  int64_t deepHl = kDeepHl;
-  if (const char* e = std::getenv("MRP_HL_DEEP")) deepHl = std::atoll(e);  // tuning knob
   const int32_t specK = specWidthSetting();
   auto tg0 = std::chrono::steady_clock::now();
   if (mrp_ll_session_begin_algo(ctx, opt.algo == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR, workgroups) != MRP_LL_SUCCESS) {
@@ -327,11 +321,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       P.res[q].states_txy = P.states.data() + q * static_cast<size_t>(cap) * 3;
       P.res[q].states_cap = cap;
     }
-    // an instance deep in its conflict tree is a long chain of dependent rounds: its searches take the priority lane,
-    // which every workgroup serves before the bulk, so the chain advances alongside the bulk instead of after it
-    const int32_t lane = I.hlExpanded() >= deepHl ? 1 : 0;
     int32_t ticket = -1;
-    int rc = mrp_ll_submit_lane(ctx, lane, static_cast<int32_t>(jobs.size()), jobs.data(), P.res.data(), &ticket);
+    int rc = mrp_ll_submit(ctx, static_cast<int32_t>(jobs.size()), jobs.data(), P.res.data(), &ticket);
     if (rc == MRP_LL_E_BUSY) {
       pendFree.push_back(pi);
       return 0;
@@ -986,16 +977,13 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
                          mrp_hl_sipp_solution* sols, const std::vector<int32_t>& idx, GroupResult& out) {
   struct Iv { int32_t s, e; };
   struct Prio {
-    int32_t mapId = -1, agent = 0, dimx = 0, ticket = -1;
-    std::vector<std::vector<Iv>> perCell;
-    std::vector<int32_t> touched;
-    std::vector<int32_t> xy, cnt, ivs, states;
+    int32_t mapId = -1, agent = 0, ticket = -1;
+    // allCollisionIntervals (mapf_prioritized_sipp.cpp:215) lives in the engine: an incrementally maintained table, so a
+    // job is a copy of the current table instead of a rebuild from every interval of the instance
+    mrp_ll_sipp_table* tab = nullptr;
+    std::vector<int32_t> states;
     mrp_ll_result res;
-    void add(int32_t x, int32_t y, Iv iv) {
-      std::vector<Iv>& v = perCell[static_cast<size_t>(y) * dimx + x];
-      if (v.empty()) touched.push_back(y * dimx + x);
-      v.push_back(iv);
-    }
+    void add(int32_t x, int32_t y, Iv iv) { (void)mrp_ll_sipp_table_add(tab, x, y, iv.s, iv.e); }
   };
   const size_t n = idx.size();
   const int32_t cap = std::max(horizon, 64);
@@ -1010,10 +998,18 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
     sols[idx[q]].cost = 0;
     sols[idx[q]].low_level_expanded = 0;
     sols[idx[q]].n_planned = 0;
-    st[q].dimx = in.dimx;
-    st[q].perCell.assign(static_cast<size_t>(std::max(in.dimx, 0)) * std::max(in.dimy, 0), std::vector<Iv>());
+    if (mrp_ll_sipp_table_create(ctx, st[q].mapId, &st[q].tab) != MRP_LL_SUCCESS) {
+      out.err = "mrp_ll_sipp_table_create failed";
+      return;
+    }
     st[q].states.resize(static_cast<size_t>(cap) * 3);
   }
+  struct TableGuard {  // the tables go when the group is done, whichever way it ends
+    std::vector<Prio>& st;
+    ~TableGuard() {
+      for (Prio& p : st) mrp_ll_sipp_table_destroy(p.tab);
+    }
+  } tableGuard{st};
   // at most one wavefront per instance, and about two per SIMD over all workers: the SIPP kernel waits on HBM for most
   // of an expansion, more resident wavefronts only slow each other down (measured 64 / 128 / 256 per worker: 0.59 /
   // 0.56 / 0.70 s for 4096 instances x 50 agents)
@@ -1027,19 +1023,6 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
   auto submit = [&](size_t q) -> int {
     Prio& p = st[q];
     const mrp_hl_instance& in = instances[idx[q]];
-    p.xy.clear();
-    p.cnt.clear();
-    p.ivs.clear();
-    for (int32_t cell : p.touched) {  // sipp.setCollisionIntervals(location, intervals) for every location (:224-226)
-      const std::vector<Iv>& v = p.perCell[cell];
-      p.xy.push_back(cell % p.dimx);
-      p.xy.push_back(cell / p.dimx);
-      p.cnt.push_back(static_cast<int32_t>(v.size()));
-      for (const Iv& iv : v) {
-        p.ivs.push_back(iv.s);
-        p.ivs.push_back(iv.e);
-      }
-    }
     mrp_ll_job j;
     std::memset(&j, 0, sizeof(j));
     j.map_id = p.mapId;
@@ -1050,10 +1033,7 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
     j.goal_x = in.goals_xy[2 * p.agent];
     j.goal_y = in.goals_xy[2 * p.agent + 1];
     j.max_expansions = -1;
-    j.n_collision_locations = static_cast<int32_t>(p.cnt.size());
-    j.collision_xy = p.xy.data();
-    j.collision_count = p.cnt.data();
-    j.collision_intervals = p.ivs.data();
+    j.sipp_table = p.tab;  // sipp.setCollisionIntervals(location, intervals) for every location (:224-226), kept up to date
     std::memset(&p.res, 0, sizeof(p.res));
     p.res.states_txy = p.states.data();
     p.res.states_cap = cap;

@@ -1025,9 +1025,31 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
     return;
   }
   {
+    // The job's safe-interval table (10-30 KB) comes out of pinned HOST memory: every load instruction is a PCIe round
+    // trip, so the copy is made of 16-byte lanes with eight loads in flight per lane (8 KB per round trip); dword by
+    // dword it was ~100 dependent round trips and the largest part of a job's time.
     const uint32_t* src = P.cons + J.vc_off;
-    for (uint32_t i = lane; i < tabWords; i += 64) tab[i] = src[i];
-    for (uint32_t i = lane; i < nStates; i += 64) g.bits[i] = 0;  // status: 0 unseen, node+1 in open, bit 31 closed
+    uint32_t done = 0;
+    if ((J.vc_off & 3u) == 0) {  // session slots are 16-byte aligned; a batch's tables start wherever the previous ended
+      const u32x4* src4 = (const u32x4*)src;
+      u32x4* dst4 = (u32x4*)tab;
+      const uint32_t n4 = tabWords / 4;
+      uint32_t i = lane;
+      for (; i + 7 * 64 < n4; i += 8 * 64) {
+        u32x4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load(src4 + i + q * 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst4[i + q * 64] = v[q];
+      }
+      for (; i < n4; i += 64) dst4[i] = __builtin_nontemporal_load(src4 + i);
+      done = n4 * 4;
+    }
+    for (uint32_t i = done + lane; i < tabWords; i += 64) tab[i] = src[i];
+    u32x4 z;
+    z.x = z.y = z.z = z.w = 0;  // status: 0 unseen, node+1 in open, bit 31 closed
+    u32x4* st4 = (u32x4*)(uint32_t*)g.bits;
+    for (uint32_t i = lane; i < (nStates + 3) / 4; i += 64) st4[i] = z;
   }
   __syncthreads();
   const uint32_t* cellIdx = tab;
@@ -1448,15 +1470,15 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams
   }
 }
 
-// Session mode.  The same workgroups stay resident for a whole solve and are fed through two ticket rings in coherent
+// Session mode.  The same workgroups stay resident for a whole solve and are fed through a ticket ring in coherent
 // pinned host memory.  An entry is (generation << 11) | job slot; job slots (descriptor, constraint words, path table,
-// result) come from a host-side free list, so a slow search holds one slot, not the ring.
-//   lane 0 (bulk)     : a workgroup takes ticket t with a device fetch-add and waits until the host has published it.
-//   lane 1 (priority) : EVERY workgroup looks here first — before taking a bulk ticket and on every poll while it
-//                       waits for one — and claims a ticket only if it is already published (compare-and-swap), so
-//                       the searches of an instance deep in its conflict tree never queue behind the bulk.
-// The finished job's slot gets ring_done[slot] = (ticket + 1) & 0x3FFFFFFF | 1 << 30 | lane << 31 (never 0) and an
-// entry in the completion queue.
+// result) come from a host-side free list, so a slow search holds one slot, not the ring.  A workgroup takes ticket t
+// with a device fetch-add and waits until the host has published it.  There is ONE queue and it is first in, first out:
+// which search runs next is decided by the HOST, which keeps the queue shallow and publishes in priority order (the
+// conflict-tree drivers, csrc/hl/mrp_hl.cpp) — a second, device-side priority ring that every polling wavefront had to
+// look at (round 1) cost more in claim traffic than it saved.
+// The finished job's slot gets ring_done[slot] = (ticket + 1) & 0x3FFFFFFF | 1 << 30 (never 0) and an entry in the
+// completion queue.
 // Exit conditions every wave reaches: *ring_stop != 0, or the host's heartbeat word has not moved for
 // ring_idle_limit_s seconds (the host is gone).
 template <bool SIPP, int KIND>
@@ -1465,13 +1487,10 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
   uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
   const uint64_t idleLimit = (uint64_t)P.ring_idle_limit_s * 100000000ull;  // s_memrealtime ticks at 100 MHz
   uint64_t busyTicks = 0, idleTicks = 0;
-  const uint32_t q0 = P.ring_size, q1 = P.ring_size1;
+  const uint32_t q0 = P.ring_size;
   uint32_t* const ring0 = P.ring_state;
-  uint32_t* const ring1 = P.ring_state + q0;
   uint32_t* const tickets0 = P.queue_head;        // device counters, 64 bytes apart
-  uint32_t* const tickets1 = P.queue_head + 16;
   uint32_t* const head0 = P.ring_head;            // host words, 64 bytes apart
-  uint32_t* const head1 = P.ring_head + 16;
   const uint32_t compSize = P.n_slots;
   bool haveBulk = false;                          // a bulk ticket is held and not yet served
   uint32_t bulkT = 0;
@@ -1482,36 +1501,6 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     uint64_t tBeat = t0;
     for (;;) {
-      // priority lane: claim only what is already published
-      const uint32_t hd1 = rfl(__hip_atomic_load(head1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
-      const uint32_t t1 = rfl(__hip_atomic_load(tickets1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if ((int32_t)(hd1 - t1) > 0) {
-        // Claim by compare-and-swap; a lost race retries on the device counter alone (the value the failed swap returned)
-        // while it is still below the published count read above — going back to the host word for every attempt would
-        // serialise the claims of all workgroups at one PCIe round trip each.  Lane 0 carries the real compare value;
-        // the other lanes compare against a value the counter cannot hold now.
-        uint32_t cur = t1;
-        bool got = false;
-        while ((int32_t)(hd1 - cur) > 0) {
-          const uint32_t old = rfl(atomicCAS(tickets1, lane == 0 ? cur : (cur ^ 0x80000000u), cur + 1u));
-          if (old == cur) {
-            got = true;
-            break;
-          }
-          cur = old;
-        }
-        if (got) {
-          const uint32_t gen = (cur / q1 + 1) & 0x1FFFFFu;
-          uint32_t e;
-          do {  // published before head1 was advanced: visible on the first look in practice
-            e = rfl(__hip_atomic_load(ring1 + cur % q1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
-          } while ((e >> kRingSlotBits) != gen);
-          slot = e & kRingSlotMask;
-          doneVal = ((cur + 1u) & 0x3FFFFFFFu) | 0xC0000000u;
-          break;
-        }
-      }
-      // bulk lane
       if (!haveBulk) {
         bulkT = rfl(atomicAdd(tickets0, lane == 0 ? 1u : 0u));
         haveBulk = true;

@@ -122,7 +122,7 @@ struct Ticket {
 // job, so one long search never blocks the publication of the searches behind it.
 struct Ring {
   static constexpr uint32_t kSlots = mrp::kRingSlots;     // job slots, shared by both lanes (the device masks with the same constant)
-  static constexpr uint32_t kReserve1 = 256;              // slots the bulk lane leaves free for the priority lane
+  static constexpr uint32_t kReserve1 = 0;                // (round 1: slots kept free for a device-side priority lane)
   static constexpr uint32_t kTickets0 = 1u << 17;         // ticket-ring entries of lane 0 / lane 1
   static constexpr uint32_t kTickets1 = 1u << 14;
   static constexpr uint32_t kTickets = kTickets0 + kTickets1;
@@ -342,8 +342,100 @@ SippScratch& sippScratchOf(mrp_ll_ctx* ctx) {
   return *static_cast<SippScratch*>(ctx->sippScratch);
 }
 
+// setCollisionIntervals for one location (sipp.hpp:245-284): collision intervals sorted by start -> safe intervals
+// appended to `out`.  `scratch` holds the sorted copy.
+void safeFromCollisions(const int32_t* civ, int cnt, std::vector<SippScratch::Iv>& scratch,
+                        std::vector<SippScratch::Iv>& out) {
+  typedef SippScratch::Iv Iv;
+  scratch.clear();
+  bool sorted = true;
+  for (int k = 0; k < cnt; ++k) {
+    scratch.push_back(Iv{civ[2 * k], civ[2 * k + 1]});
+    if (k && scratch[k].s < scratch[k - 1].s) sorted = false;
+  }
+  if (!sorted) std::stable_sort(scratch.begin(), scratch.end(), [](const Iv& a, const Iv& b) { return a.s < b.s; });
+  long long start = 0;
+  int32_t lastEnd = 0;
+  for (const Iv& c : scratch) {
+    if (start <= static_cast<long long>(c.s) - 1) out.push_back(Iv{static_cast<int32_t>(start), c.s - 1});
+    start = static_cast<long long>(c.e) + 1;
+    lastEnd = c.e;
+  }
+  if (lastEnd < INT32_MAX) out.push_back(Iv{static_cast<int32_t>(start), INT32_MAX});
+}
+
+}  // namespace
+
+// Incrementally maintained safe-interval table of one agent-planning context (include/mrp_ll.h, mrp_ll_sipp_table_*):
+// what SIPP::setCollisionIntervals would hold after the same calls, kept per cell so that adding one collision interval
+// recomputes one cell's list, and a job only has to be COPIED into its slot instead of being rebuilt from every
+// collision interval of the instance.
+struct mrp_ll_sipp_table {
+  int32_t mapId = -1, dimx = 0, dimy = 0;
+  std::vector<int32_t> cellIdx;                       // cell -> special index + 1
+  struct Spec {
+    std::vector<int32_t> collisions;                  // [n][2] in the order they were added
+    std::vector<SippScratch::Iv> safe;
+  };
+  std::vector<Spec> spec;
+  uint32_t totalSafe = 0;
+  std::vector<SippScratch::Iv> scratch;
+};
+
+namespace {
+
+// The table of a job from an mrp_ll_sipp_table: cellIdx[cells], specFirst[K + 1], ivals[total][2] (see runSipp).
+template <class ConsSink>
+bool packSippFromTable(const mrp_ll_job& j, const MapRec& mp, ConsSink& cs, DevJob& d) {
+  const mrp_ll_sipp_table& T = *j.sipp_table;
+  if (T.dimx != mp.dimx || T.dimy != mp.dimy) return false;
+  const int cells = mp.dimx * mp.dimy;
+  const uint32_t K = static_cast<uint32_t>(T.spec.size());
+  d.algo = MRP_LL_SIPP;
+  d.max_expansions = j.max_expansions;
+  d.vc_off = static_cast<uint32_t>(cs.size());
+  uint32_t* w = cs.grow(static_cast<size_t>(cells) + K + 1 + 2 * static_cast<size_t>(T.totalSafe));
+  if (!w) return false;
+  std::memcpy(w, T.cellIdx.data(), sizeof(uint32_t) * cells);
+  w += cells;
+  uint32_t run = 0;
+  for (uint32_t k = 0; k < K; ++k) {
+    w[k] = run;
+    run += static_cast<uint32_t>(T.spec[k].safe.size());
+  }
+  w[K] = run;
+  w += K + 1;
+  for (uint32_t k = 0; k < K; ++k) {
+    std::memcpy(w, T.spec[k].safe.data(), sizeof(SippScratch::Iv) * T.spec[k].safe.size());
+    w += 2 * T.spec[k].safe.size();
+  }
+  d.n_vc = K;
+  d.n_ec = T.totalSafe;
+  d.ec_off = 0;
+  d.n_agents_pad = 0;
+  d.path_off = 0;
+  const int32_t startTime = j.initial_cost;
+  if (startTime > static_cast<int32_t>(mrp::kGMask)) return false;
+  d.last_goal_constraint = startTime;
+  const int sc = j.start_y * mp.dimx + j.start_x;
+  int startIv = -1;
+  if (!T.cellIdx[sc]) {
+    startIv = 0;
+  } else {
+    const auto& v = T.spec[T.cellIdx[sc] - 1].safe;
+    for (size_t k = 0; k < v.size(); ++k)
+      if (v[k].s <= startTime && v[k].e >= startTime) {
+        startIv = static_cast<int>(k);
+        break;
+      }
+  }
+  d.t_pad = startIv < 0 ? 0xFFFFFFFFu : static_cast<uint32_t>(startIv);
+  return !cs.failed;
+}
+
 template <class ConsSink>
 bool packSipp(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, ConsSink& cs, DevJob& d) {
+  if (j.sipp_table) return packSippFromTable(j, mp, cs, d);
   const int cells = mp.dimx * mp.dimy;
   if (j.n_collision_locations < 0) return false;
   if (j.n_collision_locations > 0 && (!j.collision_xy || !j.collision_count || !j.collision_intervals)) return false;
@@ -363,24 +455,7 @@ bool packSipp(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, ConsSink& 
     if (x < 0 || x >= mp.dimx || y < 0 || y >= mp.dimy) continue;  // never visited
     const int cell = y * mp.dimx + x;
     const uint32_t p0 = static_cast<uint32_t>(sc0.pool.size());
-    if (cnt > 0) {
-      std::vector<Iv>& ci = sc0.ci;
-      ci.clear();
-      bool sorted = true;
-      for (int k = 0; k < cnt; ++k) {
-        ci.push_back(Iv{civ[2 * k], civ[2 * k + 1]});
-        if (k && ci[k].s < ci[k - 1].s) sorted = false;
-      }
-      if (!sorted) std::stable_sort(ci.begin(), ci.end(), [](const Iv& a, const Iv& b) { return a.s < b.s; });
-      long long start = 0;
-      int32_t lastEnd = 0;
-      for (const Iv& c : ci) {
-        if (start <= static_cast<long long>(c.s) - 1) sc0.pool.push_back(Iv{static_cast<int32_t>(start), c.s - 1});
-        start = static_cast<long long>(c.e) + 1;
-        lastEnd = c.e;
-      }
-      if (lastEnd < INT32_MAX) sc0.pool.push_back(Iv{static_cast<int32_t>(start), INT32_MAX});
-    }
+    if (cnt > 0) safeFromCollisions(civ, cnt, sc0.ci, sc0.pool);
     const uint32_t nSafe = static_cast<uint32_t>(sc0.pool.size()) - p0;
     // erase + re-create (sipp.hpp:247-251): an empty list restores the default single interval
     if (cellIdx[cell]) {
@@ -1343,7 +1418,9 @@ int mrp_ll_submit_lane(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp_l
                        int32_t* ticketOut) {
   if (!ctx || !ticketOut || nJobs < 0 || (nJobs > 0 && (!jobs || !results)) || lane < 0 || lane > 1) return MRP_LL_E_INVALID;
   if (!ctx->ring.active) return mrp_ll_submit(ctx, nJobs, jobs, results, ticketOut);  // batch mode has one queue
-  return sessionSubmit(ctx, lane, nJobs, jobs, results, ticketOut);
+  // one device queue, first in first out: `lane` is accepted for source compatibility and otherwise ignored — priority is
+  // the order in which the caller publishes (see mrp_ll.h)
+  return sessionSubmit(ctx, 0, nJobs, jobs, results, ticketOut);
 }
 
 int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
@@ -1389,6 +1466,37 @@ int mrp_ll_sync_maps(mrp_ll_ctx* ctx) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return syncMaps(ctx);
 }
+
+int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t mapId, mrp_ll_sipp_table** out) {
+  if (!ctx || !out || mapId < 0 || mapId >= static_cast<int32_t>(ctx->maps.size())) return MRP_LL_E_INVALID;
+  auto* t = new mrp_ll_sipp_table();
+  t->mapId = mapId;
+  t->dimx = ctx->maps[mapId].dimx;
+  t->dimy = ctx->maps[mapId].dimy;
+  t->cellIdx.assign(static_cast<size_t>(t->dimx) * t->dimy, 0);
+  *out = t;
+  return MRP_LL_SUCCESS;
+}
+
+int mrp_ll_sipp_table_add(mrp_ll_sipp_table* t, int32_t x, int32_t y, int32_t start, int32_t end) {
+  if (!t) return MRP_LL_E_INVALID;
+  if (x < 0 || x >= t->dimx || y < 0 || y >= t->dimy) return MRP_LL_SUCCESS;  // never visited
+  const size_t cell = static_cast<size_t>(y) * t->dimx + x;
+  if (!t->cellIdx[cell]) {
+    t->spec.emplace_back();
+    t->cellIdx[cell] = static_cast<int32_t>(t->spec.size());
+  }
+  mrp_ll_sipp_table::Spec& sp = t->spec[t->cellIdx[cell] - 1];
+  sp.collisions.push_back(start);
+  sp.collisions.push_back(end);
+  t->totalSafe -= static_cast<uint32_t>(sp.safe.size());
+  sp.safe.clear();
+  safeFromCollisions(sp.collisions.data(), static_cast<int>(sp.collisions.size() / 2), t->scratch, sp.safe);
+  t->totalSafe += static_cast<uint32_t>(sp.safe.size());
+  return MRP_LL_SUCCESS;
+}
+
+void mrp_ll_sipp_table_destroy(mrp_ll_sipp_table* t) { delete t; }
 
 int mrp_ll_release_maps(mrp_ll_ctx* ctx) {
   if (!ctx) return MRP_LL_E_INVALID;

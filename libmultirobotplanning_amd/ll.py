@@ -37,7 +37,8 @@ class mrp_ll_job(ctypes.Structure):
                 ("n_agents", ctypes.c_int32), ("path_len", I32P), ("path_xy", ctypes.POINTER(I32P)),
                 ("max_expansions", ctypes.c_int64),
                 ("n_collision_locations", ctypes.c_int32), ("collision_xy", I32P), ("collision_count", I32P),
-                ("collision_intervals", I32P), ("initial_cost", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("collision_intervals", I32P), ("initial_cost", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("sipp_table", ctypes.c_void_p)]
 
 
 class mrp_ll_result(ctypes.Structure):
@@ -62,7 +63,8 @@ class mrp_ll_stats(ctypes.Structure):
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
            "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version",
            "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any", "mrp_ll_submit_lane", "mrp_ll_sync_maps",
-           "mrp_ll_configure_tiers", "mrp_ll_session_begin_sipp", "mrp_ll_release_maps", "mrp_ll_session_begin_algo", "mrp_ll_conflict_scan"]
+           "mrp_ll_configure_tiers", "mrp_ll_session_begin_sipp", "mrp_ll_release_maps", "mrp_ll_session_begin_algo", "mrp_ll_conflict_scan",
+           "mrp_ll_sipp_table_create", "mrp_ll_sipp_table_add", "mrp_ll_sipp_table_destroy"]
 
 _lib = None
 
@@ -116,6 +118,12 @@ def load_library(path: Optional[str] = None):
     lib.mrp_ll_release_maps.argtypes = [ctypes.c_void_p]
     lib.mrp_ll_conflict_scan.restype = ctypes.c_int
     lib.mrp_ll_conflict_scan.argtypes = [ctypes.c_void_p, ctypes.c_int32, I32P, I32P, I32P, ctypes.POINTER(mrp_ll_conflict)]
+    lib.mrp_ll_sipp_table_create.restype = ctypes.c_int
+    lib.mrp_ll_sipp_table_create.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+    lib.mrp_ll_sipp_table_add.restype = ctypes.c_int
+    lib.mrp_ll_sipp_table_add.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 4
+    lib.mrp_ll_sipp_table_destroy.restype = None
+    lib.mrp_ll_sipp_table_destroy.argtypes = [ctypes.c_void_p]
     lib.mrp_ll_poll_any.restype = ctypes.c_int
     lib.mrp_ll_poll_any.argtypes = [ctypes.c_void_p, I32P, ctypes.c_int32, I32P]
     if path is None:
@@ -138,6 +146,7 @@ class LLJob:
     max_expansions: int = -1
     collision_intervals: Sequence[Sequence[int]] = ()  # SIPP: [x, y, start, end] (grouped per location, in order)
     initial_cost: int = 0  # A*: AStar::search(..., initialCost) a_star.hpp:64; SIPP: SIPP::search(..., startTime) sipp.hpp:92
+    sipp_table: Optional[int] = None  # SIPP: handle from LowLevelEngine.sipp_table_create (replaces collision_intervals)
 
 
 @dataclass
@@ -213,6 +222,8 @@ class LowLevelEngine:
             cj.path_xy = ctypes.cast(pptr, ctypes.POINTER(I32P))
             cj.max_expansions = j.max_expansions
             cj.initial_cost = j.initial_cost
+            if j.sipp_table is not None:
+                cj.sipp_table = j.sipp_table
             if j.collision_intervals:
                 locs, counts, ivs = [], [], []
                 for x, y, a, b in j.collision_intervals:  # consecutive entries of one location form one list
@@ -270,6 +281,17 @@ class LowLevelEngine:
                                                    path_first.ctypes.data_as(I32P), xy.ctypes.data_as(I32P), out),
                     "mrp_ll_conflict_scan")
         return [{k: getattr(out[i], k) for k, _ in mrp_ll_conflict._fields_} for i in range(n)]
+
+    def sipp_table_create(self, map_id: int) -> int:
+        h = ctypes.c_void_p()
+        self._check(self._lib.mrp_ll_sipp_table_create(self._h, map_id, ctypes.byref(h)), "mrp_ll_sipp_table_create")
+        return h.value
+
+    def sipp_table_add(self, table: int, x: int, y: int, start: int, end: int) -> None:
+        self._check(self._lib.mrp_ll_sipp_table_add(table, x, y, start, end), "mrp_ll_sipp_table_add")
+
+    def sipp_table_destroy(self, table: int) -> None:
+        self._lib.mrp_ll_sipp_table_destroy(table)
 
     def configure_tiers(self, lds_nodes: int = 0, lds_rows: int = 0, lds_path_bytes: int = 0) -> int:
         """Geometry of the LDS fast tier for the launches that follow (0 = keep); returns resident searches per CU."""

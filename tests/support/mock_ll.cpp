@@ -153,6 +153,13 @@ int mrp_ll_poll(mrp_ll_ctx*, int32_t, int32_t* done) {
 int mrp_ll_conflict_scan(mrp_ll_ctx*, int32_t, const int32_t*, const int32_t*, const int32_t*, mrp_ll_conflict*) {
   return MRP_LL_E_DEVICE;  // the scan kernel has no stand-in: the host drivers do not call it
 }
+struct mrp_ll_sipp_table {};  // SIPP has no stand-in here: the prioritized-SIPP driver is covered by the GPU tests
+int mrp_ll_sipp_table_create(mrp_ll_ctx*, int32_t, mrp_ll_sipp_table** out) {
+  *out = new mrp_ll_sipp_table();
+  return MRP_LL_SUCCESS;
+}
+int mrp_ll_sipp_table_add(mrp_ll_sipp_table*, int32_t, int32_t, int32_t, int32_t) { return MRP_LL_SUCCESS; }
+void mrp_ll_sipp_table_destroy(mrp_ll_sipp_table* t) { delete t; }
 int mrp_ll_get_stats(const mrp_ll_ctx* c, mrp_ll_stats* out) {
   *out = c->stats;
   return MRP_LL_SUCCESS;
