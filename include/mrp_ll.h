@@ -114,6 +114,15 @@ typedef struct mrp_ll_job {
   /* MRP_LL_SIPP only, optional: an incrementally maintained table (mrp_ll_sipp_table_*) instead of the collision_*
    * arrays above (which are then ignored).  The table must stay unchanged until the job has been submitted. */
   const struct mrp_ll_sipp_table* sipp_table;
+  /* Device-resident path store (mrp_ll_path_store_reserve).  A conflict-tree child differs from its
+   * parent in ONE path (ecbs.hpp:253-263 copies all N), and every path was produced by a search of this engine: with
+   * result_path_id >= 0 the kernel ALSO leaves the result path in that store slot, and a later MRP_LL_ASTAR_EPS job names
+   * the CT node's paths by their slots — path_ids[n_agents], -1 = no path / the searching agent itself — instead of
+   * shipping them (path_xy may then be NULL; path_len is still required).  Slot ids are managed by the caller: a slot
+   * may be reused once no unfinished job names it. */
+  const int32_t* path_ids;
+  int32_t result_path_id;  /* -1: the result path is only returned to the caller */
+  int32_t reserved2;
 } mrp_ll_job;
 
 typedef struct mrp_ll_result {
@@ -141,6 +150,8 @@ typedef struct mrp_ll_stats {
   double session_busy_ms, session_idle_ms; /* session mode: sum over resident workgroups of time in jobs / waiting */
   int64_t session_active_wgs;              /* session mode: workgroups that ran at least one job (summed over sessions) */
   double pack_ms, unpack_ms; /* host time spent packing jobs (mrp_ll_submit) / unpacking results (mrp_ll_wait)           */
+  int64_t staged_bytes;      /* bytes of job descriptors, constraint words, id lists and path / interval tables written   */
+                             /* to pinned host memory for the device to read over PCIe                                    */
   int64_t prof[8];           /* diagnostic (-DMRP_LL_TRACE library only, else 0): shader cycles in walk, pops,  */
                              /* pushes, successor generation, row init, whole job; #walks; nodes visited by walks */
 } mrp_ll_stats;
@@ -155,6 +166,11 @@ int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t n_obs
 
 /* Copies every map uploaded so far to the device now (otherwise done lazily by the next submit / session_begin). */
 int mrp_ll_sync_maps(mrp_ll_ctx* ctx);
+
+/* Allocates the device-resident path store: n_slots slots of one path each (up to mrp_ll_options.max_horizon states).
+ * Slot ids 0 .. n_slots-1 are the caller's to hand out (mrp_ll_job.result_path_id / path_ids).  MRP_LL_E_BUSY while a
+ * batch or a session is in flight; calling it again re-allocates (contents are lost). */
+int mrp_ll_path_store_reserve(mrp_ll_ctx* ctx, int32_t n_slots);
 
 /* ---- incrementally maintained SIPP tables --------------------------------------------------------------------
  * The state SIPP::setCollisionIntervals (sipp.hpp:245-284) builds up, kept by the engine so that a planner which adds a

@@ -9,12 +9,39 @@
 
 namespace mrp_hl {
 
+// Slot ids of the engine's device-resident path store (mrp_ll_path_store_reserve), handed out per worker thread.
+struct SlotPool {
+  std::vector<int32_t> freed;
+  int32_t next = 0, cap = 0;
+  int32_t take() {
+    if (!freed.empty()) {
+      const int32_t s = freed.back();
+      freed.pop_back();
+      return s;
+    }
+    return next < cap ? next++ : -1;
+  }
+  void give(int32_t s) {
+    if (s >= 0) freed.push_back(s);
+  }
+};
+
 struct Path {                 // PlanResult of one agent (planresult.hpp:18-27); state k is at time k, every step costs 1
   std::vector<int32_t> xy;    // [len][2]
   int32_t cost = 0;
   int32_t fmin = 0;
   bool fits8 = false;         // every coordinate is in 0..255 (set by whoever fills xy; enables the linear scans)
+  // the search that produced this path also left it in the engine's device path store; the slot goes back
+  // to its pool with the last conflict-tree node that shares the path (ecbs.hpp:253 would have copied it instead)
+  int32_t devSlot = -1;
+  SlotPool* pool = nullptr;
   int32_t len() const { return static_cast<int32_t>(xy.size() / 2); }
+  Path() = default;
+  Path(const Path&) = delete;
+  Path& operator=(const Path&) = delete;
+  ~Path() {
+    if (pool) pool->give(devSlot);
+  }
 };
 typedef std::shared_ptr<const Path> PathPtr;
 

@@ -40,6 +40,7 @@ struct mrp_hl_solver {
   mrp_ll_options llOpt;
   std::string err;
   int32_t nPreloaded = 0;  // live mrp_hl_preloaded objects (their maps are released with the last one)
+  int32_t pathSlots = 0;   // slots of the engines' device path stores (0: not allocated)
 };
 
 namespace {
@@ -57,8 +58,9 @@ struct GroupResult {
 
 // One low-level job of the C-ABI for request `r` of instance `I`; the focal-context arrays go to the pools (pointers
 // are patched in by the caller once the pools have stopped growing).
+// `idPool` != nullptr: also name the context paths by their device path-store slots (f2) when every one of them has one.
 void fillJob(const Instance& I, const LLRequest& r, mrp_ll_job& j, std::vector<int32_t>& pathLenPool,
-             std::vector<const int32_t*>& pathPtrPool) {
+             std::vector<const int32_t*>& pathPtrPool, std::vector<int32_t>* idPool = nullptr, bool* idsOk = nullptr) {
   std::memset(&j, 0, sizeof(j));
   j.map_id = I.mapId();
   j.algo = I.algo() == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR;
@@ -73,16 +75,28 @@ void fillJob(const Instance& I, const LLRequest& r, mrp_ll_job& j, std::vector<i
   j.n_edge_constraints = static_cast<int32_t>(r.constraints->edge.size() / 5);
   j.edge_constraints = r.constraints->edge.data();
   j.max_expansions = I.remainingLL();
+  j.result_path_id = -1;
+  if (idsOk) *idsOk = false;
   if (r.context) {
     j.n_agents = static_cast<int32_t>(r.context->size());
+    bool all = idPool != nullptr;
+    int32_t a = 0;
     for (const PathPtr& p : *r.context) {
       pathLenPool.push_back(p->len());
       pathPtrPool.push_back(p->xy.data());
+      if (idPool) {
+        const bool needed = a != r.agent && p->len() > 0;
+        idPool->push_back(needed ? p->devSlot : -1);
+        if (needed && p->devSlot < 0) all = false;
+      }
+      ++a;
     }
+    if (idsOk) *idsOk = all;
   }
 }
 
-LLAnswer answerOf(const mrp_ll_result& r) {
+// `slot` / `pool`: the path-store slot the job was given for its result path (-1: none)
+LLAnswer answerOf(const mrp_ll_result& r, int32_t slot = -1, SlotPool* pool = nullptr) {
   LLAnswer a;
   a.status = r.status;
   a.cost = r.cost;
@@ -100,7 +114,13 @@ LLAnswer answerOf(const mrp_ll_result& r) {
     p->fits8 = orAll < 256u;
     p->cost = r.cost;
     p->fmin = r.fmin;
+    if (pool && slot >= 0) {
+      p->devSlot = slot;
+      p->pool = pool;
+    }
     a.path = p;
+  } else if (pool) {
+    pool->give(slot);  // no path came out of this search
   }
   return a;
 }
@@ -242,8 +262,8 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
 // otherwise the worker owns exactly idx[...].
 void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance* instIn, mrp_hl_solution* sols,
                      const std::vector<int32_t>& idx, const std::vector<int32_t>& mapIds, int32_t horizon,
-                     int32_t workgroups, GroupResult& out, std::atomic<int32_t>* shared = nullptr, int32_t nTotal = 0,
-                     int32_t mapBase = 0, int32_t nWorkersIn = 1) {
+                     int32_t workgroups, int32_t pathSlots, GroupResult& out, std::atomic<int32_t>* shared = nullptr,
+                     int32_t nTotal = 0, int32_t mapBase = 0, int32_t nWorkersIn = 1) {
   const size_t nWorkers = static_cast<size_t>(std::max(nWorkersIn, 1));
   const size_t n = shared ? static_cast<size_t>(nTotal) : idx.size();
   struct Live {
@@ -259,7 +279,15 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     int32_t group = 0;
     std::vector<mrp_ll_result> res;
     std::vector<int32_t> states;
+    std::vector<int32_t> outSlot;  // per job: the path-store slot its result path also goes to (-1: none)
   };
+  // f2: slots of the engine's device-resident path store, handed to the searches of this worker for their result paths;
+  // declared before `live` so that it outlives every Path that returns its slot to it
+  SlotPool slotPool;
+  slotPool.cap = pathSlots;
+  std::vector<int32_t> idPool;
+  std::vector<size_t> idOff;
+  std::vector<uint8_t> idOk;
   std::deque<Live> live;        // grows as instances are admitted; references stay valid
   std::vector<int32_t> gidx;    // live entry -> instance index
   std::deque<Pending> pend;
@@ -289,12 +317,18 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     pathLenPool.clear();
     pathPtrPool.clear();
     poolOff.clear();
+    idPool.clear();
+    idOff.clear();
+    idOk.clear();
     const int32_t group = L.req[L.reqHead].group;
     size_t end = L.reqHead;
     while (end < L.req.size() && L.req[end].group == group) {
       mrp_ll_job j;
       poolOff.push_back(pathLenPool.size());
-      fillJob(I, L.req[end], j, pathLenPool, pathPtrPool);
+      idOff.push_back(idPool.size());
+      bool ok = false;
+      fillJob(I, L.req[end], j, pathLenPool, pathPtrPool, pathSlots > 0 ? &idPool : nullptr, &ok);
+      idOk.push_back(ok ? 1 : 0);
       jobs.push_back(j);
       ++end;
     }
@@ -302,6 +336,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       if (jobs[q].n_agents > 0) {
         jobs[q].path_len = pathLenPool.data() + poolOff[q];
         jobs[q].path_xy = pathPtrPool.data() + poolOff[q];
+        if (idOk[q]) jobs[q].path_ids = idPool.data() + idOff[q];  // every needed path is in the device store
       }
     int32_t pi;
     if (!pendFree.empty()) {
@@ -314,6 +349,9 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     Pending& P = pend[pi];
     P.live = k;
     P.group = group;
+    P.outSlot.assign(jobs.size(), -1);
+    if (pathSlots > 0)
+      for (size_t q = 0; q < jobs.size(); ++q) jobs[q].result_path_id = P.outSlot[q] = slotPool.take();
     P.res.assign(jobs.size(), mrp_ll_result());
     P.states.resize(jobs.size() * static_cast<size_t>(cap) * 3);
     for (size_t q = 0; q < jobs.size(); ++q) {
@@ -323,6 +361,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     }
     int32_t ticket = -1;
     int rc = mrp_ll_submit(ctx, static_cast<int32_t>(jobs.size()), jobs.data(), P.res.data(), &ticket);
+    if (rc != MRP_LL_SUCCESS)
+      for (int32_t sl : P.outSlot) slotPool.give(sl);
     if (rc == MRP_LL_E_BUSY) {
       pendFree.push_back(pi);
       return 0;
@@ -500,9 +540,9 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       jobsOut -= static_cast<int64_t>(P.res.size());
       auto tu0 = nowS();
       ans.clear();
-      for (const mrp_ll_result& r : P.res) {
-        ranExpansions += r.expanded;
-        ans.push_back(answerOf(r));
+      for (size_t q = 0; q < P.res.size(); ++q) {
+        ranExpansions += P.res[q].expanded;
+        ans.push_back(answerOf(P.res[q], P.outSlot[q], &slotPool));
       }
       const int32_t group = P.group;
       pendFree.push_back(donePend[d]);
@@ -635,6 +675,7 @@ int mrp_hl_solver_ll_stats(mrp_hl_solver* s, mrp_ll_stats* out, int32_t reset) {
     out->h2d_ms += st.h2d_ms;
     out->d2h_ms += st.d2h_ms;
     out->pack_ms += st.pack_ms;
+    out->staged_bytes += st.staged_bytes;
     out->session_busy_ms += st.session_busy_ms;
     out->session_idle_ms += st.session_idle_ms;
     out->session_active_wgs += st.session_active_wgs;
@@ -754,6 +795,22 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   // resident wavefronts per engine: the chip holds 256 CUs x `occupancy` workgroups of this kernel at once
   int32_t sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, (256 * occupancy) / nThreads));
   if (const char* e = std::getenv("MRP_HL_SESSION_WGS")) sessionWgs = std::max(1, std::atoi(e));  // tuning knob
+  // f2: the engines' device-resident path stores (ECBS only: CBS's low level has no focal context).  A search leaves its
+  // path there, and later jobs name the paths of their CT node by slot instead of shipping a [t][agent] table.
+  int32_t pathSlots = 0;
+  if (opt.algo == MRP_HL_ECBS && opt.mode != 1) {
+    pathSlots = 1 << 18;
+    if (const char* e = std::getenv("MRP_HL_PATH_SLOTS")) pathSlots = std::max(0, std::atoi(e));  // 0 = ship tables (round 1)
+    if (pathSlots != s->pathSlots) {
+      for (int32_t t = 0; t < static_cast<int32_t>(s->engines.size()); ++t)
+        if (mrp_ll_path_store_reserve(s->engines[t], pathSlots) != MRP_LL_SUCCESS) {
+          pathSlots = 0;  // e.g. the CPU test build: fall back to tables everywhere
+          for (int32_t u = 0; u <= t; ++u) (void)mrp_ll_path_store_reserve(s->engines[u], 0);
+          break;
+        }
+      s->pathSlots = pathSlots;
+    }
+  }
   // one pool of instances for all workers (MRP_HL_STATIC_SPLIT=1 restores the fixed interleaved split)
   std::atomic<int32_t> nextInstance(0);
   const bool sharedPool = std::getenv("MRP_HL_STATIC_SPLIT") == nullptr;
@@ -765,10 +822,11 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
         if (opt.mode == 1)
           runGroup(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, gr[t]);
         else if (sharedPool)
-          runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, gr[t],
-                          &nextInstance, nInst, pre->mapBase[t], nThreads);
+          runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, pathSlots,
+                          gr[t], &nextInstance, nInst, pre->mapBase[t], nThreads);
         else
-          runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, gr[t]);
+          runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, pathSlots,
+                          gr[t]);
       });
     for (auto& x : th) x.join();
   }

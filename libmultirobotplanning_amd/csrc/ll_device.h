@@ -29,7 +29,7 @@ constexpr uint32_t kHeartbeatWord = 32;                           // ring_head[3
 // status codes mirror include/mrp_ll.h
 enum : int32_t { ST_OK = 0, ST_NO_SOLUTION = 1, ST_CAP_EXP = 2, ST_CAP_NODES = 3, ST_CAP_HORIZON = 4, ST_BAD = 5 };
 
-struct DevJob {            // 80 bytes, 16-byte aligned
+struct DevJob {            // 96 bytes, 16-byte aligned
   uint32_t map_word_off;   // offset (uint32 words) of the obstacle bitmap inside the maps buffer
   uint32_t dimx, dimy;
   uint32_t words_per_row;  // ceil(dimx*dimy / 32)
@@ -43,7 +43,15 @@ struct DevJob {            // 80 bytes, 16-byte aligned
   uint32_t t_pad;          // path table rows (>= 1 when n_agents_pad > 0); row t_pad-1 repeats forever
   uint32_t path_off;       // offset (uint16 units) of the job's table  [t_pad][n_agents_pad]
   int64_t max_expansions;  // < 0: unlimited
+  // ---- device-resident path store ----
+  uint32_t ctx_flags;      // bit 0: the focal context is a list of path-store ids (n_ctx words at cons[path_off]) instead
+                           // of a table at paths[path_off]; the workgroup builds the time-major table itself
+  uint32_t n_ctx;          // agents in that list
+  uint32_t store_out_id;   // kNoStoreSlot, or the path-store slot that also receives the result path
+  uint32_t reserved;
 };
+constexpr uint32_t kNoStoreSlot = 0xFFFFFFFFu;
+constexpr uint32_t kCtxById = 1u;
 
 struct DevResult {         // 64 bytes
   int32_t status;
@@ -96,6 +104,10 @@ struct LaunchParams {
   uint32_t ring_size1;        // ticket-ring entries of lane 1, the priority lane (stored after lane 0's)
   uint32_t n_slots;           // job slots (both lanes); at most 2048 (11-bit slot field)
   uint32_t ring_idle_limit_s; // a workgroup leaves when the host heartbeat (ring_head[kHeartbeatWord]) stood still this long
+  // ---- device-resident path store: slot = [len][cell 0][cell 1]... halfwords, cell = y * dimx + x ----
+  uint16_t* path_store;       // device (uncached allocation: written by one workgroup, read by others of a resident kernel)
+  uint32_t path_store_stride; // halfwords per slot (0 = no store)
+  uint32_t path_store_slots;
 };
 
 }  // namespace mrp

@@ -882,7 +882,37 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     const uint32_t* psrc = (const uint32_t*)(P.paths + J.path_off);
     uint8_t* ldsPaths = smem + ldsBytes(P.lds_nodes, P.lds_rows, P.lds_row_words, 0);
     c.pathsLds = nullptr;
-    if (pathBytes == 0) {
+    if (pathBytes != 0 && (J.ctx_flags & kCtxById)) {
+      // f2: the CT node's paths are named by their slots in the device-resident path store (each was written there by
+      // the search that produced it); the time-major table [t][agent] is built here, on the device, instead of being
+      // packed by the host and read over PCIe.  One coalesced read per agent (lane = time step).
+      const bool inLds = P.lds_nodes != 0 && pathBytes <= P.lds_paths_bytes;
+      uint16_t* dst = inLds ? (uint16_t*)ldsPaths : (uint16_t*)pathsArena;
+      {
+        uint32_t* d32 = (uint32_t*)dst;
+        for (uint32_t i = lane; i < pathBytes / 4; i += 64) d32[i] = 0xFFFFFFFFu;  // kEmptyCell everywhere
+      }
+      __syncthreads();
+      const uint32_t* ids = P.cons + J.path_off;
+      const uint32_t nCtx = J.n_ctx;
+      for (uint32_t a0 = 0; a0 < nCtx; a0 += 64) {
+        // this chunk's ids and lengths, one agent per lane (one gather for all lengths)
+        uint32_t idL = kNoStoreSlot, lenL = 0;
+        if (a0 + lane < nCtx) idL = ids[a0 + lane];
+        if (idL < P.path_store_slots) lenL = P.path_store[(size_t)idL * P.path_store_stride];
+        if (lenL > P.path_store_stride - 1) lenL = P.path_store_stride - 1;
+        const uint32_t nHere = nCtx - a0 < 64 ? nCtx - a0 : 64;
+        for (uint32_t q = 0; q < nHere; ++q) {
+          const uint32_t id = __builtin_amdgcn_readlane(idL, q);
+          const uint32_t len = __builtin_amdgcn_readlane(lenL, q);
+          if (id >= P.path_store_slots || len == 0) continue;  // empty path, or the searching agent itself
+          const uint16_t* slot = P.path_store + (size_t)id * P.path_store_stride + 1;
+          for (uint32_t t = lane; t < c.tPad; t += 64) dst[t * c.nAgentsPad + a0 + q] = slot[t < len ? t : len - 1];
+        }
+      }
+      c.paths = dst;
+      if (inLds) c.pathsLds = (__attribute__((address_space(3))) const uint16_t*)ldsPaths;
+    } else if (pathBytes == 0) {
       c.paths = nullptr;
     } else if (P.lds_nodes != 0 && pathBytes <= P.lds_paths_bytes) {
       uint32_t* dst = (uint32_t*)ldsPaths;
@@ -1387,6 +1417,18 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
     const uint32_t* src = (const uint32_t*)outPath;
     uint32_t* dst = (uint32_t*)pathDst;
     for (uint32_t i = lane; i < words; i += 64) dst[i] = src[i];
+    // f2: the path also goes into the device path store (as cells), where the jobs of the conflict-tree nodes that
+    // contain it will read it; visible to them because they are published after this job's completion was seen
+    const uint32_t sid = rfl(J.store_out_id);
+    if (sid < P.path_store_slots && (uint32_t)res.n_states < P.path_store_stride) {
+      uint16_t* slot = P.path_store + (size_t)sid * P.path_store_stride;
+      const uint32_t dimx = rfl(J.dimx);
+      for (uint32_t i = lane; i < (uint32_t)res.n_states; i += 64) {
+        const uint32_t xy = outPath[i];
+        slot[1 + i] = (uint16_t)((xy >> 8) * dimx + (xy & 0xFF));
+      }
+      slot[0] = (uint16_t)res.n_states;
+    }
   }
 }
 

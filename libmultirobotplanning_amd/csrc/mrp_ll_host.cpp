@@ -207,6 +207,8 @@ struct mrp_ll_ctx {
   std::vector<SessTicket> sess;
   std::vector<int32_t> sessFree;   // free session-ticket ids (stack)
   void* sippScratch = nullptr;     // SippScratch, created on first use (packSipp)
+  uint16_t* pathStore = nullptr;   // device-resident path store (mrp_ll_path_store_reserve)
+  uint32_t pathStoreStride = 0, pathStoreSlots = 0;
   uint8_t* scanDev = nullptr;      // mrp_ll_conflict_scan: device staging (grown on demand)
   size_t scanDevCap = 0;
   std::vector<uint16_t> scanStates;
@@ -582,7 +584,30 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   d.n_agents_pad = 0;
   d.t_pad = 0;
   d.path_off = 0;
-  if (j.algo == MRP_LL_ASTAR_EPS && j.n_agents > 0) {
+  d.store_out_id = (j.result_path_id >= 0 && static_cast<uint32_t>(j.result_path_id) < ctx->pathStoreSlots)
+                       ? static_cast<uint32_t>(j.result_path_id)
+                       : mrp::kNoStoreSlot;
+  if (j.result_path_id >= 0 && d.store_out_id == mrp::kNoStoreSlot) return false;  // no such slot
+  if (j.algo == MRP_LL_ASTAR_EPS && j.n_agents > 0 && j.path_ids) {
+    // f2: the CT node's paths by their path-store slots; the workgroup builds the table (ll_kernel.hip runJob)
+    if (!j.path_len || !ctx->pathStore) return false;
+    int tpad = 0;
+    for (int a = 0; a < j.n_agents; ++a)
+      if (a != j.agent_idx && j.path_len[a] > 0) {
+        if (j.path_ids[a] < 0 || static_cast<uint32_t>(j.path_ids[a]) >= ctx->pathStoreSlots) return false;
+        tpad = std::max(tpad, j.path_len[a]);
+      }
+    if (tpad > 0) {
+      d.path_off = static_cast<uint32_t>(cs.size());
+      for (int a = 0; a < j.n_agents; ++a)
+        cs.push(a != j.agent_idx && j.path_len[a] > 0 ? static_cast<uint32_t>(j.path_ids[a]) : mrp::kNoStoreSlot);
+      if (cs.failed) return false;
+      d.ctx_flags = mrp::kCtxById;
+      d.n_ctx = static_cast<uint32_t>(j.n_agents);
+      d.n_agents_pad = (static_cast<uint32_t>(j.n_agents) + 15u) & ~15u;
+      d.t_pad = static_cast<uint32_t>(tpad);
+    }
+  } else if (j.algo == MRP_LL_ASTAR_EPS && j.n_agents > 0) {
     if (!j.path_len || !j.path_xy) return false;
     int tpad = 0;
     for (int a = 0; a < j.n_agents; ++a)
@@ -651,6 +676,9 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
       ldsNodes = 0;
     }
   }
+  P.path_store = ctx->pathStore;
+  P.path_store_stride = ctx->pathStoreStride;
+  P.path_store_slots = ctx->pathStore ? ctx->pathStoreSlots : 0;
   P.lds_nodes = ldsNodes;
   P.lds_rows = rows;
   P.lds_row_words = rowWords;
@@ -859,6 +887,7 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
   }
   if (ctx->mapsDev) (void)hipFree(ctx->mapsDev);
   if (ctx->scanDev) (void)hipFree(ctx->scanDev);
+  if (ctx->pathStore) (void)hipFree(ctx->pathStore);
   delete ctx;
 }
 
@@ -1199,6 +1228,8 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
       st.state[i] = 2;
     }
     g.jobs[slot] = d;
+    ctx->stats.staged_bytes += static_cast<int64_t>(sizeof(DevJob)) + 4 * static_cast<int64_t>(g.sipp ? 0 : cs.used) +
+                               (d.ctx_flags & mrp::kCtxById ? 0 : 2 * static_cast<int64_t>(d.t_pad) * d.n_agents_pad);
     g.slotInit[slot] = ok ? jobs[i].initial_cost : 0;
     g.busy[slot] = 1;
     g.slotTicket[slot] = ti;
@@ -1465,6 +1496,34 @@ int mrp_ll_sync_maps(mrp_ll_ctx* ctx) {
   if (ctx->ring.active) return MRP_LL_SUCCESS;  // in-session uploads are copied immediately
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return syncMaps(ctx);
+}
+
+int mrp_ll_path_store_reserve(mrp_ll_ctx* ctx, int32_t nSlots) {
+  if (!ctx || nSlots < 0) return MRP_LL_E_INVALID;
+  if (ctx->ring.active) return MRP_LL_E_BUSY;
+  for (const Ticket& t : ctx->tickets)
+    if (t.inFlight) return MRP_LL_E_BUSY;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->pathStore) HIPCHK(ctx, hipFree(ctx->pathStore));
+  ctx->pathStore = nullptr;
+  ctx->pathStoreSlots = 0;
+  if (nSlots == 0) return MRP_LL_SUCCESS;
+  // [len][cells...]: one halfword in front of up to max_horizon states, rounded up to 16 bytes
+  ctx->pathStoreStride = (static_cast<uint32_t>(ctx->opt.max_horizon) + 1u + 7u) & ~7u;
+  const size_t bytes = static_cast<size_t>(nSlots) * ctx->pathStoreStride * sizeof(uint16_t);
+  // Uncached device memory: a slot is written by one workgroup of a resident kernel and read by workgroups on other CUs /
+  // XCDs of the SAME launch, whose L1 / per-XCD L2 are never invalidated in between; ordering is carried by the host
+  // (a reader's job is published only after the writer's completion was seen).
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    ctx->err = std::string("mrp_ll_path_store_reserve: ") + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? MRP_LL_E_NOMEM : MRP_LL_E_DEVICE;
+  }
+  ctx->pathStore = static_cast<uint16_t*>(p);
+  ctx->pathStoreSlots = static_cast<uint32_t>(nSlots);
+  HIPCHK(ctx, hipMemset(ctx->pathStore, 0, bytes));
+  return MRP_LL_SUCCESS;
 }
 
 int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t mapId, mrp_ll_sipp_table** out) {

@@ -38,7 +38,8 @@ class mrp_ll_job(ctypes.Structure):
                 ("max_expansions", ctypes.c_int64),
                 ("n_collision_locations", ctypes.c_int32), ("collision_xy", I32P), ("collision_count", I32P),
                 ("collision_intervals", I32P), ("initial_cost", ctypes.c_int32), ("reserved", ctypes.c_int32),
-                ("sipp_table", ctypes.c_void_p)]
+                ("sipp_table", ctypes.c_void_p), ("path_ids", I32P), ("result_path_id", ctypes.c_int32),
+                ("reserved2", ctypes.c_int32)]
 
 
 class mrp_ll_result(ctypes.Structure):
@@ -57,14 +58,14 @@ class mrp_ll_stats(ctypes.Structure):
                 ("nodes_created", ctypes.c_int64), ("migrated", ctypes.c_int64), ("kernel_ms", ctypes.c_double),
                 ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("session_busy_ms", ctypes.c_double),
                 ("session_idle_ms", ctypes.c_double), ("session_active_wgs", ctypes.c_int64), ("pack_ms", ctypes.c_double),
-                ("unpack_ms", ctypes.c_double), ("prof", ctypes.c_int64 * 8)]
+                ("unpack_ms", ctypes.c_double), ("staged_bytes", ctypes.c_int64), ("prof", ctypes.c_int64 * 8)]
 
 
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
            "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version",
            "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any", "mrp_ll_submit_lane", "mrp_ll_sync_maps",
            "mrp_ll_configure_tiers", "mrp_ll_session_begin_sipp", "mrp_ll_release_maps", "mrp_ll_session_begin_algo", "mrp_ll_conflict_scan",
-           "mrp_ll_sipp_table_create", "mrp_ll_sipp_table_add", "mrp_ll_sipp_table_destroy"]
+           "mrp_ll_sipp_table_create", "mrp_ll_sipp_table_add", "mrp_ll_sipp_table_destroy", "mrp_ll_path_store_reserve"]
 
 _lib = None
 
@@ -118,6 +119,8 @@ def load_library(path: Optional[str] = None):
     lib.mrp_ll_release_maps.argtypes = [ctypes.c_void_p]
     lib.mrp_ll_conflict_scan.restype = ctypes.c_int
     lib.mrp_ll_conflict_scan.argtypes = [ctypes.c_void_p, ctypes.c_int32, I32P, I32P, I32P, ctypes.POINTER(mrp_ll_conflict)]
+    lib.mrp_ll_path_store_reserve.restype = ctypes.c_int
+    lib.mrp_ll_path_store_reserve.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.mrp_ll_sipp_table_create.restype = ctypes.c_int
     lib.mrp_ll_sipp_table_create.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
     lib.mrp_ll_sipp_table_add.restype = ctypes.c_int
@@ -147,6 +150,8 @@ class LLJob:
     collision_intervals: Sequence[Sequence[int]] = ()  # SIPP: [x, y, start, end] (grouped per location, in order)
     initial_cost: int = 0  # A*: AStar::search(..., initialCost) a_star.hpp:64; SIPP: SIPP::search(..., startTime) sipp.hpp:92
     sipp_table: Optional[int] = None  # SIPP: handle from LowLevelEngine.sipp_table_create (replaces collision_intervals)
+    path_ids: Optional[Sequence[int]] = None  # f2: path-store slots of ctx_paths (-1 = none); lengths come from ctx_paths
+    result_path_id: int = -1                  # f2: path-store slot that also receives the result path
 
 
 @dataclass
@@ -224,6 +229,11 @@ class LowLevelEngine:
             cj.initial_cost = j.initial_cost
             if j.sipp_table is not None:
                 cj.sipp_table = j.sipp_table
+            cj.result_path_id = j.result_path_id
+            if j.path_ids is not None:
+                ids = np.ascontiguousarray(np.asarray(j.path_ids, dtype=np.int32))
+                cj.path_ids = ids.ctypes.data_as(I32P)
+                keep.append(ids)
             if j.collision_intervals:
                 locs, counts, ivs = [], [], []
                 for x, y, a, b in j.collision_intervals:  # consecutive entries of one location form one list
@@ -281,6 +291,10 @@ class LowLevelEngine:
                                                    path_first.ctypes.data_as(I32P), xy.ctypes.data_as(I32P), out),
                     "mrp_ll_conflict_scan")
         return [{k: getattr(out[i], k) for k, _ in mrp_ll_conflict._fields_} for i in range(n)]
+
+    def path_store_reserve(self, n_slots: int) -> None:
+        """Allocate the device-resident path store (f2): slots 0..n_slots-1 are the caller's to hand out."""
+        self._check(self._lib.mrp_ll_path_store_reserve(self._h, n_slots), "mrp_ll_path_store_reserve")
 
     def sipp_table_create(self, map_id: int) -> int:
         h = ctypes.c_void_p()

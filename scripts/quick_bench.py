@@ -25,6 +25,7 @@ for rep in range(int(os.environ.get('MRP_REPS', '3'))):
     print("   host thread-seconds: build %.3f  ll_call %.3f (pack %.3f unpack %.3f kernel %.3f h2d %.3f d2h %.3f)  consume %.3f" % (
         st["build_seconds"], st["ll_call_seconds"], ls["pack_ms"] / 1e3, ls["unpack_ms"] / 1e3, ls["kernel_ms"] / 1e3,
         ls["h2d_ms"] / 1e3, ls["d2h_ms"] / 1e3, st["consume_seconds"]), flush=True)
+    print("   staged in pinned host memory: %.1f MB = %.0f bytes per search" % (ls["staged_bytes"] / 1e6, ls["staged_bytes"] / max(st["ll_searches"], 1)), flush=True)
     print("   resident workgroups: busy %.3f s, waiting %.3f s (sum over workgroups) -> busy fraction %.2f" % (
         ls["session_busy_ms"] / 1e3, ls["session_idle_ms"] / 1e3,
         ls["session_busy_ms"] / max(ls["session_busy_ms"] + ls["session_idle_ms"], 1e-9)), flush=True)

@@ -153,6 +153,7 @@ int mrp_ll_poll(mrp_ll_ctx*, int32_t, int32_t* done) {
 int mrp_ll_conflict_scan(mrp_ll_ctx*, int32_t, const int32_t*, const int32_t*, const int32_t*, mrp_ll_conflict*) {
   return MRP_LL_E_DEVICE;  // the scan kernel has no stand-in: the host drivers do not call it
 }
+int mrp_ll_path_store_reserve(mrp_ll_ctx*, int32_t) { return MRP_LL_E_DEVICE; }  // no store here: the drivers fall back to tables
 struct mrp_ll_sipp_table {};  // SIPP has no stand-in here: the prioritized-SIPP driver is covered by the GPU tests
 int mrp_ll_sipp_table_create(mrp_ll_ctx*, int32_t, mrp_ll_sipp_table** out) {
   *out = new mrp_ll_sipp_table();

@@ -521,3 +521,70 @@ def test_specialised_sessions_and_liveness(oracle_mod, bench_instances):
     finally:
         del os.environ["MRP_LL_IDLE_LIMIT_S"]
         eng.close()
+
+
+def test_device_path_store(oracle_mod, bench_instances):
+    """a search leaves its path in the engine's device-resident path store (result_path_id) and later
+    A*-epsilon jobs name their focal context by slot (path_ids) instead of shipping it.  The conflict tree of a 30-agent
+    instance is replayed that way — every low-level call of the oracle's run, contexts by slot — in batch mode and through
+    a session; results must equal the oracle's and those of the table form."""
+    from libmultirobotplanning_amd import ll
+    name = "map_32by32_obst204_agents30_ex1"
+    inst = bench_instances[name]
+    _, calls = oracle_mod.mapf_record(oracle_mod.ECBS, inst, w=1.3)
+    eng = ll.LowLevelEngine(device=0, n_tickets=1, slots=64)
+    try:
+        eng.path_store_reserve(4096)
+        mid = eng.upload_map(inst["dimx"], inst["dimy"], inst["obstacles"])
+        slot_of = {}          # path (as tuple) -> slot where some search left it
+        next_slot = [0]
+
+        def run(session):
+            slot_of.clear()
+            next_slot[0] = 0
+            for c in calls:
+                ids = []
+                ok = True
+                for a, p in enumerate(c["ctx_paths"]):
+                    if a == c["agent"] or not p:
+                        ids.append(-1)
+                    else:
+                        sid = slot_of.get(tuple(map(tuple, p)))
+                        ok = ok and sid is not None
+                        ids.append(-1 if sid is None else sid)
+                assert ok, "every context path was produced by an earlier search of this run"
+                out = next_slot[0]
+                next_slot[0] += 1
+                job = ll.LLJob(map_id=mid, algo=ll.ASTAR_EPS, start=inst["starts"][c["agent"]], goal=inst["goals"][c["agent"]],
+                               agent_idx=c["agent"], w=1.3, vertex_constraints=c["vertex_constraints"],
+                               edge_constraints=c["edge_constraints"], ctx_paths=c["ctx_paths"], path_ids=ids,
+                               result_path_id=out)
+                r = eng.search_batch([job])[0]
+                assert (r.success, r.expanded) == (c["success"], c["expanded"]), (session, c["agent"])
+                if r.success:
+                    assert (r.cost, r.fmin, [s[1:] for s in r.states]) == (c["cost"], c["fmin"], c["states"])
+                    slot_of[tuple(map(tuple, c["states"]))] = out
+
+        run(False)
+        st0 = eng.stats()["staged_bytes"]
+        eng.session_begin_algo(ll.ASTAR_EPS, 16)
+        try:
+            run(True)
+            st1 = eng.stats()["staged_bytes"]
+            # the same jobs with their tables shipped: far more bytes through pinned host memory
+            jobs = [ll.LLJob(map_id=mid, algo=ll.ASTAR_EPS, start=inst["starts"][c["agent"]], goal=inst["goals"][c["agent"]],
+                             agent_idx=c["agent"], w=1.3, vertex_constraints=c["vertex_constraints"],
+                             edge_constraints=c["edge_constraints"], ctx_paths=c["ctx_paths"]) for c in calls]
+            res = eng.search_batch(jobs)
+            st2 = eng.stats()["staged_bytes"]
+        finally:
+            eng.session_end()
+        for c, r in zip(calls, res):
+            assert (r.success, r.expanded, r.cost if r.success else 0) == (c["success"], c["expanded"], c["cost"] if c["success"] else 0)
+        assert (st2 - st1) > 4 * (st1 - st0) > 0
+        # a slot that does not exist is rejected on the host, loudly
+        bad = eng.search_batch([ll.LLJob(map_id=mid, algo=ll.ASTAR_EPS, start=inst["starts"][0], goal=inst["goals"][0],
+                                         w=1.3, result_path_id=999999)])
+        assert bad[0].status == ll.BAD_JOB
+    finally:
+        eng.close()
