@@ -902,12 +902,27 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
         if (idL < P.path_store_slots) lenL = P.path_store[(size_t)idL * P.path_store_stride];
         if (lenL > P.path_store_stride - 1) lenL = P.path_store_stride - 1;
         const uint32_t nHere = nCtx - a0 < 64 ? nCtx - a0 : 64;
-        for (uint32_t q = 0; q < nHere; ++q) {
-          const uint32_t id = __builtin_amdgcn_readlane(idL, q);
-          const uint32_t len = __builtin_amdgcn_readlane(lenL, q);
-          if (id >= P.path_store_slots || len == 0) continue;  // empty path, or the searching agent itself
-          const uint16_t* slot = P.path_store + (size_t)id * P.path_store_stride + 1;
-          for (uint32_t t = lane; t < c.tPad; t += 64) dst[t * c.nAgentsPad + a0 + q] = slot[t < len ? t : len - 1];
+        // the store is uncached memory (every load goes to HBM): eight agents' loads are in flight before the first store
+        for (uint32_t t0 = 0; t0 < c.tPad; t0 += 64) {
+          const uint32_t t = t0 + lane;
+          for (uint32_t q0 = 0; q0 < nHere; q0 += 8) {
+            uint32_t v[8];
+            bool has[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+              uint32_t id = kNoStoreSlot, len = 0;
+              if (q0 + u < nHere) {
+                id = __builtin_amdgcn_readlane(idL, q0 + u);
+                len = __builtin_amdgcn_readlane(lenL, q0 + u);
+              }
+              has[u] = id < P.path_store_slots && len != 0 && t < c.tPad;  // not: empty path / the searching agent itself
+              v[u] = kEmptyCell;
+              if (has[u]) v[u] = P.path_store[(size_t)id * P.path_store_stride + 1 + (t < len ? t : len - 1)];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u)
+              if (has[u]) dst[t * c.nAgentsPad + a0 + q0 + u] = (uint16_t)v[u];
+          }
         }
       }
       c.paths = dst;
@@ -1015,7 +1030,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
 // isCommandValid :129-142: arrival t = max(si.start, g + 1), cost t - g; swaps are not checked) and isSolution
 // sipp.hpp:185-189 (goal cell AND the interval ends at INT_MAX).  Edge costs vary, so the decrease-key branch
 // a_star.hpp:139-145 (`openSet.increase(handle)` == sift-up from the handle's position) is live here.
-// Job tables (packed by the host, copied into the arena slot): cellIdx[cells] (0 = single default interval
+// Job tables (packed by the host, copied into the arena slot): cellIdx[cells] (halfwords; 0 = single default interval
 // [0, INT_MAX], k+1 = special cell k), specFirst[K+1], ivals[total][2].  State id = cell for default cells,
 // cells + specFirst[k] + i for interval i of special cell k.  HBM tier only.
 constexpr int32_t kIntMax = 0x7FFFFFFF;
@@ -1048,7 +1063,8 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
     res.status = ST_NO_SOLUTION;
     return;
   }
-  const uint32_t tabWords = cells + K + 1 + 2 * totalIv;
+  const uint32_t cw = (cells + 1) / 2;  // cellIdx is a halfword per cell (cells <= 65025, so K + 1 fits)
+  const uint32_t tabWords = cw + K + 1 + 2 * totalIv;
   const uint32_t nStates = cells + totalIv;
   if (tabWords * 4 > P.arena_paths_bytes || nStates > P.arena_rows * P.arena_row_words) {
     res.status = ST_CAP_NODES;
@@ -1082,9 +1098,9 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
     for (uint32_t i = lane; i < (nStates + 3) / 4; i += 64) st4[i] = z;
   }
   __syncthreads();
-  const uint32_t* cellIdx = tab;
-  const uint32_t* specFirst = tab + cells;
-  const int32_t* ivals = (const int32_t*)(tab + cells + K + 1);
+  const uint16_t* cellIdx = (const uint16_t*)tab;
+  const uint32_t* specFirst = tab + cw;
+  const int32_t* ivals = (const int32_t*)(tab + cw + K + 1);
 
   // start node
   uint32_t nNodes = 1, nOpen = 1;

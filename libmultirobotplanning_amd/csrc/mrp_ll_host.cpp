@@ -375,6 +375,7 @@ void safeFromCollisions(const int32_t* civ, int cnt, std::vector<SippScratch::Iv
 struct mrp_ll_sipp_table {
   int32_t mapId = -1, dimx = 0, dimy = 0;
   std::vector<int32_t> cellIdx;                       // cell -> special index + 1
+  std::vector<uint16_t> cellIdx16;                    // the same as the device reads it
   struct Spec {
     std::vector<int32_t> collisions;                  // [n][2] in the order they were added
     std::vector<SippScratch::Iv> safe;
@@ -396,10 +397,12 @@ bool packSippFromTable(const mrp_ll_job& j, const MapRec& mp, ConsSink& cs, DevJ
   d.algo = MRP_LL_SIPP;
   d.max_expansions = j.max_expansions;
   d.vc_off = static_cast<uint32_t>(cs.size());
-  uint32_t* w = cs.grow(static_cast<size_t>(cells) + K + 1 + 2 * static_cast<size_t>(T.totalSafe));
+  const size_t cw = (static_cast<size_t>(cells) + 1) / 2;  // cellIdx travels as halfwords
+  uint32_t* w = cs.grow(cw + K + 1 + 2 * static_cast<size_t>(T.totalSafe));
   if (!w) return false;
-  std::memcpy(w, T.cellIdx.data(), sizeof(uint32_t) * cells);
-  w += cells;
+  w[cw - 1] = 0;
+  std::memcpy(w, T.cellIdx16.data(), sizeof(uint16_t) * cells);
+  w += cw;
   uint32_t run = 0;
   for (uint32_t k = 0; k < K; ++k) {
     w[k] = run;
@@ -483,10 +486,13 @@ bool packSipp(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, ConsSink& 
   d.max_expansions = j.max_expansions;
   d.vc_off = static_cast<uint32_t>(cs.size());
   {  // cellIdx[cells], specFirst[K + 1], ivals[total][2]
-    uint32_t* w = cs.grow(static_cast<size_t>(cells) + K + 1 + 2 * static_cast<size_t>(total));
+    const size_t cw = (static_cast<size_t>(cells) + 1) / 2;  // cellIdx travels as halfwords
+    uint32_t* w = cs.grow(cw + K + 1 + 2 * static_cast<size_t>(total));
     if (!w) return false;
-    std::memcpy(w, cellIdx.data(), sizeof(uint32_t) * cells);
-    w += cells;
+    w[cw - 1] = 0;
+    uint16_t* w16 = reinterpret_cast<uint16_t*>(w);
+    for (int c = 0; c < cells; ++c) w16[c] = static_cast<uint16_t>(cellIdx[c]);
+    w += cw;
     uint32_t run = 0;
     for (uint32_t k = 0; k < K; ++k) {
       w[k] = run;
@@ -1533,6 +1539,7 @@ int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t mapId, mrp_ll_sipp_table**
   t->dimx = ctx->maps[mapId].dimx;
   t->dimy = ctx->maps[mapId].dimy;
   t->cellIdx.assign(static_cast<size_t>(t->dimx) * t->dimy, 0);
+  t->cellIdx16.assign(static_cast<size_t>(t->dimx) * t->dimy, 0);
   *out = t;
   return MRP_LL_SUCCESS;
 }
@@ -1544,6 +1551,7 @@ int mrp_ll_sipp_table_add(mrp_ll_sipp_table* t, int32_t x, int32_t y, int32_t st
   if (!t->cellIdx[cell]) {
     t->spec.emplace_back();
     t->cellIdx[cell] = static_cast<int32_t>(t->spec.size());
+    t->cellIdx16[cell] = static_cast<uint16_t>(t->spec.size());
   }
   mrp_ll_sipp_table::Spec& sp = t->spec[t->cellIdx[cell] - 1];
   sp.collisions.push_back(start);
