@@ -1069,9 +1069,9 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
     }
   } tableGuard{st};
   // at most one wavefront per instance, and about two per SIMD over all workers: the SIPP kernel waits on HBM for most
-  // of an expansion, more resident wavefronts only slow each other down (measured 64 / 128 / 256 per worker: 0.59 /
-  // 0.56 / 0.70 s for 4096 instances x 50 agents)
-  int32_t wgs = static_cast<int32_t>(std::min<size_t>(std::min<size_t>(std::max<size_t>(n, 16), slots), 128));
+  // of an expansion, more resident wavefronts only slow each other down (round 2, 2048 instances x 100 agents, 64 / 96 /
+  // 128 / 192 / 256 per worker: 0.43 / 0.38 / 0.42 / 0.51 / 0.61 s)
+  int32_t wgs = static_cast<int32_t>(std::min<size_t>(std::min<size_t>(std::max<size_t>(n, 16), slots), 96));
   if (const char* e = std::getenv("MRP_HL_SIPP_WGS")) wgs = std::max(1, std::atoi(e));          // tuning knob
   if (mrp_ll_session_begin_sipp(ctx, wgs) != MRP_LL_SUCCESS) {
     out.err = std::string("mrp_ll_session_begin_sipp: ") + mrp_ll_last_error(ctx);

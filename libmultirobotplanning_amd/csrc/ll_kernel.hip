@@ -892,6 +892,13 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
         uint32_t* d32 = (uint32_t*)dst;
         for (uint32_t i = lane; i < pathBytes / 4; i += 64) d32[i] = 0xFFFFFFFFu;  // kEmptyCell everywhere
       }
+      // The slots named here were written by OTHER workgroups of this same resident launch (possibly on another XCD,
+      // whose L2 is not coherent with ours), each before its job's completion was published (processJob writes them in
+      // front of residentLoop's system-scope release).  One agent-scope acquire drops whatever stale copies this CU's L1 /
+      // this XCD's L2 may hold from an earlier use of a recycled slot; after it plain, cached, coalesced loads are
+      // correct (MI355X_MICROARCH.md "Valid forms": poll -> ONE acquire -> s_waitcnt -> barrier -> plain loads).
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       const uint32_t* ids = P.cons + J.path_off;
       const uint32_t nCtx = J.n_ctx;
@@ -902,7 +909,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
         if (idL < P.path_store_slots) lenL = P.path_store[(size_t)idL * P.path_store_stride];
         if (lenL > P.path_store_stride - 1) lenL = P.path_store_stride - 1;
         const uint32_t nHere = nCtx - a0 < 64 ? nCtx - a0 : 64;
-        // the store is uncached memory (every load goes to HBM): eight agents' loads are in flight before the first store
+        // eight agents' loads are in flight before the first store
         for (uint32_t t0 = 0; t0 < c.tPad; t0 += 64) {
           const uint32_t t = t0 + lane;
           for (uint32_t q0 = 0; q0 < nHere; q0 += 8) {

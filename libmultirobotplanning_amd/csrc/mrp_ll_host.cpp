@@ -1517,11 +1517,15 @@ int mrp_ll_path_store_reserve(mrp_ll_ctx* ctx, int32_t nSlots) {
   // [len][cells...]: one halfword in front of up to max_horizon states, rounded up to 16 bytes
   ctx->pathStoreStride = (static_cast<uint32_t>(ctx->opt.max_horizon) + 1u + 7u) & ~7u;
   const size_t bytes = static_cast<size_t>(nSlots) * ctx->pathStoreStride * sizeof(uint16_t);
-  // Uncached device memory: a slot is written by one workgroup of a resident kernel and read by workgroups on other CUs /
-  // XCDs of the SAME launch, whose L1 / per-XCD L2 are never invalidated in between; ordering is carried by the host
-  // (a reader's job is published only after the writer's completion was seen).
+  // A slot is written by one workgroup of a resident kernel and read by workgroups on other CUs / XCDs of the SAME launch.
+  // Ordering is carried by the host (a reader's job is published only after the writer's completion was seen: the
+  // writer's stores sit in front of a system-scope release); the reader drops stale cached copies with one agent-scope
+  // acquire per job (ll_kernel.hip runJob), so ordinary cached device memory is enough — and the paths of a conflict-
+  // tree node, read again by job after job, are served from L2.  MRP_LL_STORE_UNCACHED=1: uncached allocation instead
+  // (measured: agents100 steps 23 % longer — every table build then reads HBM).
   void* p = nullptr;
-  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+  hipError_t e = std::getenv("MRP_LL_STORE_UNCACHED") ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached)
+                                                      : hipMalloc(&p, bytes);
   if (e != hipSuccess) {
     ctx->err = std::string("mrp_ll_path_store_reserve: ") + hipGetErrorString(e);
     return e == hipErrorOutOfMemory ? MRP_LL_E_NOMEM : MRP_LL_E_DEVICE;

@@ -8,8 +8,8 @@ from libmultirobotplanning_amd import hl
 s = hl.BatchSolver(device=0, n_threads=16, slots=512)
 out = {}
 # ---- config 3: CBS on 8x8_obst12-shaped synthetic instances, agents 4..10, cap 1e5 LL expansions per instance ----
-for agents, n in ((4, 4096), (6, 4096), (8, 2048)):
-    insts = [hl.generate_instance(800000 + 1000 * agents + k, 8, 8, 12, agents) for k in range(n)]
+for agents, n in ((4, 4096), (6, 4096), (8, 2048), (10, 1024)):
+    insts = list(hl.generate_instances(800000 + 1000 * agents, n, 8, 8, 12, agents))
     s.solve(insts[:256], algo=hl.CBS, max_ll_expansions=100000, want_paths=False)
     res, st = s.solve(insts, algo=hl.CBS, max_ll_expansions=100000, want_paths=False)
     m = min(n, 256)
