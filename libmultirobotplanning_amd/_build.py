@@ -48,6 +48,19 @@ def build_trace(verbose=False):
     return out
 
 
+def build_variant(name, defines, verbose=False):
+    """A/B build of libmrp_ll.so with extra -D flags (e.g. build_variant("regparams", ["-DMRP_LL_PARAMS_IN_REGS"]));
+    use it under the host drivers with LD_PRELOAD=<returned path>."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    spec = TARGETS["libmrp_ll.so"]
+    out = os.path.join(LIBDIR, "libmrp_ll_%s.so" % name)
+    cmd = [HIPCC] + COMMON + list(defines) + ["-o", out] + [os.path.join(CSRC, s) for s in spec["srcs"]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return out
+
+
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     built = []

@@ -909,7 +909,30 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
         if (idL < P.path_store_slots) lenL = P.path_store[(size_t)idL * P.path_store_stride];
         if (lenL > P.path_store_stride - 1) lenL = P.path_store_stride - 1;
         const uint32_t nHere = nCtx - a0 < 64 ? nCtx - a0 : 64;
-        // eight agents' loads are in flight before the first store
+        if (!inLds) {
+          // Table in the arena (global memory): one lane per AGENT, so that a row of the table is one coalesced store
+          // (a lane per time step would scatter 2-byte stores 2 * n_agents_pad bytes apart — measured on agents100: the
+          // longest conflict-tree chain of a batch a third slower).  The reads gather one cell per slot and stay in L2
+          // from row to row; eight rows are in flight at a time.
+          const uint32_t lenA = lenL;
+          const uint16_t* slotA = P.path_store + (size_t)(idL < P.path_store_slots ? idL : 0) * P.path_store_stride + 1;
+          const bool hasA = idL < P.path_store_slots && lenA != 0;
+          for (uint32_t t0 = 0; t0 < c.tPad; t0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+              const uint32_t t = t0 + u;
+              v[u] = kEmptyCell;
+              if (hasA && t < c.tPad) v[u] = slotA[t < lenA ? t : lenA - 1];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u)
+              if (hasA && t0 + u < c.tPad) dst[(t0 + u) * c.nAgentsPad + a0 + lane] = (uint16_t)v[u];
+          }
+          continue;
+        }
+        // table in LDS: a lane per time step (one coalesced read per agent); eight agents' loads are in flight before
+        // the first store
         for (uint32_t t0 = 0; t0 < c.tPad; t0 += 64) {
           const uint32_t t = t0 + lane;
           for (uint32_t q0 = 0; q0 < nHere; q0 += 8) {
@@ -1456,6 +1479,25 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
 }
 
 // Batch mode.  One workgroup == one wavefront; pulls jobs from the batch's queue (exit: queue exhausted).
+// The launch parameters (45 dwords) live in LDS, not in SGPRs: they are needed at the start and at the end of a job, and
+// keeping them alive across the search loop is what made the register allocator spill (ECBS resident kernel: 229 SGPR
+// spill slots with them in registers, 100 with them in LDS).  -DMRP_LL_PARAMS_IN_REGS builds the other form for A/B runs.
+#ifdef MRP_LL_PARAMS_IN_REGS
+#define MRP_LL_STAGE_PARAMS(P, Parg) const LaunchParams& P = Parg
+#else
+#define MRP_LL_STAGE_PARAMS(P, Parg) \
+  __shared__ LaunchParams P;         \
+  stageParams(P, Parg)
+#endif
+// One coalesced copy of the kernel arguments into LDS (read back with ds_read where they are needed).
+DEVI void stageParams(LaunchParams& dst, const LaunchParams& src) {
+  const uint32_t lane = threadIdx.x;
+  constexpr uint32_t n = sizeof(LaunchParams) / 4;
+  static_assert(sizeof(LaunchParams) % 4 == 0 && n <= 64, "LaunchParams is staged by one wavefront instruction");
+  if (lane < n) ((uint32_t*)&dst)[lane] = ((const uint32_t*)&src)[lane];
+  __syncthreads();
+}
+
 template <int KIND>
 DEVI void batchLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevResult& resS) {
   const uint32_t lane = threadIdx.x;
@@ -1474,22 +1516,25 @@ DEVI void batchLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevResul
   DBG(P, 4, 1);
 }
 
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchParams P) {  // mixed batches
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchParams Parg) {  // mixed batches
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
+  MRP_LL_STAGE_PARAMS(P, Parg);
   batchLoop<0>(P, smem, jobS, resS);
 }
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_search_kernel(LaunchParams P) {  // A*-epsilon jobs only
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_search_kernel(LaunchParams Parg) {  // A*-epsilon jobs only
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
+  MRP_LL_STAGE_PARAMS(P, Parg);
   batchLoop<1>(P, smem, jobS, resS);
 }
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_search_kernel(LaunchParams P) {  // A* jobs only
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_search_kernel(LaunchParams Parg) {  // A* jobs only
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
+  MRP_LL_STAGE_PARAMS(P, Parg);
   batchLoop<2>(P, smem, jobS, resS);
 }
 
@@ -1522,9 +1567,10 @@ DEVI void processSippJob(const LaunchParams& P, const DevJob* jobSrc, DevResult*
 
 // SIPP batches (MRP_LL_SIPP jobs only) run in their own kernels so that the CBS/ECBS kernels' register allocation is
 // not widened by a path they never take.  Same queue discipline as mrp_ll_search_kernel.
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams P) {
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams Parg) {
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
+  MRP_LL_STAGE_PARAMS(P, Parg);
   const uint32_t lane = threadIdx.x;
   uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
   for (;;) {
@@ -1628,29 +1674,33 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
   atomicAdd(P.sess_ticks + 2, (lane == 0 && busyTicks != 0) ? 1ull : 0ull);  // workgroups that ran at least one job
 }
 
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(LaunchParams P) {  // mixed sessions
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(LaunchParams Parg) {  // mixed sessions
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
+  MRP_LL_STAGE_PARAMS(P, Parg);
   residentLoop<false, 0>(P, smem, jobS, resS);
 }
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_persistent_kernel(LaunchParams P) {  // A*-epsilon only
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_persistent_kernel(LaunchParams Parg) {  // A*-epsilon only
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
+  MRP_LL_STAGE_PARAMS(P, Parg);
   residentLoop<false, 1>(P, smem, jobS, resS);
 }
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_persistent_kernel(LaunchParams P) {  // A* only
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_persistent_kernel(LaunchParams Parg) {  // A* only
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
+  MRP_LL_STAGE_PARAMS(P, Parg);
   residentLoop<false, 2>(P, smem, jobS, resS);
 }
 
 // The same resident loop for SIPP sessions (jobs of algo MRP_LL_SIPP only; no LDS tier).
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_persistent_kernel(LaunchParams P) {
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_persistent_kernel(LaunchParams Parg) {
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
+  MRP_LL_STAGE_PARAMS(P, Parg);
   residentLoop<true, 0>(P, nullptr, jobS, resS);
 }
 
