@@ -49,7 +49,7 @@ def build_trace(verbose=False):
 
 
 def build_variant(name, defines, verbose=False):
-    """A/B build of libmrp_ll.so with extra -D flags (e.g. build_variant("regparams", ["-DMRP_LL_PARAMS_IN_REGS"]));
+    """A/B build of libmrp_ll.so with extra -D flags (e.g. build_variant("ldsparams", ["-DMRP_LL_PARAMS_IN_LDS"]));
     use it under the host drivers with LD_PRELOAD=<returned path>."""
     os.makedirs(LIBDIR, exist_ok=True)
     spec = TARGETS["libmrp_ll.so"]

@@ -1479,10 +1479,12 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
 }
 
 // Batch mode.  One workgroup == one wavefront; pulls jobs from the batch's queue (exit: queue exhausted).
-// The launch parameters (45 dwords) live in LDS, not in SGPRs: they are needed at the start and at the end of a job, and
-// keeping them alive across the search loop is what made the register allocator spill (ECBS resident kernel: 229 SGPR
-// spill slots with them in registers, 100 with them in LDS).  -DMRP_LL_PARAMS_IN_REGS builds the other form for A/B runs.
-#ifdef MRP_LL_PARAMS_IN_REGS
+// The launch parameters (45 dwords) stay in SGPRs.  -DMRP_LL_PARAMS_IN_LDS keeps them in LDS instead: they are needed
+// only at the start and at the end of a job, and with them out of the way the ECBS resident kernel has 100 SGPR spill
+// slots instead of 229 — but it then keeps wave-uniform values in VGPRs (135 instead of 113) and was 5-6 % SLOWER in an
+// A/B on one box (busy workgroup time 787 s vs 736 s per 65 536 agents10 instances; scripts/r2m.sh): a spilled SGPR is
+// one v_readlane when it is needed, a uniform held in a VGPR costs a v_readfirstlane or a VALU compare at every use.
+#ifndef MRP_LL_PARAMS_IN_LDS
 #define MRP_LL_STAGE_PARAMS(P, Parg) const LaunchParams& P = Parg
 #else
 #define MRP_LL_STAGE_PARAMS(P, Parg) \

@@ -2,8 +2,8 @@ R=$GRAFT_REPO_ROOT
 timeout -k 10 400 python -m pytest tests/test_ll_parity_gpu.py tests/test_hl_parity_gpu.py -m gpu -x -q > gpurun_out/r2m_pytest.log 2>&1 || { tail -20 gpurun_out/r2m_pytest.log; exit 1; }
 tail -2 gpurun_out/r2m_pytest.log
 export MRP_REPS=3
-for v in lds regs lds regs; do
-  if [ $v = regs ]; then export LD_PRELOAD=$R/libmultirobotplanning_amd/lib/libmrp_ll_regparams.so; else unset LD_PRELOAD; fi
+for v in regs lds regs lds; do
+  if [ $v = lds ]; then export LD_PRELOAD=$R/libmultirobotplanning_amd/lib/libmrp_ll_ldsparams.so; else unset LD_PRELOAD; fi
   timeout -k 10 200 python scripts/quick_bench.py 65536 10 16 512 0 > gpurun_out/r2m_$v.log 2>&1 || { tail -5 gpurun_out/r2m_$v.log; exit 1; }
   echo "== launch params in $v"; grep "^rep\|resident" gpurun_out/r2m_$v.log | tail -4
 done
