@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=65536, help="instances per GPU per step (headline workload)")
+    ap.add_argument("--instances", type=int, default=131072, help="instances per GPU per step (headline workload)")
     ap.add_argument("--agents", type=int, default=10)
     ap.add_argument("--threads", type=int, default=0, help="host worker threads per GPU (0 = auto)")
     ap.add_argument("--slots", type=int, default=0)
@@ -293,7 +293,7 @@ def main():
             # batches large enough that the one-wavefront chains of the few pathological instances (the capped ones run
             # for seconds) do not leave the chip idle for most of the step
             "agents50": (50, 16384, 400000, 192),
-            "agents100": (100, 4096, 2000000, 24),
+            "agents100": (100, 4096, 3000000, 24),
         }
         for name in [x for x in legs.split(",") if x and x != "none"]:
             if name in leg_specs:

@@ -812,8 +812,22 @@ DEVI int runSearch(Mem<T>& m, SState& s, const Ctx& c, typename Mem<T>::P32 obst
         ((typename Mem<T>::PNode4)m.nodes)[nid] = nn;
       }
       // mark (t1, cell) discovered: stands for stateToHeap / closedSet membership (a_star_epsilon.hpp:224-227); the
-      // successors of one expansion are distinct cells, so marking them together changes nothing
-      __hip_atomic_fetch_or(m.bits + bitIdx, 1u << (ncell & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // successors of one expansion are distinct cells, so marking them together changes nothing.  LDS: one ds_or.
+      if constexpr (T::AS == 3)
+        __hip_atomic_fetch_or(m.bits + bitIdx, 1u << (ncell & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if constexpr (T::AS != 3) {
+      // HBM tier: a plain store of the merged word instead of a memory-side atomic per successor (successors that share
+      // a bitmap word all store the same merged word)
+      const uint32_t myBit = mine ? 1u << (ncell & 31) : 0u;
+      uint32_t merged = word;
+#pragma unroll
+      for (uint32_t k = 0; k < 5; ++k) {
+        const uint32_t oi = __builtin_amdgcn_readlane(bitIdx, k);
+        const uint32_t ob = __builtin_amdgcn_readlane(myBit, k);
+        merged |= oi == bitIdx ? ob : 0u;
+      }
+      if (mine) m.bits[bitIdx] = merged;
     }
     s.nNodes = nBase + (uint32_t)__builtin_popcount(mask);
     E e[5];
