@@ -52,6 +52,18 @@ struct DevJob {            // 96 bytes, 16-byte aligned
 };
 constexpr uint32_t kNoStoreSlot = 0xFFFFFFFFu;
 constexpr uint32_t kCtxById = 1u;
+// MRP_LL_SIPP with a device-resident table (mrp_ll_sipp_table_* in a session): ctx_flags bit 1.  The table lives in
+// device memory at the 64-bit address (n_agents_pad | path_off << 32), in a fixed-capacity layout the search reads directly:
+//   cnt[cells] bytes (0 = the default single interval, n + 1 = n safe intervals), padded to 256 bytes,
+//   iv[cells][kSippCap][2] int32 {start, end},
+//   status[cells][kSippCap] words  epoch << 24 | closed << 23 | node + 1   (a word of another epoch reads as "unseen").
+// cons[vc_off] holds only the DELTA since the table's previous job: ec_off & 0x7FFFFFFF records (bit 31: zero cnt and
+// status first), as  hdr[nRec]  (cell | count << 16; padded to a multiple of 4 words)  then  nRec x kSippCap x {start, end}.
+// n_ctx = the job's epoch (1..255).  One job per table in flight.
+constexpr uint32_t kSippResident = 2u;
+constexpr uint32_t kSippCap = 8;                                   // safe intervals per cell the resident layout holds
+constexpr uint32_t kSippEpochShift = 24, kSippEpochMax = 255;
+constexpr uint32_t kSippStClosed = 1u << 23;
 
 struct DevResult {         // 64 bytes
   int32_t status;

@@ -1078,8 +1078,50 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
 // [0, INT_MAX], k+1 = special cell k), specFirst[K+1], ivals[total][2].  State id = cell for default cells,
 // cells + specFirst[k] + i for interval i of special cell k.  HBM tier only.
 constexpr int32_t kIntMax = 0x7FFFFFFF;
-constexpr uint32_t kStClosed = 0x80000000u;
 
+// Where runSipp finds a cell's safe intervals and a state's open/closed status.
+//   RES = false: the job's own compact table, copied from the host into the arena (layout above); status words
+//                (0 unseen, node + 1 in open, bit 31 closed) in the arena too, zeroed per job.
+//   RES = true:  the device-resident table of an mrp_ll_sipp_table (ll_device.h kSippResident): cnt byte per cell,
+//                kSippCap interval slots per cell, status words tagged with the job's epoch so nothing is zeroed per job.
+template <bool RES>
+struct SippView {
+  static constexpr uint32_t kClosed = RES ? kSippStClosed : 0x80000000u;
+  const uint16_t* cellIdx;
+  const uint32_t* specFirst;
+  const uint8_t* cnt;
+  const int32_t* ivals;
+  uint32_t* status;
+  uint32_t cells, epochBits;
+  // nk != 0: the cell has its own interval list, `n` entries from ivals[2 * first]; nk == 0: the default [0, INT_MAX]
+  DEVI void lookup(uint32_t cell, uint32_t& nk, uint32_t& first, uint32_t& n) const {
+    if constexpr (RES) {
+      nk = cnt[cell];
+      first = cell * kSippCap;
+      n = nk ? nk - 1 : 1;
+    } else {
+      nk = cellIdx[cell];
+      first = 0;
+      n = 1;
+      if (nk) {
+        first = specFirst[nk - 1];
+        n = specFirst[nk] - first;
+      }
+    }
+  }
+  DEVI uint32_t sid(uint32_t cell, uint32_t nk, uint32_t first, uint32_t i) const {
+    if constexpr (RES) return cell * kSippCap + i;
+    return nk ? cells + first + i : cell;
+  }
+  DEVI uint32_t getSt(uint32_t id) const {
+    uint32_t v = status[id];
+    if constexpr (RES) v = (v >> kSippEpochShift) == (epochBits >> kSippEpochShift) ? (v & ((1u << kSippEpochShift) - 1u)) : 0u;
+    return v;
+  }
+  DEVI void putSt(uint32_t id, uint32_t v) const { status[id] = RES ? (v | epochBits) : v; }
+};
+
+template <bool RES>
 DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, DevResult& res, uint16_t* outPath) {
   const uint32_t lane = threadIdx.x;
   const uint32_t dimx = J.dimx, dimy = J.dimy, cells = dimx * dimy;
@@ -1103,10 +1145,61 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
   }
   uint8_t* scratch = arenaSlot + P.arena_scratch_off;
   uint32_t* tab = (uint32_t*)((uint32_t*)(scratch + (size_t)P.out_stride * 2) + kConsLocalWords);  // path-table area
-  if (J.t_pad == 0xFFFFFFFFu) {  // no safe interval contains the start time: SIPP::search returns false (sipp.hpp:98-100)
-    res.status = ST_NO_SOLUTION;
-    return;
-  }
+  SippView<RES> tv;
+  tv.cells = cells;
+  tv.epochBits = 0;
+  if constexpr (RES) {
+    uint8_t* rt = (uint8_t*)((uint64_t)J.n_agents_pad | ((uint64_t)J.path_off << 32));
+    const uint32_t cntBytes = (cells + 255u) & ~255u;
+    uint8_t* cnt8 = rt;
+    u32x4* iv4 = (u32x4*)(rt + cntBytes);
+    tv.cnt = cnt8;
+    tv.ivals = (const int32_t*)iv4;
+    tv.status = (uint32_t*)(rt + cntBytes + (size_t)cells * kSippCap * 8);
+    tv.epochBits = J.n_ctx << kSippEpochShift;
+    tv.cellIdx = nullptr;
+    tv.specFirst = nullptr;
+    // the table was last written by another workgroup, possibly on another XCD (its results were released at system
+    // scope before the host saw them and packed this job)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const uint32_t nRec = J.ec_off & 0x7FFFFFFFu;
+    if (J.ec_off >> 31) {  // first job of the table (or its epochs are used up): no cell has a list, no state is seen
+      u32x4 z;
+      z.x = z.y = z.z = z.w = 0;
+      u32x4* c4 = (u32x4*)cnt8;
+      for (uint32_t i = lane; i < cntBytes / 16; i += 64) c4[i] = z;
+      u32x4* s4 = (u32x4*)tv.status;
+      for (uint32_t i = lane; i < cells * (kSippCap / 4); i += 64) s4[i] = z;
+      __syncthreads();
+    }
+    // the cells whose lists changed since the table's previous job, out of pinned host memory: lane u copies 16 bytes
+    // of record u / 4, four rounds in flight (one PCIe round trip per 64 records)
+    const uint32_t* hdr = P.cons + J.vc_off;
+    const u32x4* recs = (const u32x4*)(hdr + ((nRec + 3u) & ~3u));
+    const uint32_t nUnits = nRec * (kSippCap / 2);
+    for (uint32_t u0 = 0; u0 < nUnits; u0 += 256) {
+      uint32_t h[4];
+      u32x4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t u = u0 + q * 64 + lane;
+        if (u < nUnits) {
+          h[q] = __builtin_nontemporal_load(hdr + (u >> 2));
+          v[q] = __builtin_nontemporal_load(recs + u);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t u = u0 + q * 64 + lane;
+        if (u < nUnits) {
+          const uint32_t cell = h[q] & 0xFFFFu;
+          iv4[cell * (kSippCap / 2) + (u & 3u)] = v[q];
+          if ((u & 3u) == 0) cnt8[cell] = (uint8_t)((h[q] >> 16) + 1u);
+        }
+      }
+    }
+    __syncthreads();
+  } else {
   const uint32_t cw = (cells + 1) / 2;  // cellIdx is a halfword per cell (cells <= 65025, so K + 1 fits)
   const uint32_t tabWords = cw + K + 1 + 2 * totalIv;
   const uint32_t nStates = cells + totalIv;
@@ -1142,9 +1235,17 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
     for (uint32_t i = lane; i < (nStates + 3) / 4; i += 64) st4[i] = z;
   }
   __syncthreads();
-  const uint16_t* cellIdx = (const uint16_t*)tab;
-  const uint32_t* specFirst = tab + cw;
-  const int32_t* ivals = (const int32_t*)(tab + cw + K + 1);
+  tv.cellIdx = (const uint16_t*)tab;
+  tv.specFirst = tab + cw;
+  tv.ivals = (const int32_t*)(tab + cw + K + 1);
+  tv.status = (uint32_t*)g.bits;
+  tv.cnt = nullptr;
+  }
+  const int32_t* ivals = tv.ivals;
+  if (J.t_pad == 0xFFFFFFFFu) {  // no safe interval contains the start time: SIPP::search returns false (sipp.hpp:98-100)
+    res.status = ST_NO_SOLUTION; // (after the table update: a resident table must not miss this job's delta)
+    return;
+  }
 
   // start node
   uint32_t nNodes = 1, nOpen = 1;
@@ -1163,9 +1264,9 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
     n0.w = 0;
     gNodes[0] = n0;
     g.open[0] = T::pack(0, h0, startTime, 0);
-    const uint32_t k = rfl(cellIdx[sc]);
-    const uint32_t sid = k ? cells + rfl(specFirst[k - 1]) + si : sc;
-    g.bits[sid] = 1;
+    uint32_t k, f0, n0c;
+    tv.lookup(sc, k, f0, n0c);
+    tv.putSt(tv.sid(sc, rfl(k), rfl(f0), si), 1);
   }
   for (;;) {
     if (nOpen == 0) {
@@ -1179,14 +1280,13 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
     const uint32_t cell = cw & 0xFFFF, iv = cw >> 16;
     const uint32_t gcur = rfl(nd.z);
     const uint32_t cx = cell % dimx, cy = cell / dimx;
-    const uint32_t ck = rfl(cellIdx[cell]);
+    uint32_t ck, f0, nCur;
+    tv.lookup(cell, ck, f0, nCur);
+    ck = rfl(ck);
+    f0 = rfl(f0);
     int32_t endT = kIntMax;
-    uint32_t curSid = cell;
-    if (ck) {
-      const uint32_t f0 = rfl(specFirst[ck - 1]);
-      endT = rfli(ivals[2 * (f0 + iv) + 1]);
-      curSid = cells + f0 + iv;
-    }
+    if (ck) endT = rfli(ivals[2 * (f0 + iv) + 1]);
+    const uint32_t curSid = tv.sid(cell, ck, f0, iv);
     expansions += 1;
     if (maxExp >= 0 && expansions > maxExp) {
       res.status = ST_CAP_EXP;
@@ -1214,7 +1314,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
       break;
     }
     heapPop<T, 0, true>(g, g.open, nOpen);
-    g.bits[curSid] = kStClosed;
+    tv.putSt(curSid, SippView<RES>::kClosed);
     const uint32_t startT = gcur + 1;
     if (startT > kGMask) {
       res.status = ST_CAP_HORIZON;
@@ -1231,17 +1331,13 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
       const uint32_t nxL = cx + (lane == 3) - (lane == 2), nyL = cy + (lane == 0) - (lane == 1);
       const bool inbL = lane < 4 && nxL < dimx && nyL < dimy;
       const uint32_t ncL = inbL ? nyL * dimx + nxL : 0;
-      uint32_t obstW = 0xFFFFFFFFu, nkL = 0;
+      uint32_t obstW = 0xFFFFFFFFu, nkL = 0, firstL = 0, cntL = 0;
       if (inbL) {
         obstW = obst[ncL >> 5];
-        nkL = cellIdx[ncL];
+        tv.lookup(ncL, nkL, firstL, cntL);
       }
       const bool validL = inbL && !((obstW >> (ncL & 31)) & 1u);
-      uint32_t firstL = 0, cntL = validL ? 1u : 0u;
-      if (validL && nkL) {
-        firstL = specFirst[nkL - 1];
-        cntL = specFirst[nkL] - firstL;
-      }
+      if (!validL) cntL = 0;
       const uint32_t hL = (nxL > gx ? nxL - gx : gx - nxL) + (nyL > gy ? nyL - gy : gy - nyL);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -1262,21 +1358,21 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
       const uint32_t hM = mm == 0 ? h4[0] : mm == 1 ? h4[1] : mm == 2 ? h4[2] : h4[3];
       const bool act = i < cntM;
       int32_t siS = 0, siE = kIntMax;
-      const uint32_t sidL = nkM ? cells + firstM + i : ncM;
+      const uint32_t sidL = tv.sid(ncM, nkM, firstM, i);
       uint32_t stL = 0;
       if (act) {
         if (nkM) {
           siS = ivals[2 * (firstM + i)];
           siE = ivals[2 * (firstM + i) + 1];
         }
-        stL = g.bits[sidL];
+        stL = tv.getSt(sidL);
       }
       // sipp.hpp:209: skip if si.start - m_time > end_t || si.end < start_t
       const bool cand = act && !((int64_t)siS - 1 > (int64_t)endT || siE < (int32_t)startT);
       const uint32_t tArr = (uint32_t)(siS > (int32_t)startT ? siS : (int32_t)startT);
       const uint64_t candMask = ballot64(cand);
       const uint64_t lateMask = ballot64(cand && tArr > kGMask);
-      const uint64_t openMask = ballot64(cand && stL != 0 && !(stL & kStClosed));   // already in the open list
+      const uint64_t openMask = ballot64(cand && stL != 0 && !(stL & SippView<RES>::kClosed));   // already in the open list
       const uint64_t newMask = ballot64(cand && stL == 0);
       const uint32_t nNew = (uint32_t)__popcll(newMask);
       if (lateMask) {
@@ -1307,7 +1403,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
               nn.z = t;
               nn.w = 0;
               gNodes[nid] = nn;
-              g.bits[sid] = nid + 1;
+              tv.putSt(sid, nid + 1);
               e[k] = T::pack(0, t + hN, t, nid);
             }
           }
@@ -1328,7 +1424,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
           const uint32_t nc = __builtin_amdgcn_readlane(ncM, l);
           const uint32_t hN = __builtin_amdgcn_readlane(hM, l);
           const uint32_t st = __builtin_amdgcn_readlane(stL, l);
-          if (st & kStClosed) continue;                   // closedSet.find (a_star.hpp:117)
+          if (st & SippView<RES>::kClosed) continue;                   // closedSet.find (a_star.hpp:117)
           if (st == 0) {                                   // new state (a_star.hpp:120-129)
             if (nNodes >= g.capNodes) {
               res.status = ST_CAP_NODES;
@@ -1342,7 +1438,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
             nn.z = t;
             nn.w = 0;
             gNodes[nid] = nn;
-            g.bits[sid] = nid + 1;
+            tv.putSt(sid, nid + 1);
             siftUp<T, 0, true>(g, g.open, nOpen, T::pack(0, t + hN, t, nid));
             nOpen += 1;
           } else {                                         // already in open (a_star.hpp:130-146)
@@ -1364,12 +1460,11 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
         if (nx >= dimx || ny >= dimy) continue;
         const uint32_t nc = ny * dimx + nx;
         if ((rfl(obst[nc >> 5]) >> (nc & 31)) & 1u) continue;
-        const uint32_t nk = rfl(cellIdx[nc]);
-        uint32_t first = 0, cnt = 1;
-        if (nk) {
-          first = rfl(specFirst[nk - 1]);
-          cnt = rfl(specFirst[nk]) - first;
-        }
+        uint32_t nk, first, cnt;
+        tv.lookup(nc, nk, first, cnt);
+        nk = rfl(nk);
+        first = rfl(first);
+        cnt = rfl(cnt);
         const uint32_t hN = (nx > gx ? nx - gx : gx - nx) + (ny > gy ? ny - gy : gy - ny);
         for (uint32_t base = 0; base < cnt && !fail; base += 64) {
           const uint32_t i = base + lane;
@@ -1392,9 +1487,9 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
               fail = true;
               break;
             }
-            const uint32_t sid = nk ? cells + first + ii : nc;
-            const uint32_t st = rfl(g.bits[sid]);
-            if (st & kStClosed) continue;                   // closedSet.find (a_star.hpp:117)
+            const uint32_t sid = tv.sid(nc, nk, first, ii);
+            const uint32_t st = rfl(tv.getSt(sid));
+            if (st & SippView<RES>::kClosed) continue;                   // closedSet.find (a_star.hpp:117)
             if (st == 0) {                                   // new state (a_star.hpp:120-129)
               if (nNodes >= g.capNodes) {
                 res.status = ST_CAP_NODES;
@@ -1408,7 +1503,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
               nn.z = t;
               nn.w = 0;
               gNodes[nid] = nn;
-              g.bits[sid] = nid + 1;
+              tv.putSt(sid, nid + 1);
               siftUp<T, 0, true>(g, g.open, nOpen, T::pack(0, t + hN, t, nid));
               nOpen += 1;
             } else {                                         // already in open (a_star.hpp:130-146)
@@ -1569,7 +1664,12 @@ DEVI void processSippJob(const LaunchParams& P, const DevJob* jobSrc, DevResult*
   res.tier = 1;
   for (int q = 0; q < 8; ++q) res.prof[q] = 0;
   uint16_t* outPath = (uint16_t*)(arenaSlot + P.arena_scratch_off);
-  if (rfl(jobS.algo) == 2) runSipp(P, jobS, arenaSlot, res, outPath);  // anything else stays ST_BAD
+  if (rfl(jobS.algo) == 2) {  // anything else stays ST_BAD
+    if (rfl(jobS.ctx_flags) & kSippResident)
+      runSipp<true>(P, jobS, arenaSlot, res, outPath);
+    else
+      runSipp<false>(P, jobS, arenaSlot, res, outPath);
+  }
   __syncthreads();
   resS = res;
   __syncthreads();

@@ -169,6 +169,7 @@ struct Ring {
   uint32_t* sippCons = nullptr;
   uint32_t sippSlotWords = 0;      // capacity per slot the buffer was allocated with
   std::vector<int32_t> slotDimx;   // SIPP: grid width of the slot's job (cell -> x, y when unpacking)
+  std::vector<mrp_ll_sipp_table*> slotTable;  // SIPP: the device-resident table the slot's job holds, if any
   std::vector<int32_t> slotInit;   // initial_cost (A*) / start_time (SIPP) of the slot's job
 };
 struct SessTicket {
@@ -207,6 +208,11 @@ struct mrp_ll_ctx {
   std::vector<SessTicket> sess;
   std::vector<int32_t> sessFree;   // free session-ticket ids (stack)
   void* sippScratch = nullptr;     // SippScratch, created on first use (packSipp)
+  // device-resident SIPP tables: chunks of kSippTablesPerChunk tables of sippTabStride bytes each
+  std::vector<uint8_t*> sippTabChunks;
+  std::vector<int32_t> sippTabFree;
+  int32_t sippTabNext = 0;
+  size_t sippTabStride = 0;
   uint16_t* pathStore = nullptr;   // device-resident path store (mrp_ll_path_store_reserve)
   uint32_t pathStoreStride = 0, pathStoreSlots = 0;
   uint8_t* scanDev = nullptr;      // mrp_ll_conflict_scan: device staging (grown on demand)
@@ -268,6 +274,7 @@ struct ConsSinkBuf {
   PinnedBuf<uint32_t>& b;
   bool failed = false;
   size_t size() const { return b.size; }
+  bool fits(size_t) const { return true; }
   void push(uint32_t w) {
     if (b.push(w) != hipSuccess) failed = true;
   }
@@ -298,6 +305,7 @@ struct ConsSinkSlot {
   uint32_t baseOff, cap, used = 0;
   bool failed = false;
   size_t size() const { return baseOff + used; }
+  bool fits(size_t n) const { return used + n <= cap; }
   void push(uint32_t w) {
     if (used >= cap) {
       failed = true;
@@ -383,6 +391,15 @@ struct mrp_ll_sipp_table {
   std::vector<Spec> spec;
   uint32_t totalSafe = 0;
   std::vector<SippScratch::Iv> scratch;
+  // device-resident copy (session mode): the jobs carry only the cells that changed since the previous job
+  mrp_ll_ctx* ctx = nullptr;
+  int32_t devIndex = -1;                              // slot in the engine's table pool (-1: none)
+  bool devFresh = true;                               // the device copy has never been written: the next job resets it
+  bool inFlight = false;                              // a job is using (and writing) the device copy
+  uint32_t epoch = 0;                                 // of the last job (status words of other epochs read as unseen)
+  bool overflow = false;                              // some cell has more than kSippCap safe intervals: ship whole tables
+  std::vector<int32_t> dirty;                         // cells changed since the last job was packed
+  std::vector<uint8_t> isDirty;
 };
 
 namespace {
@@ -438,9 +455,82 @@ bool packSippFromTable(const mrp_ll_job& j, const MapRec& mp, ConsSink& cs, DevJ
   return !cs.failed;
 }
 
+constexpr int32_t kSippTablesPerChunk = 64;
+
+// Session mode: the job carries the delta of a device-resident table (ll_device.h kSippResident).  `T` is updated (its
+// dirty list is consumed, it is marked in flight), so the job MUST run — sessionSubmit publishes it right away.
+template <class ConsSink>
+bool packSippResident(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, ConsSink& cs, DevJob& d) {
+  mrp_ll_sipp_table& T = *const_cast<mrp_ll_sipp_table*>(j.sipp_table);
+  if (T.dimx != mp.dimx || T.dimy != mp.dimy) return false;
+  const int cells = mp.dimx * mp.dimy;
+  const int32_t startTime = j.initial_cost;
+  if (startTime > static_cast<int32_t>(mrp::kGMask)) return false;
+  const bool fresh = T.devFresh || T.epoch >= mrp::kSippEpochMax;  // epochs used up: start over from a zeroed table
+  const size_t nRec = fresh ? T.spec.size() : T.dirty.size();
+  const size_t hdrWords = (nRec + 3) & ~size_t(3);
+  if ((cs.size() & 3u) != 0 || !cs.fits(hdrWords + nRec * 2 * mrp::kSippCap)) return false;  // nothing consumed yet
+  d.vc_off = static_cast<uint32_t>(cs.size());
+  uint32_t* hdr = cs.grow(hdrWords + nRec * 2 * mrp::kSippCap);
+  if (!hdr) return false;
+  uint32_t* body = hdr + hdrWords;
+  size_t r = 0;
+  auto emit = [&](int32_t cell) {
+    const mrp_ll_sipp_table::Spec& sp = T.spec[T.cellIdx[cell] - 1];
+    hdr[r] = static_cast<uint32_t>(cell) | (static_cast<uint32_t>(sp.safe.size()) << 16);
+    std::memcpy(body + r * 2 * mrp::kSippCap, sp.safe.data(), sizeof(SippScratch::Iv) * sp.safe.size());
+    r += 1;
+  };
+  if (fresh) {
+    for (int32_t cell = 0; cell < cells; ++cell)
+      if (T.cellIdx[cell]) emit(cell);
+    T.epoch = 0;
+  } else {
+    for (int32_t cell : T.dirty) emit(cell);
+  }
+  for (int32_t cell : T.dirty) T.isDirty[cell] = 0;
+  T.dirty.clear();
+  T.devFresh = false;
+  T.epoch += 1;
+  T.inFlight = true;
+  const uint64_t addr = reinterpret_cast<uint64_t>(ctx->sippTabChunks[T.devIndex / kSippTablesPerChunk]) +
+                        static_cast<uint64_t>(T.devIndex % kSippTablesPerChunk) * ctx->sippTabStride;
+  d.algo = MRP_LL_SIPP;
+  d.max_expansions = j.max_expansions;
+  d.n_agents_pad = static_cast<uint32_t>(addr);
+  d.path_off = static_cast<uint32_t>(addr >> 32);
+  d.ctx_flags = mrp::kSippResident;
+  d.n_ctx = T.epoch;
+  d.n_vc = static_cast<uint32_t>(T.spec.size());
+  d.n_ec = T.totalSafe;
+  d.ec_off = static_cast<uint32_t>(nRec) | (fresh ? 0x80000000u : 0u);
+  d.last_goal_constraint = startTime;
+  const int sc = j.start_y * mp.dimx + j.start_x;
+  int startIv = -1;
+  if (!T.cellIdx[sc]) {
+    startIv = 0;
+  } else {
+    const auto& v = T.spec[T.cellIdx[sc] - 1].safe;
+    for (size_t k = 0; k < v.size(); ++k)
+      if (v[k].s <= startTime && v[k].e >= startTime) {
+        startIv = static_cast<int>(k);
+        break;
+      }
+  }
+  d.t_pad = startIv < 0 ? 0xFFFFFFFFu : static_cast<uint32_t>(startIv);
+  return true;
+}
+
 template <class ConsSink>
 bool packSipp(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, ConsSink& cs, DevJob& d) {
-  if (j.sipp_table) return packSippFromTable(j, mp, cs, d);
+  if (j.sipp_table) {
+    const mrp_ll_sipp_table& T = *j.sipp_table;
+    // resident form: in a session, for a table of this engine that fits the fixed layout (one job per table in flight)
+    if (ctx->ring.active && T.ctx == ctx && T.devIndex >= 0 && !T.overflow && !T.inFlight &&
+        packSippResident(ctx, j, mp, cs, d))
+      return true;
+    return packSippFromTable(j, mp, cs, d);
+  }
   const int cells = mp.dimx * mp.dimy;
   if (j.n_collision_locations < 0) return false;
   if (j.n_collision_locations > 0 && (!j.collision_xy || !j.collision_count || !j.collision_intervals)) return false;
@@ -894,6 +984,7 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
   if (ctx->mapsDev) (void)hipFree(ctx->mapsDev);
   if (ctx->scanDev) (void)hipFree(ctx->scanDev);
   if (ctx->pathStore) (void)hipFree(ctx->pathStore);
+  for (uint8_t* c : ctx->sippTabChunks) (void)hipFree(c);
   delete ctx;
 }
 
@@ -1038,6 +1129,7 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
       g.sippSlotWords = want;
     }
     g.slotDimx.assign(R, 0);
+    g.slotTable.assign(R, nullptr);
   }
   g.slotInit.assign(R, 0);
   ctx->sess.clear();
@@ -1149,6 +1241,13 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
     }
   }
   g.active = false;
+  // a table whose job was abandoned: its device copy is in an unknown state, the next job rewrites it whole
+  for (mrp_ll_sipp_table*& tb : g.slotTable)
+    if (tb) {
+      tb->inFlight = false;
+      tb->devFresh = true;
+      tb = nullptr;
+    }
   // the device counter is past the published tickets: the next batch-mode launch starts from a clean base
   Ticket& t = ctx->tickets[0];
   HIPCHK(ctx, hipMemset(t.queueHead, 0, 256));
@@ -1221,10 +1320,13 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
                     Ring::kSlotPathHalfs};
     DevJob d;
     bool ok;
+    uint32_t sippWords = 0;
     if (g.sipp) {  // a SIPP session takes SIPP jobs only, an A* / A*-epsilon session none
       ConsSinkSlot csS{g.sippCons + static_cast<size_t>(slot) * g.sippSlotWords, slot * g.sippSlotWords, g.sippSlotWords};
       ok = jobs[i].algo == MRP_LL_SIPP && packJob(ctx, jobs[i], csS, ps, d);
       if (ok) g.slotDimx[slot] = ctx->maps[jobs[i].map_id].dimx;
+      sippWords = csS.used;
+      g.slotTable[slot] = ok && (d.ctx_flags & mrp::kSippResident) ? const_cast<mrp_ll_sipp_table*>(jobs[i].sipp_table) : nullptr;
     } else {
       ok = jobs[i].algo != MRP_LL_SIPP && (g.kind == 0 || jobs[i].algo == (g.kind == 1 ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR)) &&
            packJob(ctx, jobs[i], cs, ps, d);
@@ -1234,8 +1336,8 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
       st.state[i] = 2;
     }
     g.jobs[slot] = d;
-    ctx->stats.staged_bytes += static_cast<int64_t>(sizeof(DevJob)) + 4 * static_cast<int64_t>(g.sipp ? 0 : cs.used) +
-                               (d.ctx_flags & mrp::kCtxById ? 0 : 2 * static_cast<int64_t>(d.t_pad) * d.n_agents_pad);
+    ctx->stats.staged_bytes += static_cast<int64_t>(sizeof(DevJob)) + 4 * static_cast<int64_t>(g.sipp ? sippWords : cs.used) +
+                               (g.sipp || (d.ctx_flags & mrp::kCtxById) ? 0 : 2 * static_cast<int64_t>(d.t_pad) * d.n_agents_pad);
     g.slotInit[slot] = ok ? jobs[i].initial_cost : 0;
     g.busy[slot] = 1;
     g.slotTicket[slot] = ti;
@@ -1279,6 +1381,10 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
     if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != st.seq[i]) continue;
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
                  st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);
+    if (g.sipp && g.slotTable[slot]) {
+      g.slotTable[slot]->inFlight = false;
+      g.slotTable[slot] = nullptr;
+    }
     st.state[i] = 1;
     st.remaining -= 1;
     g.busy[slot] = 0;
@@ -1314,6 +1420,10 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
     const int32_t i = g.slotJob[slot];
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
                  st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);
+    if (g.sipp && g.slotTable[slot]) {
+      g.slotTable[slot]->inFlight = false;
+      g.slotTable[slot] = nullptr;
+    }
     st.state[i] = 1;
     st.remaining -= 1;
     g.busy[slot] = 0;
@@ -1544,6 +1654,25 @@ int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t mapId, mrp_ll_sipp_table**
   t->dimy = ctx->maps[mapId].dimy;
   t->cellIdx.assign(static_cast<size_t>(t->dimx) * t->dimy, 0);
   t->cellIdx16.assign(static_cast<size_t>(t->dimx) * t->dimy, 0);
+  t->isDirty.assign(static_cast<size_t>(t->dimx) * t->dimy, 0);
+  t->ctx = ctx;
+  // a slot of the device-resident table pool (grown by chunks; existing tables never move).  Failure to allocate is not
+  // an error: such a table simply ships its whole contents with every job.
+  if (ctx->sippTabStride == 0) {
+    const size_t maxCells = static_cast<size_t>(ctx->opt.max_cells);
+    ctx->sippTabStride = ((maxCells + 255) & ~size_t(255)) + maxCells * mrp::kSippCap * 12;  // cnt, iv, status
+  }
+  if (!ctx->sippTabFree.empty()) {
+    t->devIndex = ctx->sippTabFree.back();
+    ctx->sippTabFree.pop_back();
+  } else {
+    if (ctx->sippTabNext == static_cast<int32_t>(ctx->sippTabChunks.size()) * kSippTablesPerChunk) {
+      void* c = nullptr;
+      if (hipSetDevice(ctx->device) == hipSuccess && hipMalloc(&c, ctx->sippTabStride * kSippTablesPerChunk) == hipSuccess)
+        ctx->sippTabChunks.push_back(static_cast<uint8_t*>(c));
+    }
+    if (ctx->sippTabNext < static_cast<int32_t>(ctx->sippTabChunks.size()) * kSippTablesPerChunk) t->devIndex = ctx->sippTabNext++;
+  }
   *out = t;
   return MRP_LL_SUCCESS;
 }
@@ -1564,10 +1693,19 @@ int mrp_ll_sipp_table_add(mrp_ll_sipp_table* t, int32_t x, int32_t y, int32_t st
   sp.safe.clear();
   safeFromCollisions(sp.collisions.data(), static_cast<int>(sp.collisions.size() / 2), t->scratch, sp.safe);
   t->totalSafe += static_cast<uint32_t>(sp.safe.size());
+  if (sp.safe.size() > mrp::kSippCap) t->overflow = true;  // from now on this table travels whole (packSippFromTable)
+  if (!t->isDirty[cell]) {
+    t->isDirty[cell] = 1;
+    t->dirty.push_back(static_cast<int32_t>(cell));
+  }
   return MRP_LL_SUCCESS;
 }
 
-void mrp_ll_sipp_table_destroy(mrp_ll_sipp_table* t) { delete t; }
+void mrp_ll_sipp_table_destroy(mrp_ll_sipp_table* t) {
+  if (!t) return;
+  if (t->ctx && t->devIndex >= 0) t->ctx->sippTabFree.push_back(t->devIndex);
+  delete t;
+}
 
 int mrp_ll_release_maps(mrp_ll_ctx* ctx) {
   if (!ctx) return MRP_LL_E_INVALID;

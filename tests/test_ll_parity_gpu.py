@@ -588,3 +588,124 @@ def test_device_path_store(oracle_mod, bench_instances):
         assert bad[0].status == ll.BAD_JOB
     finally:
         eng.close()
+
+
+@pytest.mark.timeout(900)
+def test_sipp_device_resident_tables(oracle_mod):
+    """mrp_ll_sipp_table_* inside a SIPP session: the table lives on the device and a job carries only the cells that
+    changed since the table's previous job.  A prioritized-planner-like sequence (search, add intervals, search ...) on
+    several tables at once must match the oracle job by job — including a table that outgrows the resident layout
+    (a cell with more than 8 safe intervals: falls back to whole tables), more jobs on one table than there are epochs
+    (the status words are re-zeroed), two jobs on one table in flight (the second travels whole), a start time inside a
+    collision interval (no start interval; the delta must still be applied) and the table surviving session boundaries."""
+    import random
+    from libmultirobotplanning_amd import ll
+    rng = random.Random(99)
+    dim = 64
+    obst = [list(c) for c in {(rng.randrange(dim), rng.randrange(dim)) for _ in range(400)}]
+    oset = {tuple(c) for c in obst}
+    free = [[x, y] for x in range(dim) for y in range(dim) if (x, y) not in oset]
+    eng = ll.LowLevelEngine(device=0, max_cells=dim * dim)
+    mid = eng.upload_map(dim, dim, obst)
+
+    class Tab:
+        def __init__(self):
+            self.h = eng.sipp_table_create(mid)
+            self.cis = {}      # cell -> [[a, b], ...] in time order
+            self.next_t = {}
+
+        def add(self, c, a=None, n=1):
+            for _ in range(n):
+                t = self.next_t.get(tuple(c), rng.randrange(0, 30))
+                a0 = t + rng.randrange(0, 5)
+                b0 = a0 + rng.randrange(0, 4)
+                self.cis.setdefault(tuple(c), []).append([a0, b0])
+                self.next_t[tuple(c)] = b0 + 2 + rng.randrange(0, 3)
+                eng.sipp_table_add(self.h, c[0], c[1], a0, b0)
+
+        def flat(self):
+            return [[c[0], c[1], a, b] for c, v in sorted(self.cis.items()) for a, b in v]
+
+    def check(tab, st, go, t0, r):
+        o_states, o_exp, o_cost, o_fmin = oracle_mod.sipp_single_at(dim, dim, obst, st, go, tab.flat(), start_time=t0)
+        assert r.status != ll.BAD_JOB
+        if r.status == ll.CAP_EXPANSIONS:
+            return 0
+        assert r.success == (len(o_states) > 0), (st, go, t0)
+        if not r.success:
+            return 0
+        assert [[x, y, t] for t, x, y in r.states] == o_states, (st, go, t0)
+        assert (r.expanded, r.cost, r.fmin) == (o_exp, o_cost, o_fmin)
+        return 1
+
+    tabs = [Tab() for _ in range(6)]
+    n_ok = 0
+    st0 = eng.stats()["staged_bytes"]
+    n_jobs = 0
+    eng.session_begin_sipp(32)
+    try:
+        for rnd in range(40):
+            jobs, specs = [], []
+            for k, tb in enumerate(tabs):
+                st, go = rng.choice(free), rng.choice(free)
+                t0 = rng.choice([0, 0, 0, 2, 9])
+                if rnd == 7 and k == 1:                       # start time inside a collision interval of the start cell
+                    tb.cis.setdefault(tuple(st), [])
+                    a0 = tb.next_t.get(tuple(st), 0)
+                    tb.cis[tuple(st)].append([a0, a0 + 3])
+                    tb.next_t[tuple(st)] = a0 + 6
+                    eng.sipp_table_add(tb.h, st[0], st[1], a0, a0 + 3)
+                    t0 = a0 + 1
+                specs.append((tb, st, go, t0))
+                jobs.append(ll.LLJob(map_id=mid, algo=ll.SIPP, start=st, goal=go, sipp_table=tb.h, initial_cost=t0,
+                                     max_expansions=30000))
+            res = eng.search_batch(jobs)
+            n_jobs += len(jobs)
+            for (tb, st, go, t0), r in zip(specs, res):
+                n_ok += check(tb, st, go, t0, r)
+                # what a prioritized planner does next: the cells of this agent's path become collision intervals
+                for c in rng.sample(free, rng.randrange(1, 25)):
+                    tb.add(c)
+            if rnd == 20:
+                tabs[2].add(free[5], n=12)                    # 12 collision intervals -> 13 safe intervals: beyond the layout
+        small = (eng.stats()["staged_bytes"] - st0) / n_jobs
+        # two jobs on ONE table in the same submit: the second cannot share the device copy
+        tb = tabs[0]
+        sg = [(rng.choice(free), rng.choice(free)) for _ in range(2)]
+        res = eng.search_batch([ll.LLJob(map_id=mid, algo=ll.SIPP, start=s, goal=g_, sipp_table=tb.h) for s, g_ in sg])
+        for (s, g_), r in zip(sg, res):
+            n_ok += check(tb, s, g_, 0, r)
+        # more jobs on one table than there are epochs (255)
+        tb = tabs[3]
+        for k in range(300):
+            st, go = rng.choice(free), rng.choice(free)
+            r = eng.search_batch([ll.LLJob(map_id=mid, algo=ll.SIPP, start=st, goal=go, sipp_table=tb.h,
+                                           max_expansions=30000)])[0]
+            if k % 10 == 0 or k in (253, 254, 255, 256):
+                n_ok += check(tb, st, go, 0, r)
+            if k % 3 == 0:
+                tb.add(rng.choice(free))
+    finally:
+        eng.session_end()
+    assert n_ok > 150
+    # a delta is a few hundred bytes; the whole table of a 64x64 map is more than 8 KB
+    assert small < 4000, small
+    # outside a session the tables travel whole; back in a session the device copies pick up what changed meanwhile
+    tb = tabs[4]
+    for c in rng.sample(free, 10):
+        tb.add(c)
+    st, go = rng.choice(free), rng.choice(free)
+    r = eng.search_batch([ll.LLJob(map_id=mid, algo=ll.SIPP, start=st, goal=go, sipp_table=tb.h)])[0]
+    assert check(tb, st, go, 0, r) in (0, 1)
+    tb.add(rng.choice(free))
+    eng.session_begin_sipp(16)
+    try:
+        for tb in tabs:
+            st, go = rng.choice(free), rng.choice(free)
+            r = eng.search_batch([ll.LLJob(map_id=mid, algo=ll.SIPP, start=st, goal=go, sipp_table=tb.h)])[0]
+            check(tb, st, go, 0, r)
+    finally:
+        eng.session_end()
+    for tb in tabs:
+        eng.sipp_table_destroy(tb.h)
+    eng.close()
