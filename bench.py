@@ -18,7 +18,8 @@ Extra objects in the same line:
                  benchmark/32x32_obst204 inputs of tests/golden/bench_instances.json as ONE batch, checked against
                  tests/golden/oracle_expected.json).  Each carries value (expansions/s), instances_per_s, capped,
                  cpu_baseline (the CPU port, one thread, on a bounded sample of the SAME instances) and
-                 parity_mismatches_vs_gpu over that sample.
+                 parity_mismatches_vs_gpu over that sample.  sipp50 / sipp100 / sipp200: prioritized SIPP (config 5) on
+                 synthetic 64x64 maps with 410 obstacles, CPU leg = 512 instances timed inside the oracle.
   roofline     — dominant kernel of the headline region (session mode: one resident launch per host thread per step):
                  achieved = 128 B/expansion x expansions of the timed launches / sum of their hipEvent
                  durations; bound = HBM (8 TB/s); traffic = HBM bytes per launch SCALED from the committed PMC passes
@@ -90,7 +91,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4096, help="headline instances timed on the CPU port (rank 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--legs", default="auto", help="'auto' (all at N=1, none otherwise), 'none', or a comma list of "
-                                                   "agents50,agents100,shipped")
+                                                   "agents50,agents100,shipped,sipp50,sipp100,sipp200")
     ap.add_argument("--max-ll-expansions", type=int, default=50000,
                     help="harness cap per instance of the headline workload (the reference has none and never returns "
                          "on infeasible inputs); applied identically to the GPU path and to the CPU baseline")
@@ -285,7 +286,7 @@ def main():
 
         legs = args.legs
         if legs == "auto":
-            legs = "agents50,agents100,shipped" if world == 1 else "none"
+            legs = "agents50,agents100,shipped,sipp50,sipp100,sipp200" if world == 1 else "none"
         by = {"agents%d" % args.agents: {"value": out["value"], "instances_per_s": out["instances_per_s"],
                                          "instances": int(inst_all), "capped": capped_first,
                                          "cap_per_instance": args.max_ll_expansions, "see": "top-level fields"}}
@@ -295,6 +296,7 @@ def main():
             "agents50": (50, 16384, 400000, 192),
             "agents100": (100, 4096, 3000000, 24),
         }
+        sipp_specs = {"sipp50": (50, 2048, 512), "sipp100": (100, 2048, 512), "sipp200": (200, 1024, 512)}
         for name in [x for x in legs.split(",") if x and x != "none"]:
             if name in leg_specs:
                 ag, nb, cap, ncpu = leg_specs[name]
@@ -317,6 +319,40 @@ def main():
                        "workload": "ECBS w=1.3, synthetic 32x32_obst204-shaped, agents%d, seeds %d.." % (ag, 1000 * ag)}
                 if do_cpu:
                     leg["cpu_baseline"] = cpu_leg(oracle, ia, res, cap, ncpu, hl)
+                    leg["vs_cpu_port_1core"] = leg["value"] / max(leg["cpu_baseline"]["value"], 1e-12)
+                by[name] = leg
+            elif name in sipp_specs:
+                # BASELINE.json config 5 / SURVEY.md §8(d)(iv): prioritized planning over MRP_LL_SIPP searches, 64x64 with
+                # 410 obstacles; every instance plans its agents one after the other (mapf_prioritized_sipp.cpp:214-270),
+                # so a step is nb instances x ag sequential searches, the safe-interval tables resident on the device
+                ag, nb, ncpu = sipp_specs[name]
+                ia = hl.generate_instances(640000 + 1000 * ag, nb, 64, 64, 410, ag)
+                insts = list(ia)
+                solver.prioritized_sipp(insts[:64], want_schedules=False)  # warm-up, same shape
+                torch.cuda.synchronize()
+                res, st = solver.prioritized_sipp(insts, want_schedules=False)
+                torch.cuda.synchronize()
+                # the native driver's own clock around the whole batch (first submit to last result); the Python wrapper
+                # around it only marshals the instance arrays in and the per-agent schedules out
+                dt = st["wall_seconds"]
+                leg = {"value": st["ll_expansions"] / dt, "unit": "expansions/s", "instances_per_s": nb / dt,
+                       "instances": nb, "seconds": dt, "ll_searches": int(st["ll_searches"]),
+                       "all_agents_planned": int(st["solved"]),
+                       "workload": "prioritized SIPP, synthetic 64x64 with 410 obstacles, agents%d, seeds %d.." % (
+                           ag, 640000 + 1000 * ag)}
+                if do_cpu:
+                    nt = max(1, min(hc, 8))
+                    per, wall = oracle.prioritized_sipp_batch(64, 64, ia.obstacles[:ncpu], ia.starts[:ncpu], ia.goals[:ncpu],
+                                                              n_threads=nt)
+                    secs = float(per[:, 3].sum()) / 1e9
+                    mism = sum((int(q[1]), int(q[0]), int(q[2])) != (r["cost"], r["n_planned"], r["expanded"])
+                               for q, r in zip(per, res[:ncpu]))
+                    leg["cpu_baseline"] = {
+                        "value": float(per[:, 2].sum()) / max(secs, 1e-12), "unit": "expansions/s", "cores": 1, "kind": "port",
+                        "sample": "first %d instances of the leg's batch; each instance timed inside the oracle (g++ -O3), "
+                                  "%d at a time; expansions / sum of the per-instance seconds" % (ncpu, nt),
+                        "instances_per_s": ncpu / max(secs, 1e-12), "seconds": secs, "pool_wall_seconds": wall,
+                        "parity_mismatches_vs_gpu": int(mism)}
                     leg["vs_cpu_port_1core"] = leg["value"] / max(leg["cpu_baseline"]["value"], 1e-12)
                 by[name] = leg
             elif name == "shipped":

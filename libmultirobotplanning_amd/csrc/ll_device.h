@@ -61,6 +61,7 @@ constexpr uint32_t kCtxById = 1u;
 // status first), as  hdr[nRec]  (cell | count << 16; padded to a multiple of 4 words)  then  nRec x kSippCap x {start, end}.
 // n_ctx = the job's epoch (1..255).  One job per table in flight.
 constexpr uint32_t kSippResident = 2u;
+constexpr uint32_t kSippNoLds = 4u;                                // ctx_flags bit 2: keep nodes and open list in the arena (MRP_LL_SIPP_NO_LDS=1)
 constexpr uint32_t kSippCap = 8;                                   // safe intervals per cell the resident layout holds
 constexpr uint32_t kSippEpochShift = 24, kSippEpochMax = 255;
 constexpr uint32_t kSippStClosed = 1u << 23;

@@ -31,6 +31,7 @@
 namespace mrp {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
 #define DEVI __device__ __forceinline__
@@ -93,6 +94,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct TierHbm {
   static constexpr int AS = 1;
+  static constexpr bool kWideNodes = true;   // four words per node (the position of its open entry in word 3)
   typedef uint64_t E;
   typedef u64x2 Pair;
   static constexpr uint32_t kFhCap = kFhMax;
@@ -120,6 +122,7 @@ struct TierHbm {
 
 struct TierLds {
   static constexpr int AS = 3;
+  static constexpr bool kWideNodes = false;  // one word per node + a halfword position array
   typedef uint32_t E;
   typedef u32x2 Pair;
   static constexpr uint32_t kIdBits = 9, kGB = 6, kFB = 7, kFhB = 10;
@@ -141,6 +144,11 @@ struct TierLds {
   DEVI static E shr1(E v) { return waveShr1(v); }
 };
 
+// TierHbm's records in LDS: the SIPP fast tier (times do not fit TierLds' 6-bit g / 7-bit f)
+struct TierLdsWide : TierHbm {
+  static constexpr int AS = 3;
+};
+
 template <class T>
 struct Mem {
   typedef typename T::E E;
@@ -160,7 +168,7 @@ struct Mem {
 
 template <class T>
 DEVI void setPos(Mem<T>& m, uint32_t id, uint32_t idx) {
-  if constexpr (T::AS == 3)
+  if constexpr (!T::kWideNodes)
     m.pos[id] = (uint16_t)idx;
   else
     m.nodes[id * 4 + 3] = idx;
@@ -1121,14 +1129,346 @@ struct SippView {
   DEVI void putSt(uint32_t id, uint32_t v) const { status[id] = RES ? (v | epochBits) : v; }
 };
 
+struct SippState {  // wave-uniform
+  uint32_t nNodes, nOpen;
+  int64_t expansions;
+};
+
+// The search loop over one memory tier.  Returns the job's status, or RUN_MIGRATE_NODES when the LDS tier has no room
+// for the successors of the next expansion (nothing of that expansion has happened yet: the caller copies nodes and
+// open list into the arena and calls the TierHbm instance with the same state).
+template <class T, bool RES>
+DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const SippView<RES>& tv, SippState& s,
+                      DevResult& res, uint16_t* outPath) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t dimx = J.dimx, dimy = J.dimy;
+  const uint32_t gx = J.gx, gy = J.gy;
+  const int64_t maxExp = J.max_expansions;
+  const uint32_t* obst = P.maps + J.map_word_off;
+  const int32_t* ivals = tv.ivals;
+  typename Mem<T>::PNode4 gNodes = (typename Mem<T>::PNode4)g.nodes;
+  uint32_t& nNodes = s.nNodes;
+  uint32_t& nOpen = s.nOpen;
+  int64_t& expansions = s.expansions;
+  for (;;) {
+    if (nOpen == 0) {
+      res.status = ST_NO_SOLUTION;
+      break;
+    }
+    const uint64_t curE = ldU<T>(g.open, 0);
+    const uint32_t curId = T::id(curE);
+    const u32x4 nd = gNodes[curId];
+    const uint32_t cw = rfl(nd.x);
+    const uint32_t cell = cw & 0xFFFF, iv = RES ? (cw >> 16) & 0x7FFFu : cw >> 16;
+    const uint32_t gcur = rfl(nd.z);
+    const uint32_t cx = cell % dimx, cy = cell / dimx;
+    // RES: every table word this expansion needs has an address that follows from (cell, iv) alone — the cell's own
+    // list length and interval end, and for the four neighbours (lanes 16 * motion + i) the obstacle word, the list
+    // length, interval slot i and its status word.  All of it is requested here, in ONE round trip to HBM, and the
+    // heap pop below (LDS tier) runs while it is in flight; slots beyond a list's length hold stale words that are
+    // loaded and ignored.  "Ends at INT_MAX", which the goal test needs at once, rides in bit 31 of the node's x.
+    uint32_t ck = 0, f0 = 0, nCur = 0;
+    int32_t endT = kIntMax;
+    uint32_t r_nc = 0, r_obstW = 0xFFFFFFFFu, r_nk = 0, r_st = 0, r_ck = 0, r_h = 0;
+    int32_t r_s = 0, r_e = kIntMax, r_endT = kIntMax;
+    bool r_inb = false;
+    if constexpr (RES) {
+      const uint32_t mm = lane >> 4, i = lane & 15u;
+      const uint32_t nx = cx + (mm == 3) - (mm == 2), ny = cy + (mm == 0) - (mm == 1);
+      r_inb = nx < dimx && ny < dimy;
+      r_nc = r_inb ? ny * dimx + nx : 0;
+      r_h = (nx > gx ? nx - gx : gx - nx) + (ny > gy ? ny - gy : gy - ny);
+      r_ck = tv.cnt[cell];
+      r_endT = ivals[2 * (cell * kSippCap + iv) + 1];
+      r_obstW = obst[r_nc >> 5];
+      r_nk = tv.cnt[r_nc];
+      if (i < kSippCap) {
+        const i32x2 se = *(const i32x2*)(ivals + 2 * (r_nc * kSippCap + i));
+        r_s = se.x;
+        r_e = se.y;
+        r_st = tv.status[r_nc * kSippCap + i];
+      }
+      if (!(cw >> 31)) endT = 0;  // any finite value: the goal test below only asks whether it is INT_MAX
+    } else {
+      tv.lookup(cell, ck, f0, nCur);
+      ck = rfl(ck);
+      f0 = rfl(f0);
+      if (ck) endT = rfli(ivals[2 * (f0 + iv) + 1]);
+    }
+    if constexpr (T::AS == 3) {  // LDS tier: room for every successor of this expansion, or continue in the arena
+      if (nNodes + 4 * kSippCap > g.capNodes) return RUN_MIGRATE_NODES;
+    }
+    expansions += 1;
+    if (maxExp >= 0 && expansions > maxExp) {
+      res.status = ST_CAP_EXP;
+      break;
+    }
+    if (cx == gx && cy == gy && endT == kIntMax) {
+      // raw A* solution: (cell, g) per state; the host inserts the explicit Wait actions (sipp.hpp:105-128)
+      uint32_t len = 0;
+      for (uint32_t nid = curId; nid != kNoParent; nid = rfl(gNodes[nid].y)) len += 1;
+      if (len * 2 > P.out_stride) {
+        res.status = ST_CAP_HORIZON;
+        break;
+      }
+      uint32_t* out32 = (uint32_t*)outPath;
+      uint32_t nid = curId;
+      for (int32_t k = (int32_t)len - 1; k >= 0; --k) {
+        const u32x4 pn = gNodes[nid];
+        out32[k] = (rfl(pn.x) & 0xFFFF) | (rfl(pn.z) << 16);
+        nid = rfl(pn.y);
+      }
+      res.status = ST_OK;
+      res.cost = (int32_t)gcur;
+      res.fmin = (int32_t)T::f(curE);
+      res.n_states = (int32_t)len;
+      break;
+    }
+    heapPop<T, 0, true>(g, g.open, nOpen);
+    if constexpr (RES) {
+      ck = rfl(r_ck);
+      f0 = cell * kSippCap;
+      if (ck) endT = rfli(r_endT);
+      else endT = kIntMax;
+    }
+    const uint32_t curSid = tv.sid(cell, ck, f0, iv);
+    tv.putSt(curSid, SippView<RES>::kClosed);
+    const uint32_t startT = gcur + 1;
+    if (startT > kGMask) {
+      res.status = ST_CAP_HORIZON;
+      break;
+    }
+    bool fail = false;
+    // ---- neighbours.  Lanes 0..3 probe the four motions Up, Down, Left, Right at once (bounds, obstacle bit, the
+    // cell's safe-interval list); when no list is longer than 16 the intervals of all four cells are then evaluated on
+    // lanes 16*m + i together with their open/closed status — three dependent global round trips per expansion
+    // instead of three to five per motion.  Candidates are consumed in lane order, which IS the reference's order
+    // (motion-major, interval-minor, sipp.hpp:205-222).
+    uint32_t c4[4] = {0, 0, 0, 0}, f4[4] = {0, 0, 0, 0}, nc4[4] = {0, 0, 0, 0}, nk4[4] = {0, 0, 0, 0}, h4[4] = {0, 0, 0, 0};
+    if constexpr (!RES) {
+      const uint32_t nxL = cx + (lane == 3) - (lane == 2), nyL = cy + (lane == 0) - (lane == 1);
+      const bool inbL = lane < 4 && nxL < dimx && nyL < dimy;
+      const uint32_t ncL = inbL ? nyL * dimx + nxL : 0;
+      uint32_t obstW = 0xFFFFFFFFu, nkL = 0, firstL = 0, cntL = 0;
+      if (inbL) {
+        obstW = obst[ncL >> 5];
+        tv.lookup(ncL, nkL, firstL, cntL);
+      }
+      const bool validL = inbL && !((obstW >> (ncL & 31)) & 1u);
+      if (!validL) cntL = 0;
+      const uint32_t hL = (nxL > gx ? nxL - gx : gx - nxL) + (nyL > gy ? nyL - gy : gy - nyL);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        c4[m] = __builtin_amdgcn_readlane(cntL, m);
+        f4[m] = __builtin_amdgcn_readlane(firstL, m);
+        nc4[m] = __builtin_amdgcn_readlane(ncL, m);
+        nk4[m] = __builtin_amdgcn_readlane(nkL, m);
+        h4[m] = __builtin_amdgcn_readlane(hL, m);
+      }
+    }
+    const uint32_t cMax = RES ? 0u : max(max(c4[0], c4[1]), max(c4[2], c4[3]));
+    if (cMax <= 16) {
+      const uint32_t mm = lane >> 4, i = lane & 15;
+      uint32_t cntM, firstM, ncM, nkM, hM, sidL, stL = 0;
+      int32_t siS = 0, siE = kIntMax;
+      bool act;
+      if constexpr (RES) {
+        const bool valid = r_inb && !((r_obstW >> (r_nc & 31)) & 1u);
+        nkM = r_nk;
+        ncM = r_nc;
+        hM = r_h;
+        firstM = r_nc * kSippCap;
+        cntM = valid ? (nkM ? nkM - 1 : 1u) : 0u;
+        act = i < cntM;
+        sidL = r_nc * kSippCap + i;
+        if (act) {
+          if (nkM) {
+            siS = r_s;
+            siE = r_e;
+          }
+          stL = (r_st >> kSippEpochShift) == (tv.epochBits >> kSippEpochShift) ? (r_st & ((1u << kSippEpochShift) - 1u)) : 0u;
+        }
+      } else {
+        cntM = mm == 0 ? c4[0] : mm == 1 ? c4[1] : mm == 2 ? c4[2] : c4[3];
+        firstM = mm == 0 ? f4[0] : mm == 1 ? f4[1] : mm == 2 ? f4[2] : f4[3];
+        ncM = mm == 0 ? nc4[0] : mm == 1 ? nc4[1] : mm == 2 ? nc4[2] : nc4[3];
+        nkM = mm == 0 ? nk4[0] : mm == 1 ? nk4[1] : mm == 2 ? nk4[2] : nk4[3];
+        hM = mm == 0 ? h4[0] : mm == 1 ? h4[1] : mm == 2 ? h4[2] : h4[3];
+        act = i < cntM;
+        sidL = tv.sid(ncM, nkM, firstM, i);
+        if (act) {
+          if (nkM) {
+            siS = ivals[2 * (firstM + i)];
+            siE = ivals[2 * (firstM + i) + 1];
+          }
+          stL = tv.getSt(sidL);
+        }
+      }
+      // sipp.hpp:209: skip if si.start - m_time > end_t || si.end < start_t
+      const bool cand = act && !((int64_t)siS - 1 > (int64_t)endT || siE < (int32_t)startT);
+      const uint32_t tArr = (uint32_t)(siS > (int32_t)startT ? siS : (int32_t)startT);
+      const uint64_t candMask = ballot64(cand);
+      const uint64_t lateMask = ballot64(cand && tArr > kGMask);
+      const uint64_t openMask = ballot64(cand && stL != 0 && !(stL & SippView<RES>::kClosed));   // already in the open list
+      const uint64_t newMask = ballot64(cand && stL == 0);
+      const uint32_t nNew = (uint32_t)__popcll(newMask);
+      if (lateMask) {
+        res.status = ST_CAP_HORIZON;
+        fail = true;
+      } else if (openMask == 0 && nNew <= 5) {
+        // the usual case — nothing to re-key: all pushes of the expansion in one round trip (PushChains)
+        if (nNodes + nNew > g.capNodes) {
+          res.status = ST_CAP_NODES;
+          fail = true;
+        } else if (nNew) {
+          uint64_t e[5];
+          uint64_t mk = newMask;
+#pragma unroll
+          for (uint32_t k = 0; k < 5; ++k) {
+            e[k] = 0;
+            if (k < nNew) {
+              const uint32_t l = (uint32_t)__builtin_ctzll(mk);
+              mk &= mk - 1;
+              const uint32_t t = __builtin_amdgcn_readlane(tArr, l);
+              const uint32_t sid = __builtin_amdgcn_readlane(sidL, l);
+              const uint32_t nc = __builtin_amdgcn_readlane(ncM, l);
+              const uint32_t hN = __builtin_amdgcn_readlane(hM, l);
+              const uint32_t nid = nNodes + k;
+              u32x4 nn;
+              nn.x = nc | ((l & 15u) << 16) | (RES ? __builtin_amdgcn_readlane(siE == kIntMax ? 1u : 0u, l) << 31 : 0u);
+              nn.y = curId;
+              nn.z = t;
+              nn.w = 0;
+              gNodes[nid] = nn;
+              tv.putSt(sid, nid + 1);
+              e[k] = T::pack(0, t + hN, t, nid);
+            }
+          }
+          const uint32_t pm = (1u << nNew) - 1u;
+          PushChains<T> pc;
+          pc.load(g.open, nOpen, pm);
+          pc.template resolve<0, true>(g, g.open, nOpen, pm, e);
+          nNodes += nNew;
+          nOpen += nNew;
+        }
+      } else {
+        uint64_t mask = candMask;
+        while (mask && !fail) {
+          const uint32_t l = (uint32_t)__builtin_ctzll(mask);
+          mask &= mask - 1;
+          const uint32_t t = __builtin_amdgcn_readlane(tArr, l);
+          const uint32_t sid = __builtin_amdgcn_readlane(sidL, l);
+          const uint32_t nc = __builtin_amdgcn_readlane(ncM, l);
+          const uint32_t hN = __builtin_amdgcn_readlane(hM, l);
+          const uint32_t st = __builtin_amdgcn_readlane(stL, l);
+          if (st & SippView<RES>::kClosed) continue;                   // closedSet.find (a_star.hpp:117)
+          if (st == 0) {                                   // new state (a_star.hpp:120-129)
+            if (nNodes >= g.capNodes) {
+              res.status = ST_CAP_NODES;
+              fail = true;
+              break;
+            }
+            const uint32_t nid = nNodes++;
+            u32x4 nn;
+            nn.x = nc | ((l & 15u) << 16) | (RES ? __builtin_amdgcn_readlane(siE == kIntMax ? 1u : 0u, l) << 31 : 0u);
+            nn.y = curId;
+            nn.z = t;
+            nn.w = 0;
+            gNodes[nid] = nn;
+            tv.putSt(sid, nid + 1);
+            siftUp<T, 0, true>(g, g.open, nOpen, T::pack(0, t + hN, t, nid));
+            nOpen += 1;
+          } else {                                         // already in open (a_star.hpp:130-146)
+            const uint32_t nid = st - 1;
+            const u32x4 on = gNodes[nid];
+            if (t >= rfl(on.z)) continue;
+            u32x4 nn = on;
+            nn.y = curId;
+            nn.z = t;
+            gNodes[nid] = nn;                             // cameFrom update + new g
+            siftUp<T, 0, true>(g, g.open, rfl(on.w), T::pack(0, t + hN, t, nid));  // increase(handle)
+          }
+        }
+      }
+    } else {
+      // a cell with more than 16 safe intervals: one motion at a time, 64 intervals per pass
+      for (uint32_t m = 0; m < 4 && !fail; ++m) {  // Up, Down, Left, Right
+        const uint32_t nx = cx + (m == 3) - (m == 2), ny = cy + (m == 0) - (m == 1);
+        if (nx >= dimx || ny >= dimy) continue;
+        const uint32_t nc = ny * dimx + nx;
+        if ((rfl(obst[nc >> 5]) >> (nc & 31)) & 1u) continue;
+        uint32_t nk, first, cnt;
+        tv.lookup(nc, nk, first, cnt);
+        nk = rfl(nk);
+        first = rfl(first);
+        cnt = rfl(cnt);
+        const uint32_t hN = (nx > gx ? nx - gx : gx - nx) + (ny > gy ? ny - gy : gy - ny);
+        for (uint32_t base = 0; base < cnt && !fail; base += 64) {
+          const uint32_t i = base + lane;
+          int32_t siS = 0, siE = kIntMax;
+          if (nk && i < cnt) {
+            siS = ivals[2 * (first + i)];
+            siE = ivals[2 * (first + i) + 1];
+          }
+          // sipp.hpp:209: skip if si.start - m_time > end_t || si.end < start_t
+          const bool cand = (i < cnt) && !((int64_t)siS - 1 > (int64_t)endT || siE < (int32_t)startT);
+          const uint32_t tArr = (uint32_t)(siS > (int32_t)startT ? siS : (int32_t)startT);
+          uint64_t mask = ballot64(cand);
+          while (mask) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1;
+            const uint32_t ii = base + l;
+            const uint32_t t = __builtin_amdgcn_readlane(tArr, l);
+            if (t > kGMask) {
+              res.status = ST_CAP_HORIZON;
+              fail = true;
+              break;
+            }
+            const uint32_t sid = tv.sid(nc, nk, first, ii);
+            const uint32_t st = rfl(tv.getSt(sid));
+            if (st & SippView<RES>::kClosed) continue;                   // closedSet.find (a_star.hpp:117)
+            if (st == 0) {                                   // new state (a_star.hpp:120-129)
+              if (nNodes >= g.capNodes) {
+                res.status = ST_CAP_NODES;
+                fail = true;
+                break;
+              }
+              const uint32_t nid = nNodes++;
+              u32x4 nn;
+              nn.x = nc | (ii << 16);
+              nn.y = curId;
+              nn.z = t;
+              nn.w = 0;
+              gNodes[nid] = nn;
+              tv.putSt(sid, nid + 1);
+              siftUp<T, 0, true>(g, g.open, nOpen, T::pack(0, t + hN, t, nid));
+              nOpen += 1;
+            } else {                                         // already in open (a_star.hpp:130-146)
+              const uint32_t nid = st - 1;
+              const u32x4 on = gNodes[nid];
+              if (t >= rfl(on.z)) continue;
+              u32x4 nn = on;
+              nn.y = curId;
+              nn.z = t;
+              gNodes[nid] = nn;                             // cameFrom update + new g
+              siftUp<T, 0, true>(g, g.open, rfl(on.w), T::pack(0, t + hN, t, nid));  // increase(handle)
+            }
+          }
+        }
+      }
+    }
+    if (fail) return res.status;
+  }
+  return res.status;
+}
+
 template <bool RES>
-DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, DevResult& res, uint16_t* outPath) {
+DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, uint8_t* ldsTier, uint32_t ldsNodes, DevResult& res,
+                  uint16_t* outPath) {
   const uint32_t lane = threadIdx.x;
   const uint32_t dimx = J.dimx, dimy = J.dimy, cells = dimx * dimy;
   const uint32_t K = J.n_vc, totalIv = J.n_ec;
   const uint32_t gx = J.gx, gy = J.gy;
-  const int64_t maxExp = J.max_expansions;
-  const uint32_t* obst = P.maps + J.map_word_off;
   typedef TierHbm T;
   Mem<T> g;
   Mem<T>::PNode4 gNodes;
@@ -1241,290 +1581,84 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, De
   tv.status = (uint32_t*)g.bits;
   tv.cnt = nullptr;
   }
-  const int32_t* ivals = tv.ivals;
   if (J.t_pad == 0xFFFFFFFFu) {  // no safe interval contains the start time: SIPP::search returns false (sipp.hpp:98-100)
     res.status = ST_NO_SOLUTION; // (after the table update: a resident table must not miss this job's delta)
     return;
   }
 
   // start node
-  uint32_t nNodes = 1, nOpen = 1;
-  int64_t expansions = 0;
+  SippState s;
+  s.nNodes = 1;
+  s.nOpen = 1;
+  s.expansions = 0;
+  u32x4 n0;
+  uint64_t e0;
   {
     const uint32_t sc = J.sy * dimx + J.sx;
     const uint32_t si = J.t_pad;  // start interval index (findSafeInterval, sipp.hpp:286-296, done by the host)
     const uint32_t h0 = (J.sx > gx ? J.sx - gx : gx - J.sx) + (J.sy > gy ? J.sy - gy : gy - J.sy);
-    u32x4 n0;
-    n0.x = sc | (si << 16);
+    n0.x = sc | (si << 16) | (RES ? J.reserved << 31 : 0u);  // RES: bit 31 = the start interval ends at INT_MAX
     n0.y = kNoParent;
     // SIPP::search(..., startTime) (sipp.hpp:92-103): the start node's g is startTime, its f is h(start) alone
     // (a_star.hpp:78 pushes Node(start, h, initialCost))
     const uint32_t startTime = (uint32_t)J.last_goal_constraint;
     n0.z = startTime;
     n0.w = 0;
-    gNodes[0] = n0;
-    g.open[0] = T::pack(0, h0, startTime, 0);
+    e0 = TierHbm::pack(0, h0, startTime, 0);
     uint32_t k, f0, n0c;
     tv.lookup(sc, k, f0, n0c);
     tv.putSt(tv.sid(sc, rfl(k), rfl(f0), si), 1);
   }
-  for (;;) {
-    if (nOpen == 0) {
-      res.status = ST_NO_SOLUTION;
-      break;
-    }
-    const uint64_t curE = ldU<T>(g.open, 0);
-    const uint32_t curId = T::id(curE);
-    const u32x4 nd = gNodes[curId];
-    const uint32_t cw = rfl(nd.x);
-    const uint32_t cell = cw & 0xFFFF, iv = cw >> 16;
-    const uint32_t gcur = rfl(nd.z);
-    const uint32_t cx = cell % dimx, cy = cell / dimx;
-    uint32_t ck, f0, nCur;
-    tv.lookup(cell, ck, f0, nCur);
-    ck = rfl(ck);
-    f0 = rfl(f0);
-    int32_t endT = kIntMax;
-    if (ck) endT = rfli(ivals[2 * (f0 + iv) + 1]);
-    const uint32_t curSid = tv.sid(cell, ck, f0, iv);
-    expansions += 1;
-    if (maxExp >= 0 && expansions > maxExp) {
-      res.status = ST_CAP_EXP;
-      break;
-    }
-    if (cx == gx && cy == gy && endT == kIntMax) {
-      // raw A* solution: (cell, g) per state; the host inserts the explicit Wait actions (sipp.hpp:105-128)
-      uint32_t len = 0;
-      for (uint32_t nid = curId; nid != kNoParent; nid = rfl(gNodes[nid].y)) len += 1;
-      if (len * 2 > P.out_stride) {
-        res.status = ST_CAP_HORIZON;
-        break;
-      }
-      uint32_t* out32 = (uint32_t*)outPath;
-      uint32_t nid = curId;
-      for (int32_t k = (int32_t)len - 1; k >= 0; --k) {
-        const u32x4 pn = gNodes[nid];
-        out32[k] = (rfl(pn.x) & 0xFFFF) | (rfl(pn.z) << 16);
-        nid = rfl(pn.y);
-      }
-      res.status = ST_OK;
-      res.cost = (int32_t)gcur;
-      res.fmin = (int32_t)T::f(curE);
-      res.n_states = (int32_t)len;
-      break;
-    }
-    heapPop<T, 0, true>(g, g.open, nOpen);
-    tv.putSt(curSid, SippView<RES>::kClosed);
-    const uint32_t startT = gcur + 1;
-    if (startT > kGMask) {
-      res.status = ST_CAP_HORIZON;
-      break;
-    }
-    bool fail = false;
-    // ---- neighbours.  Lanes 0..3 probe the four motions Up, Down, Left, Right at once (bounds, obstacle bit, the
-    // cell's safe-interval list); when no list is longer than 16 the intervals of all four cells are then evaluated on
-    // lanes 16*m + i together with their open/closed status — three dependent global round trips per expansion
-    // instead of three to five per motion.  Candidates are consumed in lane order, which IS the reference's order
-    // (motion-major, interval-minor, sipp.hpp:205-222).
-    uint32_t c4[4], f4[4], nc4[4], nk4[4], h4[4];
-    {
-      const uint32_t nxL = cx + (lane == 3) - (lane == 2), nyL = cy + (lane == 0) - (lane == 1);
-      const bool inbL = lane < 4 && nxL < dimx && nyL < dimy;
-      const uint32_t ncL = inbL ? nyL * dimx + nxL : 0;
-      uint32_t obstW = 0xFFFFFFFFu, nkL = 0, firstL = 0, cntL = 0;
-      if (inbL) {
-        obstW = obst[ncL >> 5];
-        tv.lookup(ncL, nkL, firstL, cntL);
-      }
-      const bool validL = inbL && !((obstW >> (ncL & 31)) & 1u);
-      if (!validL) cntL = 0;
-      const uint32_t hL = (nxL > gx ? nxL - gx : gx - nxL) + (nyL > gy ? nyL - gy : gy - nyL);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        c4[m] = __builtin_amdgcn_readlane(cntL, m);
-        f4[m] = __builtin_amdgcn_readlane(firstL, m);
-        nc4[m] = __builtin_amdgcn_readlane(ncL, m);
-        nk4[m] = __builtin_amdgcn_readlane(nkL, m);
-        h4[m] = __builtin_amdgcn_readlane(hL, m);
-      }
-    }
-    const uint32_t cMax = max(max(c4[0], c4[1]), max(c4[2], c4[3]));
-    if (cMax <= 16) {
-      const uint32_t mm = lane >> 4, i = lane & 15;
-      const uint32_t cntM = mm == 0 ? c4[0] : mm == 1 ? c4[1] : mm == 2 ? c4[2] : c4[3];
-      const uint32_t firstM = mm == 0 ? f4[0] : mm == 1 ? f4[1] : mm == 2 ? f4[2] : f4[3];
-      const uint32_t ncM = mm == 0 ? nc4[0] : mm == 1 ? nc4[1] : mm == 2 ? nc4[2] : nc4[3];
-      const uint32_t nkM = mm == 0 ? nk4[0] : mm == 1 ? nk4[1] : mm == 2 ? nk4[2] : nk4[3];
-      const uint32_t hM = mm == 0 ? h4[0] : mm == 1 ? h4[1] : mm == 2 ? h4[2] : h4[3];
-      const bool act = i < cntM;
-      int32_t siS = 0, siE = kIntMax;
-      const uint32_t sidL = tv.sid(ncM, nkM, firstM, i);
-      uint32_t stL = 0;
-      if (act) {
-        if (nkM) {
-          siS = ivals[2 * (firstM + i)];
-          siE = ivals[2 * (firstM + i) + 1];
-        }
-        stL = tv.getSt(sidL);
-      }
-      // sipp.hpp:209: skip if si.start - m_time > end_t || si.end < start_t
-      const bool cand = act && !((int64_t)siS - 1 > (int64_t)endT || siE < (int32_t)startT);
-      const uint32_t tArr = (uint32_t)(siS > (int32_t)startT ? siS : (int32_t)startT);
-      const uint64_t candMask = ballot64(cand);
-      const uint64_t lateMask = ballot64(cand && tArr > kGMask);
-      const uint64_t openMask = ballot64(cand && stL != 0 && !(stL & SippView<RES>::kClosed));   // already in the open list
-      const uint64_t newMask = ballot64(cand && stL == 0);
-      const uint32_t nNew = (uint32_t)__popcll(newMask);
-      if (lateMask) {
-        res.status = ST_CAP_HORIZON;
-        fail = true;
-      } else if (openMask == 0 && nNew <= 5) {
-        // the usual case — nothing to re-key: all pushes of the expansion in one round trip (PushChains)
-        if (nNodes + nNew > g.capNodes) {
-          res.status = ST_CAP_NODES;
-          fail = true;
-        } else if (nNew) {
-          uint64_t e[5];
-          uint64_t mk = newMask;
-#pragma unroll
-          for (uint32_t k = 0; k < 5; ++k) {
-            e[k] = 0;
-            if (k < nNew) {
-              const uint32_t l = (uint32_t)__builtin_ctzll(mk);
-              mk &= mk - 1;
-              const uint32_t t = __builtin_amdgcn_readlane(tArr, l);
-              const uint32_t sid = __builtin_amdgcn_readlane(sidL, l);
-              const uint32_t nc = __builtin_amdgcn_readlane(ncM, l);
-              const uint32_t hN = __builtin_amdgcn_readlane(hM, l);
-              const uint32_t nid = nNodes + k;
-              u32x4 nn;
-              nn.x = nc | ((l & 15u) << 16);
-              nn.y = curId;
-              nn.z = t;
-              nn.w = 0;
-              gNodes[nid] = nn;
-              tv.putSt(sid, nid + 1);
-              e[k] = T::pack(0, t + hN, t, nid);
-            }
-          }
-          const uint32_t pm = (1u << nNew) - 1u;
-          PushChains<T> pc;
-          pc.load(g.open, nOpen, pm);
-          pc.template resolve<0, true>(g, g.open, nOpen, pm, e);
-          nNodes += nNew;
-          nOpen += nNew;
-        }
+  int32_t rc = RUN_MIGRATE_NODES;
+  if constexpr (RES) {
+    if (ldsTier) {
+      // fast tier: nodes and open list in LDS (the table and the status words stay in HBM, one round trip per expansion)
+      typedef TierLdsWide TL;
+      Mem<TL> gl;
+      auto l8 = (__attribute__((address_space(3))) uint8_t*)ldsTier;
+      gl.nodes = (Mem<TL>::P32)l8;
+      gl.pos = nullptr;
+      gl.open = (Mem<TL>::PE)(l8 + (size_t)ldsNodes * 16 + 8);
+      gl.focal = nullptr;
+      gl.aux = nullptr;
+      gl.bits = nullptr;
+      gl.capNodes = ldsNodes; gl.capHeap = ldsNodes; gl.capRows = 0; gl.rowWords = 0;
+      ((Mem<TL>::PNode4)gl.nodes)[0] = n0;
+      gl.open[0] = e0;
+      __syncthreads();
+      const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
+      rc = sippLoop<TL, RES>(P, J, gl, tv, s, res, outPath);
+      res.prof[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);  // 100 MHz ticks / expansions in the LDS tier
+      res.prof[1] = (uint32_t)s.expansions;
+      if (rc == RUN_MIGRATE_NODES) {
+        __syncthreads();
+        auto srcN = (Mem<TL>::PNode4)gl.nodes;
+        for (uint32_t i = lane; i < s.nNodes; i += 64) gNodes[i] = srcN[i];
+        for (uint32_t i = lane; i < s.nOpen; i += 64) g.open[i] = gl.open[i];
+        __syncthreads();
+        res.tier = 2;  // started in LDS, finished in the arena
       } else {
-        uint64_t mask = candMask;
-        while (mask && !fail) {
-          const uint32_t l = (uint32_t)__builtin_ctzll(mask);
-          mask &= mask - 1;
-          const uint32_t t = __builtin_amdgcn_readlane(tArr, l);
-          const uint32_t sid = __builtin_amdgcn_readlane(sidL, l);
-          const uint32_t nc = __builtin_amdgcn_readlane(ncM, l);
-          const uint32_t hN = __builtin_amdgcn_readlane(hM, l);
-          const uint32_t st = __builtin_amdgcn_readlane(stL, l);
-          if (st & SippView<RES>::kClosed) continue;                   // closedSet.find (a_star.hpp:117)
-          if (st == 0) {                                   // new state (a_star.hpp:120-129)
-            if (nNodes >= g.capNodes) {
-              res.status = ST_CAP_NODES;
-              fail = true;
-              break;
-            }
-            const uint32_t nid = nNodes++;
-            u32x4 nn;
-            nn.x = nc | ((l & 15u) << 16);
-            nn.y = curId;
-            nn.z = t;
-            nn.w = 0;
-            gNodes[nid] = nn;
-            tv.putSt(sid, nid + 1);
-            siftUp<T, 0, true>(g, g.open, nOpen, T::pack(0, t + hN, t, nid));
-            nOpen += 1;
-          } else {                                         // already in open (a_star.hpp:130-146)
-            const uint32_t nid = st - 1;
-            const u32x4 on = gNodes[nid];
-            if (t >= rfl(on.z)) continue;
-            u32x4 nn = on;
-            nn.y = curId;
-            nn.z = t;
-            gNodes[nid] = nn;                             // cameFrom update + new g
-            siftUp<T, 0, true>(g, g.open, rfl(on.w), T::pack(0, t + hN, t, nid));  // increase(handle)
-          }
-        }
+        res.tier = 0;
       }
     } else {
-      // a cell with more than 16 safe intervals: one motion at a time, 64 intervals per pass
-      for (uint32_t m = 0; m < 4 && !fail; ++m) {  // Up, Down, Left, Right
-        const uint32_t nx = cx + (m == 3) - (m == 2), ny = cy + (m == 0) - (m == 1);
-        if (nx >= dimx || ny >= dimy) continue;
-        const uint32_t nc = ny * dimx + nx;
-        if ((rfl(obst[nc >> 5]) >> (nc & 31)) & 1u) continue;
-        uint32_t nk, first, cnt;
-        tv.lookup(nc, nk, first, cnt);
-        nk = rfl(nk);
-        first = rfl(first);
-        cnt = rfl(cnt);
-        const uint32_t hN = (nx > gx ? nx - gx : gx - nx) + (ny > gy ? ny - gy : gy - ny);
-        for (uint32_t base = 0; base < cnt && !fail; base += 64) {
-          const uint32_t i = base + lane;
-          int32_t siS = 0, siE = kIntMax;
-          if (nk && i < cnt) {
-            siS = ivals[2 * (first + i)];
-            siE = ivals[2 * (first + i) + 1];
-          }
-          // sipp.hpp:209: skip if si.start - m_time > end_t || si.end < start_t
-          const bool cand = (i < cnt) && !((int64_t)siS - 1 > (int64_t)endT || siE < (int32_t)startT);
-          const uint32_t tArr = (uint32_t)(siS > (int32_t)startT ? siS : (int32_t)startT);
-          uint64_t mask = ballot64(cand);
-          while (mask) {
-            const uint32_t l = (uint32_t)__builtin_ctzll(mask);
-            mask &= mask - 1;
-            const uint32_t ii = base + l;
-            const uint32_t t = __builtin_amdgcn_readlane(tArr, l);
-            if (t > kGMask) {
-              res.status = ST_CAP_HORIZON;
-              fail = true;
-              break;
-            }
-            const uint32_t sid = tv.sid(nc, nk, first, ii);
-            const uint32_t st = rfl(tv.getSt(sid));
-            if (st & SippView<RES>::kClosed) continue;                   // closedSet.find (a_star.hpp:117)
-            if (st == 0) {                                   // new state (a_star.hpp:120-129)
-              if (nNodes >= g.capNodes) {
-                res.status = ST_CAP_NODES;
-                fail = true;
-                break;
-              }
-              const uint32_t nid = nNodes++;
-              u32x4 nn;
-              nn.x = nc | (ii << 16);
-              nn.y = curId;
-              nn.z = t;
-              nn.w = 0;
-              gNodes[nid] = nn;
-              tv.putSt(sid, nid + 1);
-              siftUp<T, 0, true>(g, g.open, nOpen, T::pack(0, t + hN, t, nid));
-              nOpen += 1;
-            } else {                                         // already in open (a_star.hpp:130-146)
-              const uint32_t nid = st - 1;
-              const u32x4 on = gNodes[nid];
-              if (t >= rfl(on.z)) continue;
-              u32x4 nn = on;
-              nn.y = curId;
-              nn.z = t;
-              gNodes[nid] = nn;                             // cameFrom update + new g
-              siftUp<T, 0, true>(g, g.open, rfl(on.w), T::pack(0, t + hN, t, nid));  // increase(handle)
-            }
-          }
-        }
-      }
+      gNodes[0] = n0;
+      g.open[0] = e0;
     }
-    if (fail) break;
+  } else {
+    gNodes[0] = n0;
+    g.open[0] = e0;
   }
-  res.expanded = expansions;
-  res.nodes_created = nNodes;
-  res.tier = 1;
+  if (rc == RUN_MIGRATE_NODES) {
+    const uint64_t th0 = __builtin_amdgcn_s_memrealtime();
+    const int64_t e0h = s.expansions;
+    rc = sippLoop<TierHbm, RES>(P, J, g, tv, s, res, outPath);
+    res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);  // ... in the arena tier
+    res.prof[3] = (uint32_t)(s.expansions - e0h);
+    if (res.tier != 2) res.tier = 1;
+  }
+  res.status = rc;
+  res.expanded = s.expansions;
+  res.nodes_created = s.nNodes;
 }
 
 // Runs the job whose descriptor is at `jobSrc` (host memory) and writes result + path to host memory.
@@ -1650,8 +1784,11 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_search_kernel(Launch
 }
 
 // One SIPP job whose descriptor is at `jobSrc` (host memory): result + raw A* states back to host memory.
+// `ldsTier` (sessions): kSippLdsNodes node records + the open list, for jobs on device-resident tables.
+constexpr uint32_t kSippLdsNodes = 1024;
+constexpr uint32_t kSippLdsBytes = kSippLdsNodes * 16 + kSippLdsNodes * 8 + 16;
 DEVI void processSippJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* resDst, uint16_t* pathDst,
-                         uint8_t* arenaSlot, DevJob& jobS, DevResult& resS) {
+                         uint8_t* arenaSlot, uint8_t* ldsTier, DevJob& jobS, DevResult& resS) {
   const uint32_t lane = threadIdx.x;
   __syncthreads();
   {
@@ -1664,12 +1801,17 @@ DEVI void processSippJob(const LaunchParams& P, const DevJob* jobSrc, DevResult*
   res.tier = 1;
   for (int q = 0; q < 8; ++q) res.prof[q] = 0;
   uint16_t* outPath = (uint16_t*)(arenaSlot + P.arena_scratch_off);
+  const uint64_t tj0 = __builtin_amdgcn_s_memrealtime();
   if (rfl(jobS.algo) == 2) {  // anything else stays ST_BAD
-    if (rfl(jobS.ctx_flags) & kSippResident)
-      runSipp<true>(P, jobS, arenaSlot, res, outPath);
-    else
-      runSipp<false>(P, jobS, arenaSlot, res, outPath);
+    if (rfl(jobS.ctx_flags) & kSippResident) {
+      if (ldsTier)  // sessions only (else ST_BAD)
+        runSipp<true>(P, jobS, arenaSlot, (rfl(jobS.ctx_flags) & kSippNoLds) ? nullptr : ldsTier, kSippLdsNodes, res, outPath);
+    } else {
+      runSipp<false>(P, jobS, arenaSlot, nullptr, 0, res, outPath);
+    }
   }
+  res.prof[4] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tj0);  // the whole of runSipp (table update + search)
+  res.prof[5] = 1;
   __syncthreads();
   resS = res;
   __syncthreads();
@@ -1693,7 +1835,7 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams
     uint32_t j = atomicAdd(P.queue_head, lane == 0 ? 1u : 0u);
     j = rfl(j) - P.queue_base;
     if (j >= P.n_jobs) break;
-    processSippJob(P, P.jobs + j, P.results + j, P.out_paths + (size_t)j * P.out_stride, arenaSlot, jobS, resS);
+    processSippJob(P, P.jobs + j, P.results + j, P.out_paths + (size_t)j * P.out_stride, arenaSlot, nullptr, jobS, resS);
   }
 }
 
@@ -1772,7 +1914,8 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
     idleTicks += t1c - t0;
     if (stop) break;
     if (SIPP)
-      processSippJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, arenaSlot, jobS, resS);
+      processSippJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, arenaSlot, smem, jobS,
+                     resS);
     else
       processJob<KIND>(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, smem, arenaSlot,
                        jobS, resS);
@@ -1812,12 +1955,14 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_persistent_kernel(La
   residentLoop<false, 2>(P, smem, jobS, resS);
 }
 
-// The same resident loop for SIPP sessions (jobs of algo MRP_LL_SIPP only; no LDS tier).
+// The same resident loop for SIPP sessions (jobs of algo MRP_LL_SIPP only).  24.6 KB of LDS per workgroup hold the nodes
+// and the open list of searches on device-resident tables (6 workgroups per CU).
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_persistent_kernel(LaunchParams Parg) {
+  __shared__ __attribute__((aligned(16))) uint8_t sippTier[kSippLdsBytes];
   __shared__ DevJob jobS;
   __shared__ DevResult resS;
   MRP_LL_STAGE_PARAMS(P, Parg);
-  residentLoop<true, 0>(P, nullptr, jobS, resS);
+  residentLoop<true, 0>(P, sippTier, jobS, resS);
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize (a workgroup may take up to the CU's 160 KiB minus the static jobS/resS) for

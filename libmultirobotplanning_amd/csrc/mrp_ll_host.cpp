@@ -387,6 +387,7 @@ struct mrp_ll_sipp_table {
   struct Spec {
     std::vector<int32_t> collisions;                  // [n][2] in the order they were added
     std::vector<SippScratch::Iv> safe;
+    bool disjoint = true;                             // no two collision intervals of the cell have overlapped so far
   };
   std::vector<Spec> spec;
   uint32_t totalSafe = 0;
@@ -499,7 +500,11 @@ bool packSippResident(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, Co
   d.max_expansions = j.max_expansions;
   d.n_agents_pad = static_cast<uint32_t>(addr);
   d.path_off = static_cast<uint32_t>(addr >> 32);
-  d.ctx_flags = mrp::kSippResident;
+  static const bool noLds = [] {
+    const char* e = std::getenv("MRP_LL_SIPP_NO_LDS");  // tier comparison (tests, probes)
+    return e && *e == '1';
+  }();
+  d.ctx_flags = mrp::kSippResident | (noLds ? mrp::kSippNoLds : 0u);
   d.n_ctx = T.epoch;
   d.n_vc = static_cast<uint32_t>(T.spec.size());
   d.n_ec = T.totalSafe;
@@ -507,13 +512,16 @@ bool packSippResident(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, Co
   d.last_goal_constraint = startTime;
   const int sc = j.start_y * mp.dimx + j.start_x;
   int startIv = -1;
+  d.reserved = 0;  // 1: the start interval ends at INT_MAX (the kernel keeps that bit in its node records)
   if (!T.cellIdx[sc]) {
     startIv = 0;
+    d.reserved = 1;
   } else {
     const auto& v = T.spec[T.cellIdx[sc] - 1].safe;
     for (size_t k = 0; k < v.size(); ++k)
       if (v[k].s <= startTime && v[k].e >= startTime) {
         startIv = static_cast<int>(k);
+        d.reserved = v[k].e == INT32_MAX ? 1u : 0u;
         break;
       }
   }
@@ -1687,11 +1695,41 @@ int mrp_ll_sipp_table_add(mrp_ll_sipp_table* t, int32_t x, int32_t y, int32_t st
     t->cellIdx16[cell] = static_cast<uint16_t>(t->spec.size());
   }
   mrp_ll_sipp_table::Spec& sp = t->spec[t->cellIdx[cell] - 1];
+  const bool first = sp.collisions.empty();
   sp.collisions.push_back(start);
   sp.collisions.push_back(end);
   t->totalSafe -= static_cast<uint32_t>(sp.safe.size());
-  sp.safe.clear();
-  safeFromCollisions(sp.collisions.data(), static_cast<int>(sp.collisions.size() / 2), t->scratch, sp.safe);
+  // The usual case (a planner adds the stays of a path that avoided every earlier one): the new collision interval lies
+  // inside ONE safe interval, and sorting it into the list splits exactly that gap — [a, start - 1] if non-empty and
+  // [end + 1, b] if non-empty — which is what setCollisionIntervals' loop (sipp.hpp:258-277) yields for the longer list.
+  // Anything else (overlaps, start > end) recomputes the cell from all its collision intervals, as before.
+  bool split = false;
+  if (first) sp.safe.assign(1, SippScratch::Iv{0, INT32_MAX});
+  if (sp.disjoint && start <= end && start >= 0) {
+    for (size_t k = 0; k < sp.safe.size(); ++k) {
+      const SippScratch::Iv g = sp.safe[k];
+      if (g.s <= start && end <= g.e) {
+        const bool left = g.s <= start - 1, right = end < g.e;
+        if (left && right) {
+          sp.safe[k].e = start - 1;
+          sp.safe.insert(sp.safe.begin() + k + 1, SippScratch::Iv{end + 1, g.e});
+        } else if (left) {
+          sp.safe[k].e = start - 1;
+        } else if (right) {
+          sp.safe[k].s = end + 1;
+        } else {
+          sp.safe.erase(sp.safe.begin() + k);
+        }
+        split = true;
+        break;
+      }
+    }
+  }
+  if (!split) {
+    sp.disjoint = false;
+    sp.safe.clear();
+    safeFromCollisions(sp.collisions.data(), static_cast<int>(sp.collisions.size() / 2), t->scratch, sp.safe);
+  }
   t->totalSafe += static_cast<uint32_t>(sp.safe.size());
   if (sp.safe.size() > mrp::kSippCap) t->overflow = true;  // from now on this table travels whole (packSippFromTable)
   if (!t->isDirty[cell]) {

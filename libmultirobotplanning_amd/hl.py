@@ -309,8 +309,9 @@ class BatchSolver:
         finally:
             self.release(prep)
 
-    def prioritized_sipp(self, instances: Sequence[Dict], state_cap: int = 512):
-        """example/mapf_prioritized_sipp.cpp for a batch of instances: every round plans the next agent of all of them."""
+    def prioritized_sipp(self, instances: Sequence[Dict], state_cap: int = 512, want_schedules: bool = True):
+        """example/mapf_prioritized_sipp.cpp for a batch of instances: every round plans the next agent of all of them.
+        want_schedules=False leaves the per-agent state lists out of the returned dicts (benchmarks)."""
         n = len(instances)
         cin = (mrp_hl_instance * max(n, 1))()
         csol = (mrp_hl_sipp_solution * max(n, 1))()
@@ -339,7 +340,8 @@ class BatchSolver:
         for i in range(n):
             pl, ns, sx = bufs[i]
             out.append(dict(cost=csol[i].cost, expanded=csol[i].low_level_expanded, n_planned=csol[i].n_planned,
-                            planned=pl.tolist(), schedules=[sx[a, :ns[a]].tolist() for a in range(len(pl))]))
+                            planned=pl.tolist(),
+                            schedules=[sx[a, :ns[a]].tolist() for a in range(len(pl))] if want_schedules else None))
         stats = dict(wall_seconds=st.wall_seconds, rounds=st.rounds, ll_searches=st.ll_searches,
                      ll_expansions=st.ll_expansions, solved=st.solved)
         return out, stats

@@ -20,6 +20,9 @@ for rep in range(2):
     print("   engine totals over %d threads: launches %d, kernel %.1f ms, pack %.1f ms, unpack %.1f ms; resident workgroups busy %.1f s, waiting %.1f s" % (
         threads, ls["launches"], ls["kernel_ms"], ls["pack_ms"], ls["unpack_ms"], ls["session_busy_ms"] / 1e3,
         ls["session_idle_ms"] / 1e3), flush=True)
+    pf = ls["prof"]
+    print("   SIPP kernel: LDS tier %.2f us/expansion over %.3g expansions, arena tier %.2f us/expansion over %.3g; runSipp %.1f us/job over %d jobs" % (
+        pf[0] / 100.0 / max(pf[1], 1), pf[1], pf[2] / 100.0 / max(pf[3], 1), pf[3], pf[4] / 100.0 / max(pf[5], 1), pf[5]), flush=True)
     print("rep %d: %d instances x %d agents: wall %.3f s, %.3e exp/s, %.1f inst/s, rounds %d searches %d planned-all %d" % (
         rep, n, agents, st["wall_seconds"], st["ll_expansions"] / st["wall_seconds"], n / st["wall_seconds"], st["rounds"],
         st["ll_searches"], st["solved"]), flush=True)

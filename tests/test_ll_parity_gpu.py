@@ -616,15 +616,21 @@ def test_sipp_device_resident_tables(oracle_mod):
 
         def add(self, c, a=None, n=1):
             for _ in range(n):
-                t = self.next_t.get(tuple(c), rng.randrange(0, 30))
-                a0 = t + rng.randrange(0, 5)
-                b0 = a0 + rng.randrange(0, 4)
+                if n == 1 and rng.random() < 0.3:         # somewhere before / between the cell's earlier intervals
+                    a0 = rng.randrange(0, 60)
+                    b0 = a0 + rng.randrange(0, 3)
+                    if any(a0 <= q[1] and q[0] <= b0 for q in self.cis.get(tuple(c), [])):
+                        continue                          # the reference asserts that intervals do not overlap
+                else:
+                    t = self.next_t.get(tuple(c), rng.randrange(0, 30))
+                    a0 = t + rng.randrange(0, 5)
+                    b0 = a0 + rng.randrange(0, 4)
                 self.cis.setdefault(tuple(c), []).append([a0, b0])
-                self.next_t[tuple(c)] = b0 + 2 + rng.randrange(0, 3)
+                self.next_t[tuple(c)] = max(self.next_t.get(tuple(c), 0), b0 + 2 + rng.randrange(0, 3))
                 eng.sipp_table_add(self.h, c[0], c[1], a0, b0)
 
         def flat(self):
-            return [[c[0], c[1], a, b] for c, v in sorted(self.cis.items()) for a, b in v]
+            return [[c[0], c[1], a, b] for c, v in sorted(self.cis.items()) for a, b in sorted(v)]
 
     def check(tab, st, go, t0, r):
         o_states, o_exp, o_cost, o_fmin = oracle_mod.sipp_single_at(dim, dim, obst, st, go, tab.flat(), start_time=t0)
