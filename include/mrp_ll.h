@@ -110,7 +110,12 @@ typedef struct mrp_ll_job {
    *                      start cell is looked up at this time, state times are absolute, cost = arrival - startTime
    *   MRP_LL_ASTAR_EPS : AStarEpsilon::search has no such argument: a non-zero value is rejected (MRP_LL_BAD_JOB) */
   int32_t initial_cost;
-  int32_t reserved;
+  /* MRP_LL_SIPP with sipp_table: 1 = when the search succeeds, the stays of the path it found become collision
+   * intervals of the table — [t_k, t_{k+1} - 1] on the k-th cell of the path, [t_last, INT32_MAX] on the last — exactly
+   * the mrp_ll_sipp_table_add calls a prioritized planner makes with the solution (mapf_prioritized_sipp.cpp:237-246),
+   * done by the engine (in a session: by the workgroup that ran the search, on the device-resident table).  The table
+   * then has ONE user at a time: the next job on it is submitted after this one's result has been collected. */
+  int32_t sipp_commit;
   /* MRP_LL_SIPP only, optional: an incrementally maintained table (mrp_ll_sipp_table_*) instead of the collision_*
    * arrays above (which are then ignored).  The table must stay unchanged until the job has been submitted. */
   const struct mrp_ll_sipp_table* sipp_table;

@@ -1046,7 +1046,6 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
     mrp_ll_sipp_table* tab = nullptr;
     std::vector<int32_t> states;
     mrp_ll_result res;
-    void add(int32_t x, int32_t y, Iv iv) { (void)mrp_ll_sipp_table_add(tab, x, y, iv.s, iv.e); }
   };
   const size_t n = idx.size();
   const int32_t cap = std::max(horizon, 64);
@@ -1097,6 +1096,7 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
     j.goal_y = in.goals_xy[2 * p.agent + 1];
     j.max_expansions = -1;
     j.sipp_table = p.tab;  // sipp.setCollisionIntervals(location, intervals) for every location (:224-226), kept up to date
+    j.sipp_commit = 1;     // ... by the engine: the stays of the path it finds become collision intervals (:237-246)
     std::memset(&p.res, 0, sizeof(p.res));
     p.res.states_txy = p.states.data();
     p.res.states_cap = cap;
@@ -1118,10 +1118,18 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
   int64_t maxAgents = 0;
   auto t0 = std::chrono::steady_clock::now();
   uint64_t idleSpins = 0;
+  static const bool timing = std::getenv("MRP_HL_SIPP_TIMING") != nullptr;  // where a worker thread's time goes
+  double tSubmit = 0, tPoll = 0, tConsume = 0;
+  uint64_t nPolls = 0, nEmptyPolls = 0;
+  auto clk = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count();
+  };
   bool sinceProgress = false;
   auto lastProgress = t0;
   while (!failed && (nInflight != 0 || !backlog.empty())) {
     bool progress = false;
+    auto tA = timing ? clk() : t0;
     while (!backlog.empty()) {
       const size_t q = backlog.back();
       int r = submit(q);
@@ -1135,10 +1143,18 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
     }
     if (failed) break;
     int32_t nDone = 0;
+    auto tB = timing ? clk() : t0;
     if (mrp_ll_poll_any(ctx, doneTickets.data(), static_cast<int32_t>(doneTickets.size()), &nDone) != MRP_LL_SUCCESS) {
       out.err = std::string("mrp_ll_poll_any: ") + mrp_ll_last_error(ctx);
       failed = true;
       break;
+    }
+    auto tC = timing ? clk() : t0;
+    if (timing) {
+      tSubmit += secs(tA, tB);
+      tPoll += secs(tB, tC);
+      nPolls += 1;
+      nEmptyPolls += nDone == 0 ? 1 : 0;
     }
     doneOwners.resize(nDone);
     for (int32_t d = 0; d < nDone; ++d) doneOwners[d] = ticketOwner[doneTickets[d]];
@@ -1165,17 +1181,8 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
         so.n_planned += 1;
         so.cost += r.cost;
         const int32_t* S = r.states_txy;  // [t, x, y]
-        int32_t lx = S[1], ly = S[2], lt = S[0];  // collision intervals (:237-246): one per maximal stay on a cell
-        for (int32_t i = 1; i < r.n_states; ++i) {
-          if (S[3 * i + 1] != lx || S[3 * i + 2] != ly) {
-            p.add(lx, ly, Iv{lt, S[3 * i] - 1});
-            lx = S[3 * i + 1];
-            ly = S[3 * i + 2];
-            lt = S[3 * i];
-          }
-        }
-        const int32_t last = r.n_states - 1;
-        p.add(S[3 * last + 1], S[3 * last + 2], Iv{S[3 * last], INT32_MAX});
+        // (the collision intervals of this path, :237-246 — one per maximal stay on a cell — are already in the table:
+        // sipp_commit)
         if (so.states_xyt)
           for (int32_t i = 0; i < r.n_states && i < so.state_cap; ++i) {
             int32_t* dst = so.states_xyt + (static_cast<size_t>(a) * so.state_cap + i) * 3;
@@ -1199,6 +1206,7 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
         }
       }
     }
+    if (timing) tConsume += secs(tC, clk());
     if (progress) {
       idleSpins = 0;
       sinceProgress = false;
@@ -1215,6 +1223,10 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
   }
   if (mrp_ll_session_end(ctx) != MRP_LL_SUCCESS && out.err.empty())
     out.err = std::string("mrp_ll_session_end: ") + mrp_ll_last_error(ctx);
+  if (timing)
+    std::fprintf(stderr, "[mrp_hl] sipp worker: %.1f ms total; submit %.1f ms, poll_any %.1f ms (%llu calls, %llu empty), consume %.1f ms\n",
+                 secs(t0, clk()) * 1e3, tSubmit * 1e3, tPoll * 1e3, (unsigned long long)nPolls,
+                 (unsigned long long)nEmptyPolls, tConsume * 1e3);
   out.rounds = maxAgents;  // longest chain of dependent searches
 }
 

@@ -59,8 +59,12 @@ constexpr uint32_t kCtxById = 1u;
 //   status[cells][kSippCap] words  epoch << 24 | closed << 23 | node + 1   (a word of another epoch reads as "unseen").
 // cons[vc_off] holds only the DELTA since the table's previous job: ec_off & 0x7FFFFFFF records (bit 31: zero cnt and
 // status first), as  hdr[nRec]  (cell | count << 16; padded to a multiple of 4 words)  then  nRec x kSippCap x {start, end}.
-// n_ctx = the job's epoch (1..255).  One job per table in flight.
+// n_ctx = the job's epoch (1..255).  One job per table in flight.  The workgroup finds the start interval itself
+// (findSafeInterval, sipp.hpp:286-296) — the host's copy of the table may be behind the device's (kSippCommit).
 constexpr uint32_t kSippResident = 2u;
+constexpr uint32_t kSippCommit = 8u;                               // ctx_flags bit 3: on success the workgroup adds the path's stays to the table
+constexpr uint32_t kSippTierCommitFailed = 0x100u;                 // DevResult.tier flag: a stay did not fit (more than kSippCap intervals,
+                                                                   // or no safe interval contains it): the host redoes the table
 constexpr uint32_t kSippNoLds = 4u;                                // ctx_flags bit 2: keep nodes and open list in the arena (MRP_LL_SIPP_NO_LDS=1)
 constexpr uint32_t kSippCap = 8;                                   // safe intervals per cell the resident layout holds
 constexpr uint32_t kSippEpochShift = 24, kSippEpochMax = 255;

@@ -120,34 +120,39 @@ struct TierHbm {
   DEVI static E shr1(E v) { return ((uint64_t)waveShr1((uint32_t)(v >> 32)) << 32) | waveShr1((uint32_t)v); }
 };
 
-struct TierLds {
+template <uint32_t ID, uint32_t GBITS, uint32_t FBITS, uint32_t FHBITS>
+struct TierLdsT {
   static constexpr int AS = 3;
   static constexpr bool kWideNodes = false;  // one word per node + a halfword position array
   typedef uint32_t E;
   typedef u32x2 Pair;
-  static constexpr uint32_t kIdBits = 9, kGB = 6, kFB = 7, kFhB = 10;
+  static constexpr uint32_t kIdBits = ID, kGB = GBITS, kFB = FBITS, kFhB = FHBITS;
   static constexpr uint32_t kMaxNodes = 1u << kIdBits, kMaxRows = 1u << kGB, kFCap = (1u << kFB) - 1;
   static constexpr uint32_t kFhCap = (1u << kFhB) - 1;
   DEVI static E pack(uint32_t fh, uint32_t f, uint32_t g, uint32_t id) {
-    return ((kFhCap - fh) << (kIdBits + kGB + kFB)) | ((kFCap - f) << (kIdBits + kGB)) | (g << kIdBits) | id;
+    E e = ((kFCap - f) << (kIdBits + kGB)) | (g << kIdBits) | id;
+    if constexpr (kFhB != 0) e |= (kFhCap - fh) << (kIdBits + kGB + kFB);
+    return e;
   }
   DEVI static uint32_t keyFocal(E e) { return e >> kIdBits; }
   DEVI static uint32_t keyOpen(E e) { return (e >> kIdBits) & ((1u << (kGB + kFB)) - 1u); }
   DEVI static uint32_t id(E e) { return e & (kMaxNodes - 1u); }
   DEVI static uint32_t f(E e) { return kFCap - ((e >> (kIdBits + kGB)) & kFCap); }
   DEVI static uint32_t g(E e) { return (e >> kIdBits) & (kMaxRows - 1u); }
-  DEVI static uint32_t fh(E e) { return kFhCap - (e >> (kIdBits + kGB + kFB)); }
+  DEVI static uint32_t fh(E e) {
+    if constexpr (kFhB != 0) return kFhCap - (e >> (kIdBits + kGB + kFB));
+    return 0;
+  }
   DEVI static E aux(uint32_t openKey, uint32_t idx) { return (openKey << kIdBits) | idx; }  // idx < 256
   DEVI static uint32_t auxIdx(E e) { return e & (kMaxNodes - 1u); }
   DEVI static E first(E v) { return rfl(v); }
   DEVI static E fromLane(E v, uint32_t srcLane) { return __builtin_amdgcn_readlane(v, srcLane); }
   DEVI static E shr1(E v) { return waveShr1(v); }
 };
-
-// TierHbm's records in LDS: the SIPP fast tier (times do not fit TierLds' 6-bit g / 7-bit f)
-struct TierLdsWide : TierHbm {
-  static constexpr int AS = 3;
-};
+// CBS / ECBS fast tier: [31:22] 1023 - focalH, [21:15] 127 - f, [14:9] g, [8:0] node
+typedef TierLdsT<9, 6, 7, 10> TierLds;
+// SIPP fast tier: [31:21] 2047 - f, [20:11] g (arrival time, <= kGMask), [10:0] node — the whole open key of TierHbm
+typedef TierLdsT<11, kGBits, kFBits, 0> TierLdsSipp;
 
 template <class T>
 struct Mem {
@@ -159,6 +164,7 @@ struct Mem {
   typedef __attribute__((address_space(T::AS))) u32x4* PNode4;
   P32 nodes;     // TierLds: one word per node; TierHbm: four words per node
   P16 pos;       // TierLds only: position of the node's entry in the open array
+  P16 gOf;       // TierLdsSipp only: arrival time of the node
   PE open;       // biased: element i at open[i] (the pointer already includes the +1 bias)
   PE focal;
   PE aux;        // std::priority_queue of the ordered walk
@@ -1129,6 +1135,70 @@ struct SippView {
   DEVI void putSt(uint32_t id, uint32_t v) const { status[id] = RES ? (v | epochBits) : v; }
 };
 
+// SIPP node records.  Arena tier: u32x4 { x = cell | interval << 16 | (RES: interval ends at INT_MAX) << 31, parent, g,
+// position of the open entry }.  TierLdsSipp: one word  cell | interval << 16 | endsAtInf << 19 | parent << 20  (interval
+// < kSippCap = 8; parent < 2047, 0x7FF = none), g in Mem::gOf, the position in Mem::pos.
+constexpr uint32_t kSippNoParentLds = 0x7FFu;
+template <class T>
+DEVI uint32_t sippNodeX(Mem<T>& m, uint32_t id) {
+  if constexpr (T::kWideNodes) {
+    return rfl(((typename Mem<T>::PNode4)m.nodes)[id].x);
+  } else {
+    const uint32_t w = rfl(m.nodes[id]);
+    return (w & 0x7FFFFu) | ((w >> 19) & 1u) << 31;
+  }
+}
+template <class T>
+DEVI void sippNodeNew(Mem<T>& m, uint32_t id, uint32_t x, uint32_t parent, uint32_t t) {
+  if constexpr (T::kWideNodes) {
+    u32x4 nn;
+    nn.x = x;
+    nn.y = parent;
+    nn.z = t;
+    nn.w = 0;
+    ((typename Mem<T>::PNode4)m.nodes)[id] = nn;
+  } else {
+    m.nodes[id] = (x & 0x7FFFFu) | (x >> 31) << 19 | (parent & kSippNoParentLds) << 20;
+    m.gOf[id] = (uint16_t)t;
+  }
+}
+// g and open position of a node that is in the open list (decrease-key, a_star.hpp:130-146)
+template <class T>
+DEVI void sippNodeGPos(Mem<T>& m, uint32_t id, uint32_t& gOld, uint32_t& pos) {
+  if constexpr (T::kWideNodes) {
+    const u32x4 on = ((typename Mem<T>::PNode4)m.nodes)[id];
+    gOld = rfl(on.z);
+    pos = rfl(on.w);
+  } else {
+    gOld = rfl((uint32_t)m.gOf[id]);
+    pos = rfl((uint32_t)m.pos[id]);
+  }
+}
+template <class T>
+DEVI void sippNodeReparent(Mem<T>& m, uint32_t id, uint32_t parent, uint32_t t) {  // cameFrom update + new g
+  if constexpr (T::kWideNodes) {
+    m.nodes[id * 4 + 1] = parent;
+    m.nodes[id * 4 + 2] = t;
+  } else {
+    m.nodes[id] = (rfl(m.nodes[id]) & 0xFFFFFu) | (parent & kSippNoParentLds) << 20;
+    m.gOf[id] = (uint16_t)t;
+  }
+}
+template <class T>
+DEVI void sippNodePath(Mem<T>& m, uint32_t id, uint32_t& cell, uint32_t& gN, uint32_t& parent) {
+  if constexpr (T::kWideNodes) {
+    const u32x4 pn = ((typename Mem<T>::PNode4)m.nodes)[id];
+    cell = rfl(pn.x) & 0xFFFFu;
+    gN = rfl(pn.z);
+    parent = rfl(pn.y);
+  } else {
+    const uint32_t w = rfl(m.nodes[id]);
+    cell = w & 0xFFFFu;
+    gN = rfl((uint32_t)m.gOf[id]);
+    parent = (w >> 20) == kSippNoParentLds ? kNoParent : (w >> 20);
+  }
+}
+
 struct SippState {  // wave-uniform
   uint32_t nNodes, nOpen;
   int64_t expansions;
@@ -1146,7 +1216,6 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
   const int64_t maxExp = J.max_expansions;
   const uint32_t* obst = P.maps + J.map_word_off;
   const int32_t* ivals = tv.ivals;
-  typename Mem<T>::PNode4 gNodes = (typename Mem<T>::PNode4)g.nodes;
   uint32_t& nNodes = s.nNodes;
   uint32_t& nOpen = s.nOpen;
   int64_t& expansions = s.expansions;
@@ -1155,12 +1224,11 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
       res.status = ST_NO_SOLUTION;
       break;
     }
-    const uint64_t curE = ldU<T>(g.open, 0);
+    const typename T::E curE = ldU<T>(g.open, 0);
     const uint32_t curId = T::id(curE);
-    const u32x4 nd = gNodes[curId];
-    const uint32_t cw = rfl(nd.x);
+    const uint32_t cw = sippNodeX<T>(g, curId);
     const uint32_t cell = cw & 0xFFFF, iv = RES ? (cw >> 16) & 0x7FFFu : cw >> 16;
-    const uint32_t gcur = rfl(nd.z);
+    const uint32_t gcur = T::g(curE);  // == the node's g: every entry is packed with it
     const uint32_t cx = cell % dimx, cy = cell / dimx;
     // RES: every table word this expansion needs has an address that follows from (cell, iv) alone — the cell's own
     // list length and interval end, and for the four neighbours (lanes 16 * motion + i) the obstacle word, the list
@@ -1206,7 +1274,12 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
     if (cx == gx && cy == gy && endT == kIntMax) {
       // raw A* solution: (cell, g) per state; the host inserts the explicit Wait actions (sipp.hpp:105-128)
       uint32_t len = 0;
-      for (uint32_t nid = curId; nid != kNoParent; nid = rfl(gNodes[nid].y)) len += 1;
+      for (uint32_t nid = curId; nid != kNoParent;) {
+        uint32_t pc, pg, pp;
+        sippNodePath<T>(g, nid, pc, pg, pp);
+        nid = pp;
+        len += 1;
+      }
       if (len * 2 > P.out_stride) {
         res.status = ST_CAP_HORIZON;
         break;
@@ -1214,9 +1287,10 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
       uint32_t* out32 = (uint32_t*)outPath;
       uint32_t nid = curId;
       for (int32_t k = (int32_t)len - 1; k >= 0; --k) {
-        const u32x4 pn = gNodes[nid];
-        out32[k] = (rfl(pn.x) & 0xFFFF) | (rfl(pn.z) << 16);
-        nid = rfl(pn.y);
+        uint32_t pc, pg, pp;
+        sippNodePath<T>(g, nid, pc, pg, pp);
+        out32[k] = pc | (pg << 16);
+        nid = pp;
       }
       res.status = ST_OK;
       res.cost = (int32_t)gcur;
@@ -1321,7 +1395,7 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
           res.status = ST_CAP_NODES;
           fail = true;
         } else if (nNew) {
-          uint64_t e[5];
+          typename T::E e[5];
           uint64_t mk = newMask;
 #pragma unroll
           for (uint32_t k = 0; k < 5; ++k) {
@@ -1334,12 +1408,8 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
               const uint32_t nc = __builtin_amdgcn_readlane(ncM, l);
               const uint32_t hN = __builtin_amdgcn_readlane(hM, l);
               const uint32_t nid = nNodes + k;
-              u32x4 nn;
-              nn.x = nc | ((l & 15u) << 16) | (RES ? __builtin_amdgcn_readlane(siE == kIntMax ? 1u : 0u, l) << 31 : 0u);
-              nn.y = curId;
-              nn.z = t;
-              nn.w = 0;
-              gNodes[nid] = nn;
+              sippNodeNew<T>(g, nid, nc | ((l & 15u) << 16) | (RES ? __builtin_amdgcn_readlane(siE == kIntMax ? 1u : 0u, l) << 31 : 0u),
+                             curId, t);
               tv.putSt(sid, nid + 1);
               e[k] = T::pack(0, t + hN, t, nid);
             }
@@ -1369,24 +1439,18 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
               break;
             }
             const uint32_t nid = nNodes++;
-            u32x4 nn;
-            nn.x = nc | ((l & 15u) << 16) | (RES ? __builtin_amdgcn_readlane(siE == kIntMax ? 1u : 0u, l) << 31 : 0u);
-            nn.y = curId;
-            nn.z = t;
-            nn.w = 0;
-            gNodes[nid] = nn;
+            sippNodeNew<T>(g, nid, nc | ((l & 15u) << 16) | (RES ? __builtin_amdgcn_readlane(siE == kIntMax ? 1u : 0u, l) << 31 : 0u),
+                           curId, t);
             tv.putSt(sid, nid + 1);
             siftUp<T, 0, true>(g, g.open, nOpen, T::pack(0, t + hN, t, nid));
             nOpen += 1;
           } else {                                         // already in open (a_star.hpp:130-146)
             const uint32_t nid = st - 1;
-            const u32x4 on = gNodes[nid];
-            if (t >= rfl(on.z)) continue;
-            u32x4 nn = on;
-            nn.y = curId;
-            nn.z = t;
-            gNodes[nid] = nn;                             // cameFrom update + new g
-            siftUp<T, 0, true>(g, g.open, rfl(on.w), T::pack(0, t + hN, t, nid));  // increase(handle)
+            uint32_t gOld, posOld;
+            sippNodeGPos<T>(g, nid, gOld, posOld);
+            if (t >= gOld) continue;
+            sippNodeReparent<T>(g, nid, curId, t);
+            siftUp<T, 0, true>(g, g.open, posOld, T::pack(0, t + hN, t, nid));  // increase(handle)
           }
         }
       }
@@ -1434,24 +1498,17 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
                 break;
               }
               const uint32_t nid = nNodes++;
-              u32x4 nn;
-              nn.x = nc | (ii << 16);
-              nn.y = curId;
-              nn.z = t;
-              nn.w = 0;
-              gNodes[nid] = nn;
+              sippNodeNew<T>(g, nid, nc | (ii << 16), curId, t);
               tv.putSt(sid, nid + 1);
               siftUp<T, 0, true>(g, g.open, nOpen, T::pack(0, t + hN, t, nid));
               nOpen += 1;
             } else {                                         // already in open (a_star.hpp:130-146)
               const uint32_t nid = st - 1;
-              const u32x4 on = gNodes[nid];
-              if (t >= rfl(on.z)) continue;
-              u32x4 nn = on;
-              nn.y = curId;
-              nn.z = t;
-              gNodes[nid] = nn;                             // cameFrom update + new g
-              siftUp<T, 0, true>(g, g.open, rfl(on.w), T::pack(0, t + hN, t, nid));  // increase(handle)
+              uint32_t gOld, posOld;
+              sippNodeGPos<T>(g, nid, gOld, posOld);
+              if (t >= gOld) continue;
+              sippNodeReparent<T>(g, nid, curId, t);
+              siftUp<T, 0, true>(g, g.open, posOld, T::pack(0, t + hN, t, nid));  // increase(handle)
             }
           }
         }
@@ -1460,6 +1517,111 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
     if (fail) return res.status;
   }
   return res.status;
+}
+
+// sipp_commit (mrp_ll.h): the stays of the path just found — state k = (cell, arrival t_k) occupies its cell during
+// [t_k, t_{k+1} - 1], the last one during [t_last, INT_MAX] — become collision intervals of the resident table, i.e. each
+// splits the safe interval that contains it (what SIPP::setCollisionIntervals, sipp.hpp:245-284, yields for the longer
+// collision list; the stay lies inside ONE safe interval because the search kept the agent there).  One lane per state,
+// 64 states per pass; lanes whose states share a cell take turns.  Returns false if a cell would need more than kSippCap
+// intervals or a stay is not inside a safe interval: the table is then left half-updated and the host redoes it.
+DEVI bool sippCommitPath(const SippView<true>& tv, const uint32_t* path, uint32_t len) {
+  const uint32_t lane = threadIdx.x;
+  uint8_t* cnt8 = (uint8_t*)tv.cnt;
+  bool bad = false;
+  for (uint32_t base = 0; base < len; base += 64) {
+    const uint32_t k = base + lane;
+    const bool act = k < len;
+    const uint32_t w = act ? path[k] : 0xFFFFFFFFu;
+    const uint32_t wn = (k + 1 < len) ? path[k + 1] : 0;
+    const uint32_t cell = w & 0xFFFFu;
+    const int32_t s0 = (int32_t)(w >> 16);
+    const int32_t e0 = (k + 1 < len) ? (int32_t)(wn >> 16) - 1 : kIntMax;
+    // how many earlier states of this pass sit on the same cell (a path may come back to a cell)
+    uint32_t rank = 0;
+    const uint32_t nAct = min(len - base, 64u);
+    for (uint32_t j = 0; j + 1 < nAct; ++j) {
+      const uint32_t cj = __builtin_amdgcn_readlane(cell, j);
+      rank += (j < lane && cj == cell) ? 1u : 0u;
+    }
+    uint64_t todo = ballot64(act);
+    for (uint32_t turn = 0; todo; ++turn) {
+      const bool mine = act && rank == turn;
+      if (mine) {
+        const uint32_t n1 = cnt8[cell];
+        const uint32_t n = n1 ? n1 - 1 : 1u;
+        u32x4* row4 = (u32x4*)(tv.ivals + 2 * cell * kSippCap);
+        int32_t rs[kSippCap], re[kSippCap];
+        if (n1) {
+#pragma unroll
+          for (uint32_t q = 0; q < kSippCap / 2; ++q) {
+            const u32x4 v = row4[q];
+            rs[2 * q] = (int32_t)v.x; re[2 * q] = (int32_t)v.y;
+            rs[2 * q + 1] = (int32_t)v.z; re[2 * q + 1] = (int32_t)v.w;
+          }
+        } else {
+#pragma unroll
+          for (uint32_t q = 0; q < kSippCap; ++q) { rs[q] = 0; re[q] = -1; }
+          rs[0] = 0;
+          re[0] = kIntMax;
+        }
+        uint32_t kk = kSippCap;  // the safe interval that contains the stay
+#pragma unroll
+        for (uint32_t q = kSippCap; q-- > 0;)
+          if (q < n && rs[q] <= s0 && e0 <= re[q]) kk = q;
+        int32_t a = 0, b = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < kSippCap; ++q)
+          if (q == kk) { a = rs[q]; b = re[q]; }
+        const bool left = a <= s0 - 1, right = e0 < b;
+        const int32_t d = (left ? 1 : 0) + (right ? 1 : 0) - 1;
+        if (kk == kSippCap || n + d > kSippCap) {
+          bad = true;
+        } else {
+          int32_t ns[kSippCap], ne[kSippCap];
+#pragma unroll
+          for (uint32_t q = 0; q < kSippCap; ++q) {
+            // entry q of the new list: below kk unchanged; at kk the left part, else the right part, else (both gone)
+            // the old successor; above kk the old list shifted by d
+            int32_t vs = rs[q], ve = re[q];
+            if (q >= kk) {
+              const int32_t ps = q > 0 ? rs[q - 1] : 0, pe = q > 0 ? re[q - 1] : 0;          // old[q - 1]
+              const int32_t fs = q + 1 < kSippCap ? rs[q + 1] : 0, fe = q + 1 < kSippCap ? re[q + 1] : 0;  // old[q + 1]
+              if (d == 1) {
+                if (q == kk) { vs = a; ve = s0 - 1; }
+                else if (q == kk + 1) { vs = e0 + 1; ve = b; }
+                else { vs = ps; ve = pe; }
+              } else if (d == 0) {
+                if (q == kk) { vs = left ? a : e0 + 1; ve = left ? s0 - 1 : b; }
+              } else {
+                vs = fs; ve = fe;
+              }
+            }
+            ns[q] = vs;
+            ne[q] = ve;
+          }
+#pragma unroll
+          for (uint32_t q = 0; q < kSippCap / 2; ++q) {
+            u32x4 v;
+            v.x = (uint32_t)ns[2 * q]; v.y = (uint32_t)ne[2 * q];
+            v.z = (uint32_t)ns[2 * q + 1]; v.w = (uint32_t)ne[2 * q + 1];
+            row4[q] = v;
+          }
+          cnt8[cell] = (uint8_t)(n + d + 1);
+        }
+      }
+      todo &= ~ballot64(mine);
+      if (todo) {  // the next turn reads rows this one wrote (other lanes of the same wave: through L2, not a stale L1 line)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    if (base + 64 < len) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
+  return ballot64(bad) == 0;
 }
 
 template <bool RES>
@@ -1581,7 +1743,33 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
   tv.status = (uint32_t*)g.bits;
   tv.cnt = nullptr;
   }
-  if (J.t_pad == 0xFFFFFFFFu) {  // no safe interval contains the start time: SIPP::search returns false (sipp.hpp:98-100)
+  // start interval (findSafeInterval, sipp.hpp:286-296): found by the host for a table that travels with the job, here
+  // for a resident one (the host's copy may be behind)
+  uint32_t startIv = J.t_pad, startInf = 0;
+  if constexpr (RES) {
+    const uint32_t sc = J.sy * dimx + J.sx;
+    const int32_t st0 = J.last_goal_constraint;
+    const uint32_t n1 = rfl((uint32_t)tv.cnt[sc]);
+    if (n1 == 0) {
+      startIv = 0;
+      startInf = 1;
+    } else {
+      int32_t a = 0, b = -1;
+      if (lane < n1 - 1) {
+        const i32x2 se = *(const i32x2*)(tv.ivals + 2 * (sc * kSippCap + lane));
+        a = se.x;
+        b = se.y;
+      }
+      const uint64_t hit = ballot64(lane < n1 - 1 && a <= st0 && b >= st0);
+      if (hit) {
+        startIv = (uint32_t)__builtin_ctzll(hit);
+        startInf = __builtin_amdgcn_readlane(b == kIntMax ? 1u : 0u, startIv);
+      } else {
+        startIv = 0xFFFFFFFFu;
+      }
+    }
+  }
+  if (startIv == 0xFFFFFFFFu) {  // no safe interval contains the start time: SIPP::search returns false (sipp.hpp:98-100)
     res.status = ST_NO_SOLUTION; // (after the table update: a resident table must not miss this job's delta)
     return;
   }
@@ -1595,9 +1783,9 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
   uint64_t e0;
   {
     const uint32_t sc = J.sy * dimx + J.sx;
-    const uint32_t si = J.t_pad;  // start interval index (findSafeInterval, sipp.hpp:286-296, done by the host)
+    const uint32_t si = startIv;
     const uint32_t h0 = (J.sx > gx ? J.sx - gx : gx - J.sx) + (J.sy > gy ? J.sy - gy : gy - J.sy);
-    n0.x = sc | (si << 16) | (RES ? J.reserved << 31 : 0u);  // RES: bit 31 = the start interval ends at INT_MAX
+    n0.x = sc | (si << 16) | (RES ? startInf << 31 : 0u);  // RES: bit 31 = the start interval ends at INT_MAX
     n0.y = kNoParent;
     // SIPP::search(..., startTime) (sipp.hpp:92-103): the start node's g is startTime, its f is h(start) alone
     // (a_star.hpp:78 pushes Node(start, h, initialCost))
@@ -1613,18 +1801,21 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
   if constexpr (RES) {
     if (ldsTier) {
       // fast tier: nodes and open list in LDS (the table and the status words stay in HBM, one round trip per expansion)
-      typedef TierLdsWide TL;
+      typedef TierLdsSipp TL;
       Mem<TL> gl;
       auto l8 = (__attribute__((address_space(3))) uint8_t*)ldsTier;
       gl.nodes = (Mem<TL>::P32)l8;
-      gl.pos = nullptr;
-      gl.open = (Mem<TL>::PE)(l8 + (size_t)ldsNodes * 16 + 8);
+      gl.pos = (Mem<TL>::P16)(l8 + (size_t)ldsNodes * 4);
+      gl.gOf = (Mem<TL>::P16)(l8 + (size_t)ldsNodes * 6);
+      gl.open = (Mem<TL>::PE)(l8 + (size_t)ldsNodes * 8 + 4);
       gl.focal = nullptr;
       gl.aux = nullptr;
       gl.bits = nullptr;
-      gl.capNodes = ldsNodes; gl.capHeap = ldsNodes; gl.capRows = 0; gl.rowWords = 0;
-      ((Mem<TL>::PNode4)gl.nodes)[0] = n0;
-      gl.open[0] = e0;
+      gl.capNodes = ldsNodes - 1;  // ids below kSippNoParentLds
+      gl.capHeap = ldsNodes; gl.capRows = 0; gl.rowWords = 0;
+      sippNodeNew<TL>(gl, 0, n0.x, kNoParent, n0.z);
+      gl.pos[0] = 0;
+      gl.open[0] = TL::pack(0, TierHbm::f(e0), n0.z, 0);
       __syncthreads();
       const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
       rc = sippLoop<TL, RES>(P, J, gl, tv, s, res, outPath);
@@ -1632,9 +1823,19 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
       res.prof[1] = (uint32_t)s.expansions;
       if (rc == RUN_MIGRATE_NODES) {
         __syncthreads();
-        auto srcN = (Mem<TL>::PNode4)gl.nodes;
-        for (uint32_t i = lane; i < s.nNodes; i += 64) gNodes[i] = srcN[i];
-        for (uint32_t i = lane; i < s.nOpen; i += 64) g.open[i] = gl.open[i];
+        for (uint32_t i = lane; i < s.nNodes; i += 64) {
+          const uint32_t w = gl.nodes[i];
+          u32x4 nn;
+          nn.x = (w & 0x7FFFFu) | ((w >> 19) & 1u) << 31;
+          nn.y = (w >> 20) == kSippNoParentLds ? kNoParent : (w >> 20);
+          nn.z = gl.gOf[i];
+          nn.w = gl.pos[i];
+          gNodes[i] = nn;
+        }
+        for (uint32_t i = lane; i < s.nOpen; i += 64) {
+          const uint32_t e = gl.open[i];
+          g.open[i] = TierHbm::pack(0, TL::f(e), TL::g(e), TL::id(e));
+        }
         __syncthreads();
         res.tier = 2;  // started in LDS, finished in the arena
       } else {
@@ -1659,6 +1860,12 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
   res.status = rc;
   res.expanded = s.expansions;
   res.nodes_created = s.nNodes;
+  if constexpr (RES) {
+    if (rc == ST_OK && (J.ctx_flags & kSippCommit)) {
+      __syncthreads();
+      if (!sippCommitPath(tv, (const uint32_t*)outPath, (uint32_t)res.n_states)) res.tier |= kSippTierCommitFailed;
+    }
+  }
 }
 
 // Runs the job whose descriptor is at `jobSrc` (host memory) and writes result + path to host memory.
@@ -1785,8 +1992,8 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_search_kernel(Launch
 
 // One SIPP job whose descriptor is at `jobSrc` (host memory): result + raw A* states back to host memory.
 // `ldsTier` (sessions): kSippLdsNodes node records + the open list, for jobs on device-resident tables.
-constexpr uint32_t kSippLdsNodes = 1024;
-constexpr uint32_t kSippLdsBytes = kSippLdsNodes * 16 + kSippLdsNodes * 8 + 16;
+constexpr uint32_t kSippLdsNodes = TierLdsSipp::kMaxNodes;                 // 2048 (ids 0..2046)
+constexpr uint32_t kSippLdsBytes = kSippLdsNodes * (4 + 2 + 2) + kSippLdsNodes * 4 + 16;  // nodes, pos, g, open
 DEVI void processSippJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* resDst, uint16_t* pathDst,
                          uint8_t* arenaSlot, uint8_t* ldsTier, DevJob& jobS, DevResult& resS) {
   const uint32_t lane = threadIdx.x;
@@ -1812,6 +2019,8 @@ DEVI void processSippJob(const LaunchParams& P, const DevJob* jobSrc, DevResult*
   }
   res.prof[4] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tj0);  // the whole of runSipp (table update + search)
   res.prof[5] = 1;
+  res.prof[6] = res.nodes_created > 5000 ? res.prof[3] : 0;   // TEMP: arena expansions of searches with > 5000 / > 12000 nodes
+  res.prof[7] = res.nodes_created > 12000 ? res.prof[3] : 0;
   __syncthreads();
   resS = res;
   __syncthreads();
@@ -1955,8 +2164,8 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_persistent_kernel(La
   residentLoop<false, 2>(P, smem, jobS, resS);
 }
 
-// The same resident loop for SIPP sessions (jobs of algo MRP_LL_SIPP only).  24.6 KB of LDS per workgroup hold the nodes
-// and the open list of searches on device-resident tables (6 workgroups per CU).
+// The same resident loop for SIPP sessions (jobs of algo MRP_LL_SIPP only).  24.6 KB of LDS per workgroup hold up to 2047
+// nodes and the open list of a search on a device-resident table (6 workgroups per CU).
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_persistent_kernel(LaunchParams Parg) {
   __shared__ __attribute__((aligned(16))) uint8_t sippTier[kSippLdsBytes];
   __shared__ DevJob jobS;

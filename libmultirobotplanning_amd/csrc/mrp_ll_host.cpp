@@ -109,6 +109,7 @@ struct Ticket {
   int32_t nJobs = 0;
   mrp_ll_result* userResults = nullptr;
   std::vector<uint8_t> rejected;  // per job: rejected on the host (MRP_LL_BAD_JOB)
+  std::vector<mrp_ll_sipp_table*> commitTab;  // per job: the table a sipp_commit job reports back to (else null)
   bool sipp = false;              // the batch holds MRP_LL_SIPP jobs (own kernel, own result format)
   int kind = 0;                   // A* batches: 0 = mixed, 1 = all A*-epsilon, 2 = all A*
   std::vector<int32_t> jobDimx;   // SIPP: grid width per job (cell -> x, y when unpacking)
@@ -169,7 +170,8 @@ struct Ring {
   uint32_t* sippCons = nullptr;
   uint32_t sippSlotWords = 0;      // capacity per slot the buffer was allocated with
   std::vector<int32_t> slotDimx;   // SIPP: grid width of the slot's job (cell -> x, y when unpacking)
-  std::vector<mrp_ll_sipp_table*> slotTable;  // SIPP: the device-resident table the slot's job holds, if any
+  std::vector<mrp_ll_sipp_table*> slotTable;  // SIPP: the table of the slot's job when the job has to report back to it
+  std::vector<uint8_t> slotSippFlags;         //       bit 0: it runs on the device-resident copy, bit 1: sipp_commit
   std::vector<int32_t> slotInit;   // initial_cost (A*) / start_time (SIPP) of the slot's job
 };
 struct SessTicket {
@@ -401,13 +403,55 @@ struct mrp_ll_sipp_table {
   bool overflow = false;                              // some cell has more than kSippCap safe intervals: ship whole tables
   std::vector<int32_t> dirty;                         // cells changed since the last job was packed
   std::vector<uint8_t> isDirty;
+  // sipp_commit: stays (cell, start, end) the DEVICE copy already holds and this host copy does not yet; replayed
+  // (sippTableSync) before anything reads the host copy
+  std::vector<int32_t> log;
 };
+
+namespace {
+void sippTableAddCell(mrp_ll_sipp_table* t, size_t cell, int32_t start, int32_t end, bool markDirty);
+void sippTableSync(mrp_ll_sipp_table* t) {
+  for (size_t k = 0; k + 2 < t->log.size(); k += 3)
+    sippTableAddCell(t, static_cast<size_t>(t->log[k]), t->log[k + 1], t->log[k + 2], false);
+  t->log.clear();
+}
+// the stays of a raw solution (cell | arrival << 16 per state): one collision interval per state (mrp_ll.h, sipp_commit)
+template <class F>
+void forEachStay(const uint32_t* raw, int n, F&& f) {
+  for (int k = 0; k < n; ++k)
+    f(static_cast<int32_t>(raw[k] & 0xFFFFu), static_cast<int32_t>(raw[k] >> 16),
+      k + 1 < n ? static_cast<int32_t>(raw[k + 1] >> 16) - 1 : INT32_MAX);
+}
+// A job on an mrp_ll_sipp_table has come back.  flags: bit 0 = it ran on the device-resident copy, bit 1 = sipp_commit.
+void finishSippTableJob(mrp_ll_sipp_table* T, uint32_t flags, const mrp::DevResult& d, const uint16_t* rawPath) {
+  if (flags & 1u) T->inFlight = false;
+  if (!(flags & 2u) || d.status != mrp::ST_OK) return;
+  const uint32_t* raw = reinterpret_cast<const uint32_t*>(rawPath);
+  if (flags & 1u) {
+    // the workgroup has already put the stays into the device copy; this copy catches up when somebody needs it
+    forEachStay(raw, d.n_states, [&](int32_t cell, int32_t s0, int32_t e0) {
+      T->log.push_back(cell);
+      T->log.push_back(s0);
+      T->log.push_back(e0);
+    });
+    if (d.tier & mrp::kSippTierCommitFailed) {  // ... unless a stay did not fit the fixed layout: redo the table here,
+      sippTableSync(T);                         // and from now on it travels whole
+      T->overflow = true;
+      T->devFresh = true;
+    }
+  } else {
+    if (!T->log.empty()) sippTableSync(T);
+    forEachStay(raw, d.n_states, [&](int32_t cell, int32_t s0, int32_t e0) { sippTableAddCell(T, cell, s0, e0, true); });
+  }
+}
+}  // namespace
 
 namespace {
 
 // The table of a job from an mrp_ll_sipp_table: cellIdx[cells], specFirst[K + 1], ivals[total][2] (see runSipp).
 template <class ConsSink>
 bool packSippFromTable(const mrp_ll_job& j, const MapRec& mp, ConsSink& cs, DevJob& d) {
+  if (!j.sipp_table->log.empty()) sippTableSync(const_cast<mrp_ll_sipp_table*>(j.sipp_table));
   const mrp_ll_sipp_table& T = *j.sipp_table;
   if (T.dimx != mp.dimx || T.dimy != mp.dimy) return false;
   const int cells = mp.dimx * mp.dimy;
@@ -468,6 +512,8 @@ bool packSippResident(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, Co
   const int32_t startTime = j.initial_cost;
   if (startTime > static_cast<int32_t>(mrp::kGMask)) return false;
   const bool fresh = T.devFresh || T.epoch >= mrp::kSippEpochMax;  // epochs used up: start over from a zeroed table
+  if (fresh && !T.log.empty()) sippTableSync(&T);
+  if (T.overflow) return false;
   const size_t nRec = fresh ? T.spec.size() : T.dirty.size();
   const size_t hdrWords = (nRec + 3) & ~size_t(3);
   if ((cs.size() & 3u) != 0 || !cs.fits(hdrWords + nRec * 2 * mrp::kSippCap)) return false;  // nothing consumed yet
@@ -510,22 +556,10 @@ bool packSippResident(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, Co
   d.n_ec = T.totalSafe;
   d.ec_off = static_cast<uint32_t>(nRec) | (fresh ? 0x80000000u : 0u);
   d.last_goal_constraint = startTime;
-  const int sc = j.start_y * mp.dimx + j.start_x;
-  int startIv = -1;
-  d.reserved = 0;  // 1: the start interval ends at INT_MAX (the kernel keeps that bit in its node records)
-  if (!T.cellIdx[sc]) {
-    startIv = 0;
-    d.reserved = 1;
-  } else {
-    const auto& v = T.spec[T.cellIdx[sc] - 1].safe;
-    for (size_t k = 0; k < v.size(); ++k)
-      if (v[k].s <= startTime && v[k].e >= startTime) {
-        startIv = static_cast<int>(k);
-        d.reserved = v[k].e == INT32_MAX ? 1u : 0u;
-        break;
-      }
-  }
-  d.t_pad = startIv < 0 ? 0xFFFFFFFFu : static_cast<uint32_t>(startIv);
+  // the start interval (findSafeInterval, sipp.hpp:286-296) is looked up by the workgroup: with sipp_commit the
+  // device copy is ahead of this one
+  d.t_pad = 0;
+  if (j.sipp_commit) d.ctx_flags |= mrp::kSippCommit;
   return true;
 }
 
@@ -824,11 +858,11 @@ void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool r
   }
   r.n_states = d.status == mrp::ST_OK ? d.n_states : 0;
   r.expanded = d.expanded;
-  r.tier = static_cast<int32_t>(d.tier);
+  r.tier = static_cast<int32_t>(d.tier & 0xFFu);
   ctx->stats.jobs += 1;
   ctx->stats.expansions += d.expanded;
   ctx->stats.nodes_created += d.nodes_created;
-  ctx->stats.migrated += d.tier ? 1 : 0;
+  ctx->stats.migrated += (d.tier & 0xFFu) ? 1 : 0;
   for (int q = 0; q < 8; ++q) ctx->stats.prof[q] += d.prof[q];
   if (d.status == mrp::ST_OK && sipp) {
     // raw A* states (cell | g << 16) -> PlanResult with explicit Wait actions (sipp.hpp:105-128)
@@ -1138,6 +1172,7 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
     }
     g.slotDimx.assign(R, 0);
     g.slotTable.assign(R, nullptr);
+    g.slotSippFlags.assign(R, 0);
   }
   g.slotInit.assign(R, 0);
   ctx->sess.clear();
@@ -1253,7 +1288,7 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
   for (mrp_ll_sipp_table*& tb : g.slotTable)
     if (tb) {
       tb->inFlight = false;
-      tb->devFresh = true;
+      tb->devFresh = true;  // (a sipp_commit job that was abandoned leaves no trace: its result never reached the caller)
       tb = nullptr;
     }
   // the device counter is past the published tickets: the next batch-mode launch starts from a clean base
@@ -1334,7 +1369,12 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
       ok = jobs[i].algo == MRP_LL_SIPP && packJob(ctx, jobs[i], csS, ps, d);
       if (ok) g.slotDimx[slot] = ctx->maps[jobs[i].map_id].dimx;
       sippWords = csS.used;
-      g.slotTable[slot] = ok && (d.ctx_flags & mrp::kSippResident) ? const_cast<mrp_ll_sipp_table*>(jobs[i].sipp_table) : nullptr;
+      {
+        const uint32_t fl = !ok || !jobs[i].sipp_table ? 0u
+                            : ((d.ctx_flags & mrp::kSippResident) ? 1u : 0u) | (jobs[i].sipp_commit ? 2u : 0u);
+        g.slotTable[slot] = fl ? const_cast<mrp_ll_sipp_table*>(jobs[i].sipp_table) : nullptr;
+        g.slotSippFlags[slot] = static_cast<uint8_t>(fl);
+      }
     } else {
       ok = jobs[i].algo != MRP_LL_SIPP && (g.kind == 0 || jobs[i].algo == (g.kind == 1 ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR)) &&
            packJob(ctx, jobs[i], cs, ps, d);
@@ -1390,7 +1430,8 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
                  st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);
     if (g.sipp && g.slotTable[slot]) {
-      g.slotTable[slot]->inFlight = false;
+      finishSippTableJob(g.slotTable[slot], g.slotSippFlags[slot], g.results[slot],
+                         g.outPaths + static_cast<size_t>(slot) * g.outStride);
       g.slotTable[slot] = nullptr;
     }
     st.state[i] = 1;
@@ -1429,7 +1470,8 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
     unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
                  st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);
     if (g.sipp && g.slotTable[slot]) {
-      g.slotTable[slot]->inFlight = false;
+      finishSippTableJob(g.slotTable[slot], g.slotSippFlags[slot], g.results[slot],
+                         g.outPaths + static_cast<size_t>(slot) * g.outStride);
       g.slotTable[slot] = nullptr;
     }
     st.state[i] = 1;
@@ -1520,6 +1562,11 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
     }
     if (static_cast<int>(t.jobInit.size()) < nJobs) t.jobInit.resize(nJobs);
     t.jobInit[i] = ok ? jobs[i].initial_cost : 0;
+    if (t.sipp) {
+      if (static_cast<int>(t.commitTab.size()) < nJobs) t.commitTab.resize(nJobs);
+      t.commitTab[i] = ok && jobs[i].sipp_table && jobs[i].sipp_commit ? const_cast<mrp_ll_sipp_table*>(jobs[i].sipp_table)
+                                                                        : nullptr;
+    }
     if (cs.failed || ps.failed) t.allocFailed = true;
     if (!ok) {
       // rejected: give the device a trivially capped job and remember the rejection
@@ -1608,9 +1655,12 @@ int mrp_ll_wait(mrp_ll_ctx* ctx, int32_t ticket) {
   if (hipEventElapsedTime(&ms, t.evK0, t.evK1) == hipSuccess) ctx->stats.kernel_ms += ms;
   const uint32_t outStride = static_cast<uint32_t>(ctx->opt.max_horizon);
   auto unpackT0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < t.nJobs; ++i)
+  for (int i = 0; i < t.nJobs; ++i) {
     unpackResult(ctx, t.results.host[i], t.outPaths.host + static_cast<size_t>(i) * outStride, t.rejected[i] != 0,
                  t.userResults[i], t.sipp, t.sipp ? t.jobDimx[i] : 0, t.jobInit[i]);
+    if (t.sipp && t.commitTab[i])  // batch mode never uses the device-resident copies: the host adds the stays
+      finishSippTableJob(t.commitTab[i], 2u, t.results.host[i], t.outPaths.host + static_cast<size_t>(i) * outStride);
+  }
   ctx->stats.unpack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - unpackT0).count();
   return MRP_LL_SUCCESS;
 }
@@ -1685,10 +1735,10 @@ int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t mapId, mrp_ll_sipp_table**
   return MRP_LL_SUCCESS;
 }
 
-int mrp_ll_sipp_table_add(mrp_ll_sipp_table* t, int32_t x, int32_t y, int32_t start, int32_t end) {
-  if (!t) return MRP_LL_E_INVALID;
-  if (x < 0 || x >= t->dimx || y < 0 || y >= t->dimy) return MRP_LL_SUCCESS;  // never visited
-  const size_t cell = static_cast<size_t>(y) * t->dimx + x;
+}  // extern "C"
+
+namespace {
+void sippTableAddCell(mrp_ll_sipp_table* t, size_t cell, int32_t start, int32_t end, bool markDirty) {
   if (!t->cellIdx[cell]) {
     t->spec.emplace_back();
     t->cellIdx[cell] = static_cast<int32_t>(t->spec.size());
@@ -1732,10 +1782,20 @@ int mrp_ll_sipp_table_add(mrp_ll_sipp_table* t, int32_t x, int32_t y, int32_t st
   }
   t->totalSafe += static_cast<uint32_t>(sp.safe.size());
   if (sp.safe.size() > mrp::kSippCap) t->overflow = true;  // from now on this table travels whole (packSippFromTable)
-  if (!t->isDirty[cell]) {
+  if (markDirty && !t->isDirty[cell]) {
     t->isDirty[cell] = 1;
     t->dirty.push_back(static_cast<int32_t>(cell));
   }
+}
+}  // namespace
+
+extern "C" {
+
+int mrp_ll_sipp_table_add(mrp_ll_sipp_table* t, int32_t x, int32_t y, int32_t start, int32_t end) {
+  if (!t) return MRP_LL_E_INVALID;
+  if (x < 0 || x >= t->dimx || y < 0 || y >= t->dimy) return MRP_LL_SUCCESS;  // never visited
+  if (!t->log.empty()) sippTableSync(t);
+  sippTableAddCell(t, static_cast<size_t>(y) * t->dimx + x, start, end, true);
   return MRP_LL_SUCCESS;
 }
 

@@ -37,7 +37,7 @@ class mrp_ll_job(ctypes.Structure):
                 ("n_agents", ctypes.c_int32), ("path_len", I32P), ("path_xy", ctypes.POINTER(I32P)),
                 ("max_expansions", ctypes.c_int64),
                 ("n_collision_locations", ctypes.c_int32), ("collision_xy", I32P), ("collision_count", I32P),
-                ("collision_intervals", I32P), ("initial_cost", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("collision_intervals", I32P), ("initial_cost", ctypes.c_int32), ("sipp_commit", ctypes.c_int32),
                 ("sipp_table", ctypes.c_void_p), ("path_ids", I32P), ("result_path_id", ctypes.c_int32),
                 ("reserved2", ctypes.c_int32)]
 
@@ -150,6 +150,7 @@ class LLJob:
     collision_intervals: Sequence[Sequence[int]] = ()  # SIPP: [x, y, start, end] (grouped per location, in order)
     initial_cost: int = 0  # A*: AStar::search(..., initialCost) a_star.hpp:64; SIPP: SIPP::search(..., startTime) sipp.hpp:92
     sipp_table: Optional[int] = None  # SIPP: handle from LowLevelEngine.sipp_table_create (replaces collision_intervals)
+    sipp_commit: bool = False         # SIPP with sipp_table: on success the path's stays join the table (mrp_ll.h)
     path_ids: Optional[Sequence[int]] = None  # f2: path-store slots of ctx_paths (-1 = none); lengths come from ctx_paths
     result_path_id: int = -1                  # f2: path-store slot that also receives the result path
 
@@ -229,6 +230,7 @@ class LowLevelEngine:
             cj.initial_cost = j.initial_cost
             if j.sipp_table is not None:
                 cj.sipp_table = j.sipp_table
+                cj.sipp_commit = 1 if j.sipp_commit else 0
             cj.result_path_id = j.result_path_id
             if j.path_ids is not None:
                 ids = np.ascontiguousarray(np.asarray(j.path_ids, dtype=np.int32))

@@ -715,3 +715,112 @@ def test_sipp_device_resident_tables(oracle_mod):
     for tb in tabs:
         eng.sipp_table_destroy(tb.h)
     eng.close()
+
+
+@pytest.mark.timeout(900)
+def test_sipp_commit_paths_into_tables(oracle_mod):
+    """mrp_ll_job.sipp_commit: the engine itself turns the path it found into collision intervals of the table (what
+    mapf_prioritized_sipp.cpp:237-246 does with every solution) — in a session on the device-resident copy, by the
+    workgroup that ran the search.  Several tables are planned like prioritized-planning instances, agent after agent,
+    each job checked against the oracle run on the intervals the test derives from the returned paths; mixed with
+    caller-made mrp_ll_sipp_table_add calls, with a commit that cannot fit the device layout (the host takes over), with
+    batch mode (the host commits) and across session boundaries."""
+    import random
+    from libmultirobotplanning_amd import ll
+    rng = random.Random(4242)
+    dim = 64
+    obst = [list(c) for c in {(rng.randrange(dim), rng.randrange(dim)) for _ in range(410)}]
+    oset = {tuple(c) for c in obst}
+    free = [[x, y] for x in range(dim) for y in range(dim) if (x, y) not in oset]
+    eng = ll.LowLevelEngine(device=0, max_cells=dim * dim)
+    mid = eng.upload_map(dim, dim, obst)
+
+    class Inst:
+        def __init__(self):
+            self.h = eng.sipp_table_create(mid)
+            self.cis = {}
+
+        def flat(self):
+            return [[c[0], c[1], a, b] for c, v in sorted(self.cis.items()) for a, b in sorted(v)]
+
+        def free_at(self, c, a, b):
+            return not any(a <= q[1] and q[0] <= b for q in self.cis.get(tuple(c), []))
+
+        def manual(self, c, a, b):
+            if self.free_at(c, a, b):
+                self.cis.setdefault(tuple(c), []).append([a, b])
+                eng.sipp_table_add(self.h, c[0], c[1], a, b)
+
+        def took(self, states):                       # the stays of a returned path: one per maximal stay on a cell
+            k = 0
+            while k < len(states):
+                j = k
+                while j + 1 < len(states) and states[j + 1][1:] == states[k][1:]:
+                    j += 1
+                end = states[j + 1][0] - 1 if j + 1 < len(states) else 2 ** 31 - 1
+                self.cis.setdefault((states[k][1], states[k][2]), []).append([states[k][0], end])
+                k = j + 1
+
+    def run_round(insts, t0s=None):
+        jobs, specs = [], []
+        for n, it in enumerate(insts):
+            st, go = rng.choice(free), rng.choice(free)
+            t0 = t0s[n] if t0s else 0
+            specs.append((it, st, go, t0))
+            jobs.append(ll.LLJob(map_id=mid, algo=ll.SIPP, start=st, goal=go, sipp_table=it.h, sipp_commit=True,
+                                 initial_cost=t0, max_expansions=200000))
+        res = eng.search_batch(jobs)
+        ok = 0
+        for (it, st, go, t0), r in zip(specs, res):
+            o_states, o_exp, o_cost, o_fmin = oracle_mod.sipp_single_at(dim, dim, obst, st, go, it.flat(), start_time=t0)
+            assert r.status in (ll.OK, ll.NO_SOLUTION), r.status
+            assert r.success == (len(o_states) > 0), (st, go)
+            if r.success:
+                assert [[x, y, t] for t, x, y in r.states] == o_states, (st, go)
+                assert (r.expanded, r.cost, r.fmin) == (o_exp, o_cost, o_fmin)
+                it.took(r.states)
+                ok += 1
+        return ok
+
+    insts = [Inst() for _ in range(12)]
+    n_ok = 0
+    eng.session_begin_sipp(32)
+    try:
+        for agent in range(40):
+            n_ok += run_round(insts)
+            if agent % 5 == 2:                        # the caller's own intervals in between
+                for it in insts[:4]:
+                    for _ in range(6):
+                        a = rng.randrange(0, 90)
+                        it.manual(rng.choice(free), a, a + rng.randrange(0, 3))
+        # a stay that needs a ninth interval: cell X has eight safe intervals, the agent starts there at t = 2 and leaves
+        it = insts[5]
+        X = next(c for c in free if tuple(c) not in it.cis and all(
+            0 <= c[0] + dx < dim and 0 <= c[1] + dy < dim and (c[0] + dx, c[1] + dy) not in oset and
+            (c[0] + dx, c[1] + dy) not in it.cis for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1))))
+        for q in range(7):
+            it.manual(X, 21 + 10 * q, 21 + 10 * q)
+        go = rng.choice(free)
+        r = eng.search_batch([ll.LLJob(map_id=mid, algo=ll.SIPP, start=X, goal=go, sipp_table=it.h, sipp_commit=True,
+                                       initial_cost=2)])[0]
+        o_states, o_exp, o_cost, o_fmin = oracle_mod.sipp_single_at(dim, dim, obst, X, go, it.flat(), start_time=2)
+        assert r.success and [[x, y, t] for t, x, y in r.states] == o_states
+        it.took(r.states)
+        assert len([q for q in it.cis[tuple(X)]]) == 8
+        for agent in range(4):                        # that table now travels whole and the host commits; the others go on
+            n_ok += run_round(insts)
+    finally:
+        eng.session_end()
+    # batch mode: no device-resident copies, the host commits
+    for agent in range(3):
+        n_ok += run_round(insts)
+    eng.session_begin_sipp(16)
+    try:
+        for agent in range(3):
+            n_ok += run_round(insts, t0s=[rng.choice([0, 0, 4]) for _ in insts])
+    finally:
+        eng.session_end()
+    assert n_ok > 12 * 40
+    for it in insts:
+        eng.sipp_table_destroy(it.h)
+    eng.close()
