@@ -296,7 +296,7 @@ def main():
             "agents50": (50, 16384, 400000, 192),
             "agents100": (100, 4096, 3000000, 24),
         }
-        sipp_specs = {"sipp50": (50, 2048, 512), "sipp100": (100, 2048, 512), "sipp200": (200, 1024, 512)}
+        sipp_specs = {"sipp50": (50, 8192, 512), "sipp100": (100, 8192, 512), "sipp200": (200, 4096, 512)}
         for name in [x for x in legs.split(",") if x and x != "none"]:
             if name in leg_specs:
                 ag, nb, cap, ncpu = leg_specs[name]

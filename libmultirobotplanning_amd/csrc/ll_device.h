@@ -66,7 +66,7 @@ constexpr uint32_t kSippCommit = 8u;                               // ctx_flags 
 constexpr uint32_t kSippTierCommitFailed = 0x100u;                 // DevResult.tier flag: a stay did not fit (more than kSippCap intervals,
                                                                    // or no safe interval contains it): the host redoes the table
 constexpr uint32_t kSippNoLds = 4u;                                // ctx_flags bit 2: keep nodes and open list in the arena (MRP_LL_SIPP_NO_LDS=1)
-constexpr uint32_t kSippCap = 8;                                   // safe intervals per cell the resident layout holds
+constexpr uint32_t kSippCap = 16;                                  // safe intervals per cell the resident layout holds
 constexpr uint32_t kSippEpochShift = 24, kSippEpochMax = 255;
 constexpr uint32_t kSippStClosed = 1u << 23;
 

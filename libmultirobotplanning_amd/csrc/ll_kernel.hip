@@ -32,9 +32,19 @@ namespace mrp {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
 #define DEVI __device__ __forceinline__
+
+// SIPP node "x" word as the search loop sees it: cell | interval << 16 | (interval ends at INT_MAX) << 31.  Packed forms
+// (LDS node records, TierXT heap entries) squeeze it to kSippXBits = 16 + kSippIvBits + 1 bits.
+constexpr uint32_t kSippIvBits = 4;  // kSippCap = 16 intervals per cell
+static_assert((1u << kSippIvBits) == kSippCap, "interval index width");
+constexpr uint32_t kSippXBits = 16 + kSippIvBits + 1;                       // 21
+constexpr uint32_t kSippXLow = (1u << (16 + kSippIvBits)) - 1u;             // cell and interval
+DEVI uint32_t sippPackX(uint32_t x) { return (x & kSippXLow) | (x >> 31) << (16 + kSippIvBits); }
+DEVI uint32_t sippUnpackX(uint32_t v) { return (v & kSippXLow) | ((v >> (16 + kSippIvBits)) & 1u) << 31; }
 #ifdef MRP_LL_TRACE  // diagnostic build only (-DMRP_LL_TRACE): progress words in a host-mapped buffer
 #define DBG(P, slot, val)                                                                      \
   do {                                                                                         \
@@ -93,8 +103,10 @@ DEVI uint32_t waveShr1(uint32_t v) {  // lane i receives lane i-1's value (lane 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct TierHbm {
-  static constexpr int AS = 1;
+  static constexpr int AS = 1;   // address space of the heaps (and bitmap rows)
+  static constexpr int NAS = 1;  // ... of the node records
   static constexpr bool kWideNodes = true;   // four words per node (the position of its open entry in word 3)
+  static constexpr bool kEntryHasX = false;
   typedef uint64_t E;
   typedef u64x2 Pair;
   static constexpr uint32_t kFhCap = kFhMax;
@@ -123,7 +135,9 @@ struct TierHbm {
 template <uint32_t ID, uint32_t GBITS, uint32_t FBITS, uint32_t FHBITS>
 struct TierLdsT {
   static constexpr int AS = 3;
+  static constexpr int NAS = 3;
   static constexpr bool kWideNodes = false;  // one word per node + a halfword position array
+  static constexpr bool kEntryHasX = false;
   typedef uint32_t E;
   typedef u32x2 Pair;
   static constexpr uint32_t kIdBits = ID, kGB = GBITS, kFB = FBITS, kFhB = FHBITS;
@@ -153,6 +167,30 @@ struct TierLdsT {
 typedef TierLdsT<9, 6, 7, 10> TierLds;
 // SIPP fast tier: [31:21] 2047 - f, [20:11] g (arrival time, <= kGMask), [10:0] node — the whole open key of TierHbm
 typedef TierLdsT<11, kGBits, kFBits, 0> TierLdsSipp;
+// SIPP middle tier, for a search that has outgrown TierLdsSipp's 2047 nodes: the node records go to the arena, the open
+// list stays in LDS as 64-bit entries (the whole fast-tier area: 3072 of them).  Only the open key of the entry is ever
+// compared, so the 21 bits around it carry the node's x word (cell 16, interval 4, ends-at-INT_MAX 1): an expansion
+// then needs no node read at all, like in the fast tier.
+template <int HEAP_AS>
+struct TierXT : TierHbm {
+  static constexpr int AS = HEAP_AS;
+  static constexpr int NAS = 1;
+  static constexpr bool kEntryHasX = true;
+  static constexpr uint32_t kIdBitsMix = 22;  // kMaxArenaNodes
+  DEVI static uint32_t id(E e) { return (uint32_t)e & ((1u << kIdBitsMix) - 1u); }
+  DEVI static E withX(E e, uint32_t x) {  // x = cell | interval << 16 | endsAtInf << 31
+    const uint32_t v = sippPackX(x);                                           // 21 bits: 10 below the key word, 11 above the key
+    // (pack() leaves 2047 - focalH = all ones in the eleven bits above the open key: they are cleared first)
+    return (e & ~((uint64_t)kFhMax << (32 + kGBits + kFBits))) | ((uint64_t)(v & 0x3FFu) << kIdBitsMix) |
+           ((uint64_t)(v >> 10) << (32 + kGBits + kFBits));
+  }
+  DEVI static uint32_t xOf(E e) {
+    const uint32_t v = (((uint32_t)e >> kIdBitsMix) & 0x3FFu) | ((uint32_t)(e >> (32 + kGBits + kFBits)) & kFhMax) << 10;
+    return sippUnpackX(v);
+  }
+};
+typedef TierXT<3> TierMix;   // open list in LDS
+typedef TierXT<1> TierHbmX;  // ... in the arena: the last tier of a search on a resident table (entries keep their x word)
 
 template <class T>
 struct Mem {
@@ -161,8 +199,9 @@ struct Mem {
   typedef __attribute__((address_space(T::AS))) typename T::Pair* PPair;
   typedef __attribute__((address_space(T::AS))) uint32_t* P32;
   typedef __attribute__((address_space(T::AS))) uint16_t* P16;
-  typedef __attribute__((address_space(T::AS))) u32x4* PNode4;
-  P32 nodes;     // TierLds: one word per node; TierHbm: four words per node
+  typedef __attribute__((address_space(T::NAS))) uint32_t* PN32;
+  typedef __attribute__((address_space(T::NAS))) u32x4* PNode4;
+  PN32 nodes;     // TierLds: one word per node; TierHbm: four words per node
   P16 pos;       // TierLds only: position of the node's entry in the open array
   P16 gOf;       // TierLdsSipp only: arrival time of the node
   PE open;       // biased: element i at open[i] (the pointer already includes the +1 bias)
@@ -1010,7 +1049,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   Mem<TierHbm> g;
   {
     uint8_t* p = arenaSlot;
-    g.nodes = (Mem<TierHbm>::P32)p;              p += (size_t)P.arena_nodes * 16;
+    g.nodes = (Mem<TierHbm>::PN32)p;             p += (size_t)P.arena_nodes * 16;
     g.pos = nullptr;
     g.open = (Mem<TierHbm>::PE)(p + 8);          p += (size_t)P.arena_nodes * 8 + 16;
     g.focal = (Mem<TierHbm>::PE)(p + 8);         p += (size_t)P.arena_nodes * 8 + 16;
@@ -1025,7 +1064,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   if (ldsOk) {
     Mem<TierLds> m;
     uint8_t* p = smem;
-    m.nodes = (Mem<TierLds>::P32)p;              p += P.lds_nodes * 4;
+    m.nodes = (Mem<TierLds>::PN32)p;             p += P.lds_nodes * 4;
     m.pos = (Mem<TierLds>::P16)p;                p += (P.lds_nodes * 2 + 15u) & ~15u;
     const uint32_t heapBytes = ldsHeapBytes(P.lds_nodes);
     m.open = (Mem<TierLds>::PE)(p + 4);          p += heapBytes;
@@ -1136,8 +1175,8 @@ struct SippView {
 };
 
 // SIPP node records.  Arena tier: u32x4 { x = cell | interval << 16 | (RES: interval ends at INT_MAX) << 31, parent, g,
-// position of the open entry }.  TierLdsSipp: one word  cell | interval << 16 | endsAtInf << 19 | parent << 20  (interval
-// < kSippCap = 8; parent < 2047, 0x7FF = none), g in Mem::gOf, the position in Mem::pos.
+// position of the open entry }.  TierLdsSipp: one word  cell | interval << 16 | endsAtInf << 20 | parent << 21  (interval
+// < kSippCap = 16; parent < 2047, 0x7FF = none), g in Mem::gOf, the position in Mem::pos.
 constexpr uint32_t kSippNoParentLds = 0x7FFu;
 template <class T>
 DEVI uint32_t sippNodeX(Mem<T>& m, uint32_t id) {
@@ -1145,7 +1184,7 @@ DEVI uint32_t sippNodeX(Mem<T>& m, uint32_t id) {
     return rfl(((typename Mem<T>::PNode4)m.nodes)[id].x);
   } else {
     const uint32_t w = rfl(m.nodes[id]);
-    return (w & 0x7FFFFu) | ((w >> 19) & 1u) << 31;
+    return sippUnpackX(w);
   }
 }
 template <class T>
@@ -1158,7 +1197,7 @@ DEVI void sippNodeNew(Mem<T>& m, uint32_t id, uint32_t x, uint32_t parent, uint3
     nn.w = 0;
     ((typename Mem<T>::PNode4)m.nodes)[id] = nn;
   } else {
-    m.nodes[id] = (x & 0x7FFFFu) | (x >> 31) << 19 | (parent & kSippNoParentLds) << 20;
+    m.nodes[id] = sippPackX(x) | (parent & kSippNoParentLds) << kSippXBits;
     m.gOf[id] = (uint16_t)t;
   }
 }
@@ -1180,7 +1219,7 @@ DEVI void sippNodeReparent(Mem<T>& m, uint32_t id, uint32_t parent, uint32_t t) 
     m.nodes[id * 4 + 1] = parent;
     m.nodes[id * 4 + 2] = t;
   } else {
-    m.nodes[id] = (rfl(m.nodes[id]) & 0xFFFFFu) | (parent & kSippNoParentLds) << 20;
+    m.nodes[id] = (rfl(m.nodes[id]) & ((1u << kSippXBits) - 1u)) | (parent & kSippNoParentLds) << kSippXBits;
     m.gOf[id] = (uint16_t)t;
   }
 }
@@ -1195,8 +1234,15 @@ DEVI void sippNodePath(Mem<T>& m, uint32_t id, uint32_t& cell, uint32_t& gN, uin
     const uint32_t w = rfl(m.nodes[id]);
     cell = w & 0xFFFFu;
     gN = rfl((uint32_t)m.gOf[id]);
-    parent = (w >> 20) == kSippNoParentLds ? kNoParent : (w >> 20);
+    parent = (w >> kSippXBits) == kSippNoParentLds ? kNoParent : (w >> kSippXBits);
   }
+}
+
+template <class T>
+DEVI typename T::E sippEntry(uint32_t f, uint32_t gN, uint32_t id, uint32_t x) {
+  typename T::E e = T::pack(0, f, gN, id);
+  if constexpr (T::kEntryHasX) e = T::withX(e, x);
+  return e;
 }
 
 struct SippState {  // wave-uniform
@@ -1226,7 +1272,11 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
     }
     const typename T::E curE = ldU<T>(g.open, 0);
     const uint32_t curId = T::id(curE);
-    const uint32_t cw = sippNodeX<T>(g, curId);
+    uint32_t cw;
+    if constexpr (T::kEntryHasX)
+      cw = T::xOf(curE);
+    else
+      cw = sippNodeX<T>(g, curId);
     const uint32_t cell = cw & 0xFFFF, iv = RES ? (cw >> 16) & 0x7FFFu : cw >> 16;
     const uint32_t gcur = T::g(curE);  // == the node's g: every entry is packed with it
     const uint32_t cx = cell % dimx, cy = cell / dimx;
@@ -1263,8 +1313,8 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
       f0 = rfl(f0);
       if (ck) endT = rfli(ivals[2 * (f0 + iv) + 1]);
     }
-    if constexpr (T::AS == 3) {  // LDS tier: room for every successor of this expansion, or continue in the arena
-      if (nNodes + 4 * kSippCap > g.capNodes) return RUN_MIGRATE_NODES;
+    if constexpr (T::AS == 3) {  // LDS tiers: room for every successor of this expansion, or continue in the next tier
+      if (nNodes + 4 * kSippCap > g.capNodes || nOpen + 4 * kSippCap > g.capHeap) return RUN_MIGRATE_NODES;
     }
     expansions += 1;
     if (maxExp >= 0 && expansions > maxExp) {
@@ -1408,10 +1458,10 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
               const uint32_t nc = __builtin_amdgcn_readlane(ncM, l);
               const uint32_t hN = __builtin_amdgcn_readlane(hM, l);
               const uint32_t nid = nNodes + k;
-              sippNodeNew<T>(g, nid, nc | ((l & 15u) << 16) | (RES ? __builtin_amdgcn_readlane(siE == kIntMax ? 1u : 0u, l) << 31 : 0u),
-                             curId, t);
+              const uint32_t xN = nc | ((l & 15u) << 16) | (RES ? __builtin_amdgcn_readlane(siE == kIntMax ? 1u : 0u, l) << 31 : 0u);
+              sippNodeNew<T>(g, nid, xN, curId, t);
               tv.putSt(sid, nid + 1);
-              e[k] = T::pack(0, t + hN, t, nid);
+              e[k] = sippEntry<T>(t + hN, t, nid, xN);
             }
           }
           const uint32_t pm = (1u << nNew) - 1u;
@@ -1432,6 +1482,7 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
           const uint32_t hN = __builtin_amdgcn_readlane(hM, l);
           const uint32_t st = __builtin_amdgcn_readlane(stL, l);
           if (st & SippView<RES>::kClosed) continue;                   // closedSet.find (a_star.hpp:117)
+          const uint32_t xN = nc | ((l & 15u) << 16) | (RES ? __builtin_amdgcn_readlane(siE == kIntMax ? 1u : 0u, l) << 31 : 0u);
           if (st == 0) {                                   // new state (a_star.hpp:120-129)
             if (nNodes >= g.capNodes) {
               res.status = ST_CAP_NODES;
@@ -1439,10 +1490,9 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
               break;
             }
             const uint32_t nid = nNodes++;
-            sippNodeNew<T>(g, nid, nc | ((l & 15u) << 16) | (RES ? __builtin_amdgcn_readlane(siE == kIntMax ? 1u : 0u, l) << 31 : 0u),
-                           curId, t);
+            sippNodeNew<T>(g, nid, xN, curId, t);
             tv.putSt(sid, nid + 1);
-            siftUp<T, 0, true>(g, g.open, nOpen, T::pack(0, t + hN, t, nid));
+            siftUp<T, 0, true>(g, g.open, nOpen, sippEntry<T>(t + hN, t, nid, xN));
             nOpen += 1;
           } else {                                         // already in open (a_star.hpp:130-146)
             const uint32_t nid = st - 1;
@@ -1450,7 +1500,7 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
             sippNodeGPos<T>(g, nid, gOld, posOld);
             if (t >= gOld) continue;
             sippNodeReparent<T>(g, nid, curId, t);
-            siftUp<T, 0, true>(g, g.open, posOld, T::pack(0, t + hN, t, nid));  // increase(handle)
+            siftUp<T, 0, true>(g, g.open, posOld, sippEntry<T>(t + hN, t, nid, xN));  // increase(handle)
           }
         }
       }
@@ -1624,6 +1674,9 @@ DEVI bool sippCommitPath(const SippView<true>& tv, const uint32_t* path, uint32_
   return ballot64(bad) == 0;
 }
 
+// LDS of a resident SIPP workgroup: TierLdsSipp's nodes, positions, g and open list — or TierMix's open list alone
+constexpr uint32_t kSippLdsBytesC = TierLdsSipp::kMaxNodes * (4 + 2 + 2) + TierLdsSipp::kMaxNodes * 4 + 16;
+
 template <bool RES>
 DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, uint8_t* ldsTier, uint32_t ldsNodes, DevResult& res,
                   uint16_t* outPath) {
@@ -1636,7 +1689,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
   Mem<T>::PNode4 gNodes;
   {
     uint8_t* p = arenaSlot;
-    g.nodes = (Mem<T>::P32)p;
+    g.nodes = (Mem<T>::PN32)p;
     gNodes = (Mem<T>::PNode4)p;                  p += (size_t)P.arena_nodes * 16;
     g.pos = nullptr;
     g.open = (Mem<T>::PE)(p + 8);                p += (size_t)P.arena_nodes * 8 + 16;
@@ -1675,10 +1728,11 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
       __syncthreads();
     }
     // the cells whose lists changed since the table's previous job, out of pinned host memory: lane u copies 16 bytes
-    // of record u / 4, four rounds in flight (one PCIe round trip per 64 records)
+    // of record u / kUnits, four rounds in flight
     const uint32_t* hdr = P.cons + J.vc_off;
     const u32x4* recs = (const u32x4*)(hdr + ((nRec + 3u) & ~3u));
-    const uint32_t nUnits = nRec * (kSippCap / 2);
+    constexpr uint32_t kUnits = kSippCap / 2;  // 16-byte units per record
+    const uint32_t nUnits = nRec * kUnits;
     for (uint32_t u0 = 0; u0 < nUnits; u0 += 256) {
       uint32_t h[4];
       u32x4 v[4];
@@ -1686,7 +1740,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
       for (int q = 0; q < 4; ++q) {
         const uint32_t u = u0 + q * 64 + lane;
         if (u < nUnits) {
-          h[q] = __builtin_nontemporal_load(hdr + (u >> 2));
+          h[q] = __builtin_nontemporal_load(hdr + u / kUnits);
           v[q] = __builtin_nontemporal_load(recs + u);
         }
       }
@@ -1695,8 +1749,8 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
         const uint32_t u = u0 + q * 64 + lane;
         if (u < nUnits) {
           const uint32_t cell = h[q] & 0xFFFFu;
-          iv4[cell * (kSippCap / 2) + (u & 3u)] = v[q];
-          if ((u & 3u) == 0) cnt8[cell] = (uint8_t)((h[q] >> 16) + 1u);
+          iv4[cell * kUnits + u % kUnits] = v[q];
+          if (u % kUnits == 0) cnt8[cell] = (uint8_t)((h[q] >> 16) + 1u);
         }
       }
     }
@@ -1804,7 +1858,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
       typedef TierLdsSipp TL;
       Mem<TL> gl;
       auto l8 = (__attribute__((address_space(3))) uint8_t*)ldsTier;
-      gl.nodes = (Mem<TL>::P32)l8;
+      gl.nodes = (Mem<TL>::PN32)l8;
       gl.pos = (Mem<TL>::P16)(l8 + (size_t)ldsNodes * 4);
       gl.gOf = (Mem<TL>::P16)(l8 + (size_t)ldsNodes * 6);
       gl.open = (Mem<TL>::PE)(l8 + (size_t)ldsNodes * 8 + 4);
@@ -1826,24 +1880,51 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
         for (uint32_t i = lane; i < s.nNodes; i += 64) {
           const uint32_t w = gl.nodes[i];
           u32x4 nn;
-          nn.x = (w & 0x7FFFFu) | ((w >> 19) & 1u) << 31;
-          nn.y = (w >> 20) == kSippNoParentLds ? kNoParent : (w >> 20);
+          nn.x = sippUnpackX(w);
+          nn.y = (w >> kSippXBits) == kSippNoParentLds ? kNoParent : (w >> kSippXBits);
           nn.z = gl.gOf[i];
           nn.w = gl.pos[i];
           gNodes[i] = nn;
         }
+        // the open list: 64-bit entries with the node's x word (TierMix), staged through the arena's open array because
+        // the new list covers the area the old one and the node records occupy
         for (uint32_t i = lane; i < s.nOpen; i += 64) {
           const uint32_t e = gl.open[i];
-          g.open[i] = TierHbm::pack(0, TL::f(e), TL::g(e), TL::id(e));
+          const uint32_t w = gl.nodes[TL::id(e)];
+          g.open[i] = TierMix::withX(TierHbm::pack(0, TL::f(e), TL::g(e), TL::id(e)), sippUnpackX(w));
         }
         __syncthreads();
-        res.tier = 2;  // started in LDS, finished in the arena
+        Mem<TierMix> gm;
+        gm.nodes = g.nodes;
+        gm.pos = nullptr;
+        gm.gOf = nullptr;
+        gm.open = (Mem<TierMix>::PE)(l8 + 8);
+        gm.focal = nullptr;
+        gm.aux = nullptr;
+        gm.bits = nullptr;
+        gm.capNodes = P.arena_nodes;
+        gm.capHeap = (kSippLdsBytesC - 16) / 8;
+        gm.capRows = 0; gm.rowWords = 0;
+        for (uint32_t i = lane; i < s.nOpen; i += 64) gm.open[i] = g.open[i];
+        __syncthreads();
+        res.tier = 2;  // started in LDS, the open list still there
+        const uint64_t tm0 = __builtin_amdgcn_s_memrealtime();
+        const int64_t e0m = s.expansions;
+        rc = sippLoop<TierMix, RES>(P, J, gm, tv, s, res, outPath);
+        res.prof[6] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tm0);  // ... in the middle tier
+        res.prof[7] = (uint32_t)(s.expansions - e0m);
+        if (rc == RUN_MIGRATE_NODES) {  // the open list has outgrown LDS too: everything in the arena
+          __syncthreads();
+          for (uint32_t i = lane; i < s.nOpen; i += 64) g.open[i] = gm.open[i];
+          __syncthreads();
+          res.tier = 3;
+        }
       } else {
         res.tier = 0;
       }
     } else {
       gNodes[0] = n0;
-      g.open[0] = e0;
+      g.open[0] = TierHbmX::withX(e0, n0.x);
     }
   } else {
     gNodes[0] = n0;
@@ -1852,10 +1933,18 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
   if (rc == RUN_MIGRATE_NODES) {
     const uint64_t th0 = __builtin_amdgcn_s_memrealtime();
     const int64_t e0h = s.expansions;
-    rc = sippLoop<TierHbm, RES>(P, J, g, tv, s, res, outPath);
+    if constexpr (RES) {
+      Mem<TierHbmX> gx;
+      gx.nodes = g.nodes; gx.pos = nullptr; gx.gOf = nullptr;
+      gx.open = (Mem<TierHbmX>::PE)g.open; gx.focal = nullptr; gx.aux = nullptr; gx.bits = nullptr;
+      gx.capNodes = g.capNodes; gx.capHeap = g.capHeap; gx.capRows = 0; gx.rowWords = 0;
+      rc = sippLoop<TierHbmX, RES>(P, J, gx, tv, s, res, outPath);
+    } else {
+      rc = sippLoop<TierHbm, RES>(P, J, g, tv, s, res, outPath);
+    }
     res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);  // ... in the arena tier
     res.prof[3] = (uint32_t)(s.expansions - e0h);
-    if (res.tier != 2) res.tier = 1;
+    if (res.tier == 0) res.tier = 1;
   }
   res.status = rc;
   res.expanded = s.expansions;
@@ -1993,7 +2082,7 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_search_kernel(Launch
 // One SIPP job whose descriptor is at `jobSrc` (host memory): result + raw A* states back to host memory.
 // `ldsTier` (sessions): kSippLdsNodes node records + the open list, for jobs on device-resident tables.
 constexpr uint32_t kSippLdsNodes = TierLdsSipp::kMaxNodes;                 // 2048 (ids 0..2046)
-constexpr uint32_t kSippLdsBytes = kSippLdsNodes * (4 + 2 + 2) + kSippLdsNodes * 4 + 16;  // nodes, pos, g, open
+constexpr uint32_t kSippLdsBytes = kSippLdsBytesC;
 DEVI void processSippJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* resDst, uint16_t* pathDst,
                          uint8_t* arenaSlot, uint8_t* ldsTier, DevJob& jobS, DevResult& resS) {
   const uint32_t lane = threadIdx.x;
@@ -2019,8 +2108,6 @@ DEVI void processSippJob(const LaunchParams& P, const DevJob* jobSrc, DevResult*
   }
   res.prof[4] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tj0);  // the whole of runSipp (table update + search)
   res.prof[5] = 1;
-  res.prof[6] = res.nodes_created > 5000 ? res.prof[3] : 0;   // TEMP: arena expansions of searches with > 5000 / > 12000 nodes
-  res.prof[7] = res.nodes_created > 12000 ? res.prof[3] : 0;
   __syncthreads();
   resS = res;
   __syncthreads();

@@ -23,7 +23,7 @@ for rep in range(2):
     pf = ls["prof"]
     print("   SIPP kernel: LDS tier %.2f us/expansion over %.3g expansions, arena tier %.2f us/expansion over %.3g; runSipp %.1f us/job over %d jobs" % (
         pf[0] / 100.0 / max(pf[1], 1), pf[1], pf[2] / 100.0 / max(pf[3], 1), pf[3], pf[4] / 100.0 / max(pf[5], 1), pf[5]), flush=True)
-    print("   arena expansions by search size: >5000 nodes %.3g, >12000 nodes %.3g" % (pf[6], pf[7]))
+    print("   middle tier (open list in LDS, nodes in the arena): %.2f us/expansion over %.3g expansions" % (pf[6] / 100.0 / max(pf[7], 1), pf[7]))
     print("rep %d: %d instances x %d agents: wall %.3f s, %.3e exp/s, %.1f inst/s, rounds %d searches %d planned-all %d" % (
         rep, n, agents, st["wall_seconds"], st["ll_expansions"] / st["wall_seconds"], n / st["wall_seconds"], st["rounds"],
         st["ll_searches"], st["solved"]), flush=True)

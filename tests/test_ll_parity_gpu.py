@@ -595,7 +595,7 @@ def test_sipp_device_resident_tables(oracle_mod):
     """mrp_ll_sipp_table_* inside a SIPP session: the table lives on the device and a job carries only the cells that
     changed since the table's previous job.  A prioritized-planner-like sequence (search, add intervals, search ...) on
     several tables at once must match the oracle job by job — including a table that outgrows the resident layout
-    (a cell with more than 8 safe intervals: falls back to whole tables), more jobs on one table than there are epochs
+    (a cell with more than 16 safe intervals: falls back to whole tables), more jobs on one table than there are epochs
     (the status words are re-zeroed), two jobs on one table in flight (the second travels whole), a start time inside a
     collision interval (no start interval; the delta must still be applied) and the table surviving session boundaries."""
     import random
@@ -673,7 +673,7 @@ def test_sipp_device_resident_tables(oracle_mod):
                 for c in rng.sample(free, rng.randrange(1, 25)):
                     tb.add(c)
             if rnd == 20:
-                tabs[2].add(free[5], n=12)                    # 12 collision intervals -> 13 safe intervals: beyond the layout
+                tabs[2].add(free[5], n=20)                    # 20 collision intervals -> 21 safe intervals: beyond the layout
         small = (eng.stats()["staged_bytes"] - st0) / n_jobs
         # two jobs on ONE table in the same submit: the second cannot share the device copy
         tb = tabs[0]
@@ -793,12 +793,12 @@ def test_sipp_commit_paths_into_tables(oracle_mod):
                     for _ in range(6):
                         a = rng.randrange(0, 90)
                         it.manual(rng.choice(free), a, a + rng.randrange(0, 3))
-        # a stay that needs a ninth interval: cell X has eight safe intervals, the agent starts there at t = 2 and leaves
+        # a stay that needs a 17th interval: cell X has sixteen safe intervals, the agent starts there at t = 2 and leaves
         it = insts[5]
         X = next(c for c in free if tuple(c) not in it.cis and all(
             0 <= c[0] + dx < dim and 0 <= c[1] + dy < dim and (c[0] + dx, c[1] + dy) not in oset and
             (c[0] + dx, c[1] + dy) not in it.cis for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1))))
-        for q in range(7):
+        for q in range(15):
             it.manual(X, 21 + 10 * q, 21 + 10 * q)
         go = rng.choice(free)
         r = eng.search_batch([ll.LLJob(map_id=mid, algo=ll.SIPP, start=X, goal=go, sipp_table=it.h, sipp_commit=True,
@@ -806,7 +806,7 @@ def test_sipp_commit_paths_into_tables(oracle_mod):
         o_states, o_exp, o_cost, o_fmin = oracle_mod.sipp_single_at(dim, dim, obst, X, go, it.flat(), start_time=2)
         assert r.success and [[x, y, t] for t, x, y in r.states] == o_states
         it.took(r.states)
-        assert len([q for q in it.cis[tuple(X)]]) == 8
+        assert len([q for q in it.cis[tuple(X)]]) == 16
         for agent in range(4):                        # that table now travels whole and the host commits; the others go on
             n_ok += run_round(insts)
     finally:
