@@ -293,8 +293,8 @@ def main():
         leg_specs = {  # name -> (agents, instances, cap per instance, CPU sample)
             # batches large enough that the one-wavefront chains of the few pathological instances (the capped ones run
             # for seconds) do not leave the chip idle for most of the step
-            "agents50": (50, 16384, 400000, 192),
-            "agents100": (100, 4096, 3000000, 24),
+            "agents50": (50, 65536, 400000, 192),
+            "agents100": (100, 16384, 3000000, 24),
         }
         sipp_specs = {"sipp50": (50, 8192, 512), "sipp100": (100, 8192, 512), "sipp200": (200, 4096, 512)}
         for name in [x for x in legs.split(",") if x and x != "none"]:

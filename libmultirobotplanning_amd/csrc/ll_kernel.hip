@@ -1079,7 +1079,14 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     __syncthreads();
 
     initSearch<TierLds, EPS>(m, s, c);
+#ifndef MRP_LL_TRACE  // (the trace build uses prof[] for its phase counters)
+    const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
+#endif
     rc = runSearch<TierLds, EPS>(m, s, c, obstLocal, true, res, outPath);
+#ifndef MRP_LL_TRACE
+    res.prof[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);  // 100 MHz ticks / expansions in the LDS tier
+    res.prof[1] = (uint32_t)s.expansions;
+#endif
     if (rc == RUN_MIGRATE_NODES || rc == RUN_MIGRATE_ROWS) {
       // migrate the whole search state to the HBM arena (records converted to that tier's formats) and continue with
       // the same code on global pointers.  A migration happens at the top of an expansion, before anything was popped.
@@ -1105,13 +1112,28 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
       for (uint32_t r = 0; r < s.rowsReady; ++r)
         for (uint32_t wd = lane; wd < c.wpr; wd += 64) g.bits[r * g.rowWords + wd] = m.bits[r * m.rowWords + wd];
       __syncthreads();
+#ifndef MRP_LL_TRACE
+      const uint64_t th0 = __builtin_amdgcn_s_memrealtime();
+      const int64_t e0h = s.expansions;
+#endif
       rc = runSearch<TierHbm, EPS>(g, s, c, (Mem<TierHbm>::P32)c.obst, false, res, outPath);
+#ifndef MRP_LL_TRACE
+      res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);  // ... in the arena tier after a migration
+      res.prof[3] = (uint32_t)(s.expansions - e0h);
+#endif
     }
   } else {
     res.tier = 1;
     initSearch<TierHbm, EPS>(g, s, c);
     __syncthreads();
+#ifndef MRP_LL_TRACE
+    const uint64_t th0 = __builtin_amdgcn_s_memrealtime();
+#endif
     rc = runSearch<TierHbm, EPS>(g, s, c, (Mem<TierHbm>::P32)c.obst, false, res, outPath);
+#ifndef MRP_LL_TRACE
+    res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);
+    res.prof[3] = (uint32_t)s.expansions;
+#endif
   }
   if (rc == RUN_MIGRATE_NODES) rc = ST_CAP_NODES;
   if (rc == RUN_MIGRATE_ROWS) rc = ST_CAP_HORIZON;
@@ -1978,6 +2000,9 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
   res.tier = 0;
   for (int q = 0; q < 8; ++q) res.prof[q] = 0;
   PROF_T0();
+#ifndef MRP_LL_TRACE
+  const uint64_t tj0 = __builtin_amdgcn_s_memrealtime();
+#endif
   uint16_t* outPath = (uint16_t*)(arenaSlot + P.arena_scratch_off);  // device scratch; copied out below
   const uint32_t algo = rfl(J.algo);
   if (KIND == 0) {
@@ -1991,6 +2016,10 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
     if (algo == 0) runJob<false>(P, J, smem, arenaSlot, res, outPath);
   }
   PROF_ADD(res, 5);
+#ifndef MRP_LL_TRACE
+  res.prof[4] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tj0);  // the whole job on the device (tables, search)
+  res.prof[5] = 1;
+#endif
   DBG(P, 2, res.status + 100);
   // result + path back to host memory with lane-parallel stores
   __syncthreads();

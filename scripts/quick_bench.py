@@ -26,6 +26,10 @@ for rep in range(int(os.environ.get('MRP_REPS', '3'))):
         st["build_seconds"], st["ll_call_seconds"], ls["pack_ms"] / 1e3, ls["unpack_ms"] / 1e3, ls["kernel_ms"] / 1e3,
         ls["h2d_ms"] / 1e3, ls["d2h_ms"] / 1e3, st["consume_seconds"]), flush=True)
     print("   staged in pinned host memory: %.1f MB = %.0f bytes per search" % (ls["staged_bytes"] / 1e6, ls["staged_bytes"] / max(st["ll_searches"], 1)), flush=True)
+    pf = ls["prof"]
+    print("   kernel tiers: LDS %.2f us/expansion over %.4g expansions; arena %.2f us/expansion over %.4g expansions" % (
+        pf[0] / 100.0 / max(pf[1], 1), pf[1], pf[2] / 100.0 / max(pf[3], 1), pf[3]), flush=True)
+    print("   whole job on the device: %.1f us over %d jobs" % (pf[4] / 100.0 / max(pf[5], 1), pf[5]), flush=True)
     print("   resident workgroups: busy %.3f s, waiting %.3f s (sum over workgroups) -> busy fraction %.2f" % (
         ls["session_busy_ms"] / 1e3, ls["session_idle_ms"] / 1e3,
         ls["session_busy_ms"] / max(ls["session_busy_ms"] + ls["session_idle_ms"], 1e-9)), flush=True)
@@ -39,3 +43,8 @@ if cpu_n:
         if o["rc"] == 1 and (r["status"], r["cost"], r["hl_expanded"], r["ll_expanded"]) != (0, o["cost"], o["hl_expanded"], o["ll_expanded"]):
             mism += 1
     print("cpu oracle on first %d: %.3e exp/s, %.2f inst/s, mismatches %d" % (cpu_n, e / t, cpu_n / t, mism), flush=True)
+
+try:
+    print("peak host memory: " + [l.split(":")[1].strip() for l in open("/proc/self/status") if l.startswith("VmHWM")][0], flush=True)
+except Exception:
+    pass
