@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=131072, help="instances per GPU per step (headline workload)")
+    ap.add_argument("--instances", type=int, default=262144, help="instances per GPU per step (headline workload)")
     ap.add_argument("--agents", type=int, default=10)
     ap.add_argument("--threads", type=int, default=0, help="host worker threads per GPU (0 = auto)")
     ap.add_argument("--slots", type=int, default=0)
@@ -328,7 +328,7 @@ def main():
                 ag, nb, ncpu = sipp_specs[name]
                 ia = hl.generate_instances(640000 + 1000 * ag, nb, 64, 64, 410, ag)
                 insts = list(ia)
-                solver.prioritized_sipp(insts[:64], want_schedules=False)  # warm-up, same shape
+                solver.prioritized_sipp(insts, want_schedules=False)  # warm-up pass over the same batch (device table pool grows)
                 torch.cuda.synchronize()
                 res, st = solver.prioritized_sipp(insts, want_schedules=False)
                 torch.cuda.synchronize()

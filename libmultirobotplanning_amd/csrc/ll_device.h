@@ -58,7 +58,8 @@ constexpr uint32_t kCtxById = 1u;
 //   iv[cells][kSippCap][2] int32 {start, end},
 //   status[cells][kSippCap] words  epoch << 24 | closed << 23 | node + 1   (a word of another epoch reads as "unseen").
 // cons[vc_off] holds only the DELTA since the table's previous job: ec_off & 0x7FFFFFFF records (bit 31: zero cnt and
-// status first), as  hdr[nRec]  (cell | count << 16; padded to a multiple of 4 words)  then  nRec x kSippCap x {start, end}.
+// status first), as  hdr[nRec]  (cell | count << 16; padded to a multiple of 4 words)  then  nRec x n_vc x {start, end}
+// (n_vc = room per record of this job: the longest list among its records, as a power of two >= 2).
 // n_ctx = the job's epoch (1..255).  One job per table in flight.  The workgroup finds the start interval itself
 // (findSafeInterval, sipp.hpp:286-296) — the host's copy of the table may be behind the device's (kSippCommit).
 constexpr uint32_t kSippResident = 2u;

@@ -1750,11 +1750,13 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
       __syncthreads();
     }
     // the cells whose lists changed since the table's previous job, out of pinned host memory: lane u copies 16 bytes
-    // of record u / kUnits, four rounds in flight
+    // of record u / recUnits, four rounds in flight
     const uint32_t* hdr = P.cons + J.vc_off;
     const u32x4* recs = (const u32x4*)(hdr + ((nRec + 3u) & ~3u));
-    constexpr uint32_t kUnits = kSippCap / 2;  // 16-byte units per record
-    const uint32_t nUnits = nRec * kUnits;
+    constexpr uint32_t kUnits = kSippCap / 2;  // 16-byte units per row of the table
+    const uint32_t recUnits = J.n_vc / 2;      // ... per record of this job (a power of two, 1 .. kUnits)
+    const uint32_t recShift = 31u - (uint32_t)__builtin_clz(recUnits | 1u);
+    const uint32_t nUnits = nRec * recUnits;
     for (uint32_t u0 = 0; u0 < nUnits; u0 += 256) {
       uint32_t h[4];
       u32x4 v[4];
@@ -1762,7 +1764,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
       for (int q = 0; q < 4; ++q) {
         const uint32_t u = u0 + q * 64 + lane;
         if (u < nUnits) {
-          h[q] = __builtin_nontemporal_load(hdr + u / kUnits);
+          h[q] = __builtin_nontemporal_load(hdr + (u >> recShift));
           v[q] = __builtin_nontemporal_load(recs + u);
         }
       }
@@ -1771,8 +1773,8 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
         const uint32_t u = u0 + q * 64 + lane;
         if (u < nUnits) {
           const uint32_t cell = h[q] & 0xFFFFu;
-          iv4[cell * kUnits + u % kUnits] = v[q];
-          if (u % kUnits == 0) cnt8[cell] = (uint8_t)((h[q] >> 16) + 1u);
+          iv4[cell * kUnits + (u & (recUnits - 1u))] = v[q];
+          if ((u & (recUnits - 1u)) == 0) cnt8[cell] = (uint8_t)((h[q] >> 16) + 1u);
         }
       }
     }

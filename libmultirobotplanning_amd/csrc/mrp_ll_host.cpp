@@ -515,17 +515,26 @@ bool packSippResident(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, Co
   if (fresh && !T.log.empty()) sippTableSync(&T);
   if (T.overflow) return false;
   const size_t nRec = fresh ? T.spec.size() : T.dirty.size();
+  // every record of one job has room for the same number of intervals: the longest list among them, as a power of two >= 2
+  size_t longest = 0;
+  if (fresh) {
+    for (const mrp_ll_sipp_table::Spec& sp : T.spec) longest = std::max(longest, sp.safe.size());
+  } else {
+    for (int32_t cell : T.dirty) longest = std::max(longest, T.spec[T.cellIdx[cell] - 1].safe.size());
+  }
+  size_t recIv = 2;
+  while (recIv < longest) recIv *= 2;
   const size_t hdrWords = (nRec + 3) & ~size_t(3);
-  if ((cs.size() & 3u) != 0 || !cs.fits(hdrWords + nRec * 2 * mrp::kSippCap)) return false;  // nothing consumed yet
+  if ((cs.size() & 3u) != 0 || !cs.fits(hdrWords + nRec * 2 * recIv)) return false;  // nothing consumed yet
   d.vc_off = static_cast<uint32_t>(cs.size());
-  uint32_t* hdr = cs.grow(hdrWords + nRec * 2 * mrp::kSippCap);
+  uint32_t* hdr = cs.grow(hdrWords + nRec * 2 * recIv);
   if (!hdr) return false;
   uint32_t* body = hdr + hdrWords;
   size_t r = 0;
   auto emit = [&](int32_t cell) {
     const mrp_ll_sipp_table::Spec& sp = T.spec[T.cellIdx[cell] - 1];
     hdr[r] = static_cast<uint32_t>(cell) | (static_cast<uint32_t>(sp.safe.size()) << 16);
-    std::memcpy(body + r * 2 * mrp::kSippCap, sp.safe.data(), sizeof(SippScratch::Iv) * sp.safe.size());
+    std::memcpy(body + r * 2 * recIv, sp.safe.data(), sizeof(SippScratch::Iv) * sp.safe.size());
     r += 1;
   };
   if (fresh) {
@@ -552,7 +561,7 @@ bool packSippResident(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, Co
   }();
   d.ctx_flags = mrp::kSippResident | (noLds ? mrp::kSippNoLds : 0u);
   d.n_ctx = T.epoch;
-  d.n_vc = static_cast<uint32_t>(T.spec.size());
+  d.n_vc = static_cast<uint32_t>(recIv);  // intervals per delta record
   d.n_ec = T.totalSafe;
   d.ec_off = static_cast<uint32_t>(nRec) | (fresh ? 0x80000000u : 0u);
   d.last_goal_constraint = startTime;
