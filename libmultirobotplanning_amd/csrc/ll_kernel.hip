@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "ll_device.h"
 
@@ -192,10 +193,45 @@ struct TierXT : TierHbm {
 typedef TierXT<3> TierMix;   // open list in LDS
 typedef TierXT<1> TierHbmX;  // ... in the arena: the last tier of a search on a resident table (entries keep their x word)
 
+// ---- the arena tier of the CBS / ECBS kernels: heaps whose first nTop entries (their top levels) live in LDS ----------
+// After a search has left the compact LDS tier its 13 KB of LDS would sit idle while every heap operation walks arrays in
+// HBM, root first.  TierHyb keeps entries [0, nTop) of the open list, the focal list and the walk queue in that LDS and
+// the rest in the arena: the roots, the first sift-down block and most of every sift-up chain cost no memory round trip
+// at all, and a heap that has at most nTop entries never leaves LDS.  nTop is odd, so an aligned child pair (c, c + 1),
+// c odd, lies on one side.  nTop = 0 (no LDS tier configured) degenerates to the plain arena tier.
+struct HybRef {
+  __attribute__((address_space(3))) uint64_t* top;
+  uint64_t* rest;
+  uint32_t nTop, i;
+  DEVI operator uint64_t() const { return i < nTop ? top[i] : rest[i]; }
+  DEVI void operator=(uint64_t e) const {
+    if (i < nTop)
+      top[i] = e;
+    else
+      rest[i] = e;
+  }
+};
+struct HybPtr {
+  __attribute__((address_space(3))) uint64_t* top;  // element i at top[i] (biased like the arena pointers)
+  uint64_t* rest;
+  uint32_t nTop;
+  DEVI HybRef operator[](uint32_t i) const { return HybRef{top, rest, nTop, i}; }
+};
+struct TierHyb : TierHbm {};
+
+template <class T>
+struct HeapPtr {
+  typedef __attribute__((address_space(T::AS))) typename T::E* type;
+};
+template <>
+struct HeapPtr<TierHyb> {
+  typedef HybPtr type;
+};
+
 template <class T>
 struct Mem {
   typedef typename T::E E;
-  typedef __attribute__((address_space(T::AS))) E* PE;
+  typedef typename HeapPtr<T>::type PE;
   typedef __attribute__((address_space(T::AS))) typename T::Pair* PPair;
   typedef __attribute__((address_space(T::AS))) uint32_t* P32;
   typedef __attribute__((address_space(T::AS))) uint16_t* P16;
@@ -272,9 +308,20 @@ constexpr int32_t ST_CAP_FOCAL = 7;
 template <class T>
 DEVI typename T::E ldU(typename Mem<T>::PE p, uint32_t i) { return T::first(p[i]); }
 
+// the aligned pair (i, i + 1), i odd: one load
+template <class T>
+DEVI typename T::Pair hLoadPair(typename Mem<T>::PE p, uint32_t i) {
+  if constexpr (std::is_same<T, TierHyb>::value) {
+    if (i < p.nTop) return *(__attribute__((address_space(3))) u64x2*)(p.top + i);
+    return *(u64x2*)(p.rest + i);
+  } else {
+    return *(typename Mem<T>::PPair)(p + i);
+  }
+}
+
 template <class T>
 DEVI void ldPair(typename Mem<T>::PE p, uint32_t i, typename T::E& a, typename T::E& b) {  // i odd -> aligned pair
-  const typename T::Pair v = *(typename Mem<T>::PPair)(p + i);
+  const typename T::Pair v = hLoadPair<T>(p, i);
   a = T::first(v.x);
   b = T::first(v.y);
 }
@@ -391,7 +438,7 @@ DEVI uint32_t descend(Mem<T>& m, typename Mem<T>::PE heap, uint32_t n, uint32_t 
     typename T::Pair pr;
     pr.x = 0;
     pr.y = 0;
-    if (has) pr = *(typename Mem<T>::PPair)(heap + c);          // children (c, c+1): one aligned load
+    if (has) pr = hLoadPair<T>(heap, c);                        // children (c, c+1): one aligned load
     const uint32_t kl = keyOf<T, KEY>(pr.x);
     const uint32_t kr = keyOf<T, KEY>(pr.y);
     const bool hasR = has && (c + 1 < n);
@@ -535,7 +582,7 @@ DEVI void popFocalEraseOpen(Mem<T>& m, uint32_t& nFocal, uint32_t& nOpen, uint32
   prF.x = 0; prF.y = 0;
   const uint32_t nodeF0 = (1u << lv) - 1 + off;
   const bool hasF0 = moreF && lane < 63 && (2 * nodeF0 + 1 < nFocal);
-  if (hasF0) prF = *(typename Mem<T>::PPair)(m.focal + 2 * nodeF0 + 1);
+  if (hasF0) prF = hLoadPair<T>(m.focal, 2 * nodeF0 + 1);
   // ---- open: every ancestor of curPos moves down one level (boost erase = bubble to the root, then pop)
   if (act) {
     const uint32_t dest = ((curPos + 1) >> lane) - 1;
@@ -555,14 +602,14 @@ DEVI void popFocalEraseOpen(Mem<T>& m, uint32_t& nFocal, uint32_t& nOpen, uint32
     prO.x = 0; prO.y = 0;
     const uint32_t nodeO = ((idxO + 1) << lv) - 1 + off;
     const bool hasO = moreO && lane < 63 && (2 * nodeO + 1 < nOpen);
-    if (hasO) prO = *(typename Mem<T>::PPair)(m.open + 2 * nodeO + 1);
+    if (hasO) prO = hLoadPair<T>(m.open, 2 * nodeO + 1);
     uint32_t nodeF = nodeF0;
     bool hasF = hasF0;
     if (!firstF) {
       nodeF = ((idxF + 1) << lv) - 1 + off;
       hasF = moreF && lane < 63 && (2 * nodeF + 1 < nFocal);
       prF.x = 0; prF.y = 0;
-      if (hasF) prF = *(typename Mem<T>::PPair)(m.focal + 2 * nodeF + 1);
+      if (hasF) prF = hLoadPair<T>(m.focal, 2 * nodeF + 1);
     }
     firstF = false;
     if (moreF)
@@ -1058,6 +1105,27 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     g.capNodes = P.arena_nodes; g.capHeap = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
   }
 
+  // ... and the view the arena tier actually runs on: the same arrays, the heaps' first nTop entries in this workgroup's
+  // LDS (the compact tier's area, free once a search has left it)
+  Mem<TierHyb> gh;
+  {
+    const uint32_t area = ldsBytes(P.lds_nodes, P.lds_rows, P.lds_row_words, 0);
+    uint32_t per = (area / 3u) & ~15u;  // bytes per heap, 16-byte aligned starts
+    uint32_t nTop = per >= 32u ? ((per - 8u) / 8u) : 0u;
+    if (nTop > 4095u) nTop = 4095u;
+    nTop = nTop ? ((nTop - 1u) | 1u) : 0u;  // odd (or 0: no LDS tier configured)
+    if (P.lds_nodes == 0) nTop = 0;
+    auto l8 = (__attribute__((address_space(3))) uint8_t*)smem;
+    gh.nodes = g.nodes;
+    gh.pos = nullptr;
+    gh.gOf = nullptr;
+    gh.open = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + 8), (uint64_t*)g.open, nTop};
+    gh.focal = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + per + 8), (uint64_t*)g.focal, nTop};
+    gh.aux = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + 2 * per + 8), (uint64_t*)g.aux, nTop};
+    gh.bits = g.bits;
+    gh.capNodes = g.capNodes; gh.capHeap = g.capHeap; gh.capRows = g.capRows; gh.rowWords = g.rowWords;
+  }
+
   // the compact tier holds f in 7 bits: every f a search can reach inside its rows must fit
   const bool ldsOk = P.lds_nodes != 0 && c.wpr <= P.lds_row_words &&
                      (P.lds_rows - 1) + (c.dimx - 1) + (c.dimy - 1) <= TierLds::kFCap;
@@ -1116,7 +1184,11 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
       const uint64_t th0 = __builtin_amdgcn_s_memrealtime();
       const int64_t e0h = s.expansions;
 #endif
-      rc = runSearch<TierHbm, EPS>(g, s, c, (Mem<TierHbm>::P32)c.obst, false, res, outPath);
+      // the heaps' top entries move (back) into LDS, now as arena-format records; everything staged above is in the arena
+      for (uint32_t i = lane; i < s.nOpen && i < gh.open.nTop; i += 64) gh.open.top[i] = g.open[i];
+      for (uint32_t i = lane; i < s.nFocal && i < gh.focal.nTop; i += 64) gh.focal.top[i] = g.focal[i];
+      __syncthreads();
+      rc = runSearch<TierHyb, EPS>(gh, s, c, (Mem<TierHyb>::P32)c.obst, false, res, outPath);
 #ifndef MRP_LL_TRACE
       res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);  // ... in the arena tier after a migration
       res.prof[3] = (uint32_t)(s.expansions - e0h);
@@ -1124,12 +1196,13 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     }
   } else {
     res.tier = 1;
-    initSearch<TierHbm, EPS>(g, s, c);
+    __syncthreads();  // previous job's LDS reads are done
+    initSearch<TierHyb, EPS>(gh, s, c);
     __syncthreads();
 #ifndef MRP_LL_TRACE
     const uint64_t th0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    rc = runSearch<TierHbm, EPS>(g, s, c, (Mem<TierHbm>::P32)c.obst, false, res, outPath);
+    rc = runSearch<TierHyb, EPS>(gh, s, c, (Mem<TierHyb>::P32)c.obst, false, res, outPath);
 #ifndef MRP_LL_TRACE
     res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);
     res.prof[3] = (uint32_t)s.expansions;
