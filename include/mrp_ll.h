@@ -182,7 +182,12 @@ int mrp_ll_path_store_reserve(mrp_ll_ctx* ctx, int32_t n_slots);
  * few collision intervals between two searches (example/mapf_prioritized_sipp.cpp:237-246) does not have to hand over —
  * and the engine re-derive — every interval of every location for every job.  mrp_ll_sipp_table_add(t, x, y, s, e)
  * appends [s, e] to that location's collision list and is equivalent to calling setCollisionIntervals(location, list)
- * with the extended list.  A table belongs to one map (its dimensions); it is not thread-safe. */
+ * with the extended list.  A table belongs to one map (its dimensions); it is not thread-safe.
+ * In a session (mrp_ll_session_begin_sipp) the table also has a DEVICE-RESIDENT copy: a job on it carries only the cells
+ * changed since the table's previous job, and the search reads the copy in place (up to 16 safe intervals per cell; a
+ * table that needs more, and any table outside a session, travels whole with each job — same results).  One job per
+ * table is in flight at a time (a second one simply travels whole).  mrp_ll_job.sipp_commit lets the engine add the
+ * found path's stays itself. */
 typedef struct mrp_ll_sipp_table mrp_ll_sipp_table;
 int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t map_id, mrp_ll_sipp_table** out);
 int mrp_ll_sipp_table_add(mrp_ll_sipp_table* t, int32_t x, int32_t y, int32_t start, int32_t end);
