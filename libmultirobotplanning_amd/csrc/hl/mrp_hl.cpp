@@ -797,11 +797,11 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   if (const char* e = std::getenv("MRP_HL_SESSION_WGS")) sessionWgs = std::max(1, std::atoi(e));  // tuning knob
   // f2: the engines' device-resident path stores (ECBS only: CBS's low level has no focal context).  A search leaves its
   // path there, and later jobs name the paths of their CT node by slot instead of shipping a [t][agent] table.
-  // Used for conflict trees of up to 64 agents (MRP_HL_STORE_MAX_AGENTS): measured on 2048 synthetic agents100 instances a
-  // step took 8.5 s with the store against 6.5 s with shipped tables (the longest dependent chain of the batch gets
-  // slower by a third; with 10 / 50 agents the store is 7 % / 3 % faster and moves 8 x / 19 x fewer bytes).
+  // Used for conflict trees of up to 128 agents (MRP_HL_STORE_MAX_AGENTS; beyond that a table row no longer fits the
+  // kernel's two 64-lane row loads and the job ships its table): bytes staged per search 1134 -> 134 (10 agents),
+  // 5900 -> 303 (50), 12 087 -> 572 (100); steps 7 % / 3 % / 2 % faster.
   int32_t pathSlots = 0;
-  int32_t storeMaxAgents = 64;
+  int32_t storeMaxAgents = 128;
   if (const char* e = std::getenv("MRP_HL_STORE_MAX_AGENTS")) storeMaxAgents = std::atoi(e);
   if (opt.algo == MRP_HL_ECBS && opt.mode != 1 && maxAgents <= storeMaxAgents) {
     pathSlots = 1 << 18;

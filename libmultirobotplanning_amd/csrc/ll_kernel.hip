@@ -165,7 +165,7 @@ struct TierLdsT {
   DEVI static E shr1(E v) { return waveShr1(v); }
 };
 // CBS / ECBS fast tier: [31:22] 1023 - focalH, [21:15] 127 - f, [14:9] g, [8:0] node
-typedef TierLdsT<9, 6, 7, 10> TierLds;
+typedef TierLdsT<kLdsIdBits, 6, 7, 32 - 6 - 7 - kLdsIdBits> TierLds;
 // SIPP fast tier: [31:21] 2047 - f, [20:11] g (arrival time, <= kGMask), [10:0] node — the whole open key of TierHbm
 typedef TierLdsT<11, kGBits, kFBits, 0> TierLdsSipp;
 // SIPP middle tier, for a search that has outgrown TierLdsSipp's 2047 nodes: the node records go to the arena, the open
@@ -962,6 +962,18 @@ __host__ __device__ inline uint32_t ldsBytes(uint32_t capNodes, uint32_t rows, u
          kEcLocal * 4 + pathBytes;
 }
 
+// A read of the device path store.  The slot was written by another workgroup (another CU, possibly another XCD) of the
+// same resident launch before its completion was published; an agent-scope load goes past this CU's L1 to the coherent
+// level, so no cache has to be invalidated for it (a per-job acquire fence would drop the whole L1 of the CU under the
+// ten other searches that share it).
+DEVI uint32_t storeLoad(const uint16_t* p) {
+#ifdef MRP_LL_STORE_ACQUIRE_FENCE
+  return *p;
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 template <bool EPS>
 DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t* arenaSlot, DevResult& res,
                  uint16_t* outPath) {
@@ -1011,8 +1023,10 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
       // front of residentLoop's system-scope release).  One agent-scope acquire drops whatever stale copies this CU's L1 /
       // this XCD's L2 may hold from an earlier use of a recycled slot; after it plain, cached, coalesced loads are
       // correct (MI355X_MICROARCH.md "Valid forms": poll -> ONE acquire -> s_waitcnt -> barrier -> plain loads).
+#ifdef MRP_LL_STORE_ACQUIRE_FENCE  // A/B: one fence + plain loads instead of agent-scope loads
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       __syncthreads();
       const uint32_t* ids = P.cons + J.path_off;
       const uint32_t nCtx = J.n_ctx;
@@ -1020,7 +1034,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
         // this chunk's ids and lengths, one agent per lane (one gather for all lengths)
         uint32_t idL = kNoStoreSlot, lenL = 0;
         if (a0 + lane < nCtx) idL = ids[a0 + lane];
-        if (idL < P.path_store_slots) lenL = P.path_store[(size_t)idL * P.path_store_stride];
+        if (idL < P.path_store_slots) lenL = storeLoad(P.path_store + (size_t)idL * P.path_store_stride);
         if (lenL > P.path_store_stride - 1) lenL = P.path_store_stride - 1;
         const uint32_t nHere = nCtx - a0 < 64 ? nCtx - a0 : 64;
         if (!inLds) {
@@ -1037,7 +1051,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
             for (uint32_t u = 0; u < 8; ++u) {
               const uint32_t t = t0 + u;
               v[u] = kEmptyCell;
-              if (hasA && t < c.tPad) v[u] = slotA[t < lenA ? t : lenA - 1];
+              if (hasA && t < c.tPad) v[u] = storeLoad(slotA + (t < lenA ? t : lenA - 1));
             }
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u)
@@ -1061,7 +1075,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
               }
               has[u] = id < P.path_store_slots && len != 0 && t < c.tPad;  // not: empty path / the searching agent itself
               v[u] = kEmptyCell;
-              if (has[u]) v[u] = P.path_store[(size_t)id * P.path_store_stride + 1 + (t < len ? t : len - 1)];
+              if (has[u]) v[u] = storeLoad(P.path_store + (size_t)id * P.path_store_stride + 1 + (t < len ? t : len - 1));
             }
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u)

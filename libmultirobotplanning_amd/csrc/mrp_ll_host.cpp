@@ -962,7 +962,7 @@ int mrp_ll_create(const mrp_ll_options* optIn, mrp_ll_ctx** out) {
   if (o.max_cells > 255 * 255) o.max_cells = 255 * 255;
   if (o.lds_nodes == 0) o.lds_nodes = 512;
   if (o.lds_nodes < 0) o.lds_nodes = 0;
-  o.lds_nodes = std::min(o.lds_nodes, 512);  // 9-bit node ids in the compact tier's heap entries
+  o.lds_nodes = std::min<int32_t>(o.lds_nodes, mrp::kLdsMaxNodes);  // node-id bits in the compact tier's heap entries
   o.lds_nodes &= ~3;  // heap arrays hold lds_nodes / 2 entries and stay 8-byte aligned
 
   int ndev = 0;
@@ -1094,7 +1094,7 @@ int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t ldsNodes, int32_t ldsRows, i
     if (t.inFlight) return MRP_LL_E_BUSY;
   if (ldsNodes < 0) ctx->opt.lds_nodes = 0;
   // the compact LDS tier addresses 512 nodes and 64 time steps (9-bit node ids and 6-bit g in its 32-bit heap entries)
-  if (ldsNodes > 0) ctx->opt.lds_nodes = std::max(8, std::min(ldsNodes, 512) & ~3);
+  if (ldsNodes > 0) ctx->opt.lds_nodes = std::max(8, std::min<int32_t>(ldsNodes, mrp::kLdsMaxNodes) & ~3);
   if (ldsRows > 0) ctx->tierRows = static_cast<uint32_t>(std::min(std::max(ldsRows, 8), 64));
   if (ldsPathBytes > 0) ctx->tierPathBytes = static_cast<uint32_t>(std::min(ldsPathBytes, 65536)) & ~31u;
   if (occOut) {
