@@ -31,11 +31,16 @@ struct Path {                 // PlanResult of one agent (planresult.hpp:18-27);
   int32_t cost = 0;
   int32_t fmin = 0;
   bool fits8 = false;         // every coordinate is in 0..255 (set by whoever fills xy; enables the linear scans)
+  std::vector<uint16_t> cell; // fits8 only: x | y << 8 per state (packCells), what the vectorised conflict counts read
   // the search that produced this path also left it in the engine's device path store; the slot goes back
   // to its pool with the last conflict-tree node that shares the path (ecbs.hpp:253 would have copied it instead)
   int32_t devSlot = -1;
   SlotPool* pool = nullptr;
   int32_t len() const { return static_cast<int32_t>(xy.size() / 2); }
+  void packCells() {
+    cell.resize(xy.size() / 2);
+    for (size_t k = 0; k < cell.size(); ++k) cell[k] = static_cast<uint16_t>(xy[2 * k] | (xy[2 * k + 1] << 8));
+  }
   Path() = default;
   Path(const Path&) = delete;
   Path& operator=(const Path&) = delete;
@@ -265,6 +270,32 @@ inline int32_t countConflicts(const std::vector<PathPtr>& sol, std::vector<int32
 inline int32_t conflictsOfAgent(const std::vector<PathPtr>& sol, int32_t ag, const Path& p, int32_t T) {
   const int32_t n = static_cast<int32_t>(sol.size());
   int32_t total = 0;
+  // With 50-100 agents this count (twice per conflict-tree child) was most of a worker thread's time.  When every path
+  // carries its packed cells, agent p's cells are laid out once for t = 0..T (clamped as getState does) and each other
+  // path is compared in two branch-free loops the compiler vectorises: while q still moves, and after q has stopped.
+  bool packed = !p.cell.empty() && static_cast<int32_t>(p.cell.size()) == p.len();
+  for (int32_t j = 0; j < n && packed; ++j)
+    if (j != ag && (sol[j]->cell.empty() || static_cast<int32_t>(sol[j]->cell.size()) != sol[j]->len())) packed = false;
+  if (packed && T > 0) {
+    static thread_local std::vector<uint16_t> pc;
+    pc.resize(static_cast<size_t>(T) + 2);
+    const int32_t lp = p.len();
+    for (int32_t t = 0; t <= T + 1; ++t) pc[t] = p.cell[t < lp ? t : lp - 1];
+    const uint16_t* P0 = pc.data();
+    for (int32_t j = 0; j < n; ++j) {
+      if (j == ag) continue;
+      const Path& q = *sol[j];
+      const uint16_t* Q = q.cell.data();
+      const int32_t lq = q.len();
+      const int32_t m = std::min(T, lq - 1);  // t < m: q(t) and q(t+1) are both real states
+      int32_t c = 0;
+      for (int32_t t = 0; t < m; ++t) c += (P0[t] == Q[t]) + ((P0[t] == Q[t + 1]) & (P0[t + 1] == Q[t]));
+      const uint16_t g = Q[lq - 1];           // from then on q stays on its last cell
+      for (int32_t t = m; t < T; ++t) c += (P0[t] == g) + ((P0[t] == g) & (P0[t + 1] == g));
+      total += c;
+    }
+    return total;
+  }
   for (int32_t j = 0; j < n; ++j) {
     if (j == ag) continue;
     const Path& q = *sol[j];

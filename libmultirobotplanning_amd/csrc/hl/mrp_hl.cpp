@@ -112,6 +112,7 @@ LLAnswer answerOf(const mrp_ll_result& r, int32_t slot = -1, SlotPool* pool = nu
       orAll |= static_cast<uint32_t>(p->xy[2 * s]) | static_cast<uint32_t>(p->xy[2 * s + 1]);
     }
     p->fits8 = orAll < 256u;
+    if (p->fits8) p->packCells();
     p->cost = r.cost;
     p->fmin = r.fmin;
     if (pool && slot >= 0) {
