@@ -210,11 +210,12 @@ struct mrp_ll_ctx {
   std::vector<SessTicket> sess;
   std::vector<int32_t> sessFree;   // free session-ticket ids (stack)
   void* sippScratch = nullptr;     // SippScratch, created on first use (packSipp)
-  // device-resident SIPP tables: chunks of kSippTablesPerChunk tables of sippTabStride bytes each
+  // device-resident SIPP tables: chunks of sippTabsPerChunk tables of sippTabStride bytes each (about 64 MB a chunk)
   std::vector<uint8_t*> sippTabChunks;
   std::vector<int32_t> sippTabFree;
   int32_t sippTabNext = 0;
   size_t sippTabStride = 0;
+  int32_t sippTabsPerChunk = 64;
   uint16_t* pathStore = nullptr;   // device-resident path store (mrp_ll_path_store_reserve)
   uint32_t pathStoreStride = 0, pathStoreSlots = 0;
   uint8_t* scanDev = nullptr;      // mrp_ll_conflict_scan: device staging (grown on demand)
@@ -500,7 +501,6 @@ bool packSippFromTable(const mrp_ll_job& j, const MapRec& mp, ConsSink& cs, DevJ
   return !cs.failed;
 }
 
-constexpr int32_t kSippTablesPerChunk = 64;
 
 // Session mode: the job carries the delta of a device-resident table (ll_device.h kSippResident).  `T` is updated (its
 // dirty list is consumed, it is marked in flight), so the job MUST run — sessionSubmit publishes it right away.
@@ -549,8 +549,8 @@ bool packSippResident(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, Co
   T.devFresh = false;
   T.epoch += 1;
   T.inFlight = true;
-  const uint64_t addr = reinterpret_cast<uint64_t>(ctx->sippTabChunks[T.devIndex / kSippTablesPerChunk]) +
-                        static_cast<uint64_t>(T.devIndex % kSippTablesPerChunk) * ctx->sippTabStride;
+  const uint64_t addr = reinterpret_cast<uint64_t>(ctx->sippTabChunks[T.devIndex / ctx->sippTabsPerChunk]) +
+                        static_cast<uint64_t>(T.devIndex % ctx->sippTabsPerChunk) * ctx->sippTabStride;
   d.algo = MRP_LL_SIPP;
   d.max_expansions = j.max_expansions;
   d.n_agents_pad = static_cast<uint32_t>(addr);
@@ -1728,17 +1728,18 @@ int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t mapId, mrp_ll_sipp_table**
   if (ctx->sippTabStride == 0) {
     const size_t maxCells = static_cast<size_t>(ctx->opt.max_cells);
     ctx->sippTabStride = ((maxCells + 255) & ~size_t(255)) + maxCells * mrp::kSippCap * 12;  // cnt, iv, status
+    ctx->sippTabsPerChunk = static_cast<int32_t>(std::max<size_t>(1, std::min<size_t>(64, (size_t(64) << 20) / ctx->sippTabStride)));
   }
   if (!ctx->sippTabFree.empty()) {
     t->devIndex = ctx->sippTabFree.back();
     ctx->sippTabFree.pop_back();
   } else {
-    if (ctx->sippTabNext == static_cast<int32_t>(ctx->sippTabChunks.size()) * kSippTablesPerChunk) {
+    if (ctx->sippTabNext == static_cast<int32_t>(ctx->sippTabChunks.size()) * ctx->sippTabsPerChunk) {
       void* c = nullptr;
-      if (hipSetDevice(ctx->device) == hipSuccess && hipMalloc(&c, ctx->sippTabStride * kSippTablesPerChunk) == hipSuccess)
+      if (hipSetDevice(ctx->device) == hipSuccess && hipMalloc(&c, ctx->sippTabStride * ctx->sippTabsPerChunk) == hipSuccess)
         ctx->sippTabChunks.push_back(static_cast<uint8_t*>(c));
     }
-    if (ctx->sippTabNext < static_cast<int32_t>(ctx->sippTabChunks.size()) * kSippTablesPerChunk) t->devIndex = ctx->sippTabNext++;
+    if (ctx->sippTabNext < static_cast<int32_t>(ctx->sippTabChunks.size()) * ctx->sippTabsPerChunk) t->devIndex = ctx->sippTabNext++;
   }
   *out = t;
   return MRP_LL_SUCCESS;
