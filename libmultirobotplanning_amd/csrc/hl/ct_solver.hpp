@@ -30,7 +30,7 @@ namespace mrp_hl {
 struct LLRequest {            // one pending low-level search of an instance
   int32_t agent;
   ConsPtr constraints;        // constraint set of `agent` in the (child) node
-  const std::vector<PathPtr>* context;  // ECBS: the node's solution vector as the focal heuristics see it
+  const PathVec* context;  // ECBS: the node's solution vector as the focal heuristics see it
   int32_t slot;               // position of the answer inside its group
   int32_t group;              // kRootGroup, or the id of the CT node these searches expand; requests of one group are
                               // consecutive and are answered together
@@ -68,7 +68,7 @@ class Instance {
   int64_t llExpanded() const { return llExpanded_; }
   int32_t llSearches() const { return llSearches_; }
   int64_t specSearches() const { return specSearches_; }  // searches issued ahead of their node's pop
-  const std::vector<PathPtr>& finalSolution() const { return final_; }
+  const PathVec& finalSolution() const { return final_; }
   int64_t remainingLL() const { return capLL_ < 0 ? -1 : std::max<int64_t>(0, capLL_ - llExpanded_); }
   // CT nodes whose children may be computed at the same time (1 = the popped node only, i.e. no speculation)
   void setSpecWidth(int32_t k) { specWidth_ = std::max(1, k); }
@@ -100,7 +100,7 @@ class Instance {
             finish(MRP_HL_NO_SOLUTION);
             return;
           }
-          root_.solution[i] = answers[i].path;
+          root_.solution.set(i, answers[i].path);
           root_.cost += answers[i].cost;
         }
       } else {
@@ -109,7 +109,7 @@ class Instance {
           finish(MRP_HL_NO_SOLUTION);
           return;
         }
-        root_.solution[rootAgent_] = a.path;
+        root_.solution.set(rootAgent_, a.path);
         root_.cost += a.cost;
         root_.LB += a.fmin;
         rootAgent_ += 1;
@@ -275,7 +275,7 @@ class Instance {
     for (int k = 0; k < 2; ++k) {
       auto ch = std::make_shared<CTNode>(P);  // shares every path / constraint set with the parent
       const int32_t ag = ags[k];
-      ch->constraints[ag] = withAdded(P.constraints[ag], *adds[k]);
+      ch->constraints.set(ag, withAdded(P.constraints[ag], *adds[k]));
       ch->cost -= P.solution[ag]->cost;
       if (algo_ == MRP_HL_ECBS) ch->LB -= P.solution[ag]->fmin;
       b.child[k] = ch;
@@ -303,7 +303,7 @@ class Instance {
       if (a.status == MRP_LL_OK) {
         const PathPtr oldPath = ch.solution[ag];  // the parent's path of this agent
         const int32_t oldT = maxT(ch.solution);
-        ch.solution[ag] = a.path;
+        ch.solution.set(ag, a.path);
         ch.cost += a.cost;
         if (algo_ == MRP_HL_ECBS) {
           ch.LB += a.fmin;
@@ -368,7 +368,7 @@ class Instance {
   int32_t specWidth_ = 1;
   std::unordered_map<int32_t, Branch> branches_;  // storage index of a CT node -> its expansion
   std::vector<int32_t> cand_;
-  std::vector<PathPtr> final_;
+  PathVec final_;
   int64_t hlExpanded_ = 0, llExpanded_ = 0, specSearches_ = 0;
   int32_t llSearches_ = 0;
   std::vector<int32_t> scratch_;

@@ -64,9 +64,60 @@ struct Conflict {             // ecbs.cpp:80-106
   int32_t x1, y1, x2, y2;
 };
 
+// The per-agent arrays of a conflict-tree node.  A child is its parent with ONE entry replaced (ecbs.hpp:253-263 copies
+// all N PlanResults); a plain vector of shared_ptr still touches N reference counts — N cache lines — per copy and per
+// destruction, which with 100 agents was most of a tree step.  Entries therefore live in shared chunks of 16: copying a
+// node copies N / 16 chunk pointers, replacing an entry clones one chunk.
+template <class P>
+class CowVec {
+ public:
+  static constexpr size_t kChunk = 16;
+  struct Chunk {
+    P v[kChunk];
+  };
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  const P& operator[](size_t i) const { return chunks_[i / kChunk]->v[i % kChunk]; }
+  void assign(size_t n, const P& value) {
+    n_ = n;
+    chunks_.clear();
+    if (n == 0) return;
+    auto c = std::make_shared<Chunk>();
+    for (size_t k = 0; k < kChunk; ++k) c->v[k] = value;
+    chunks_.assign((n + kChunk - 1) / kChunk, c);  // chunks are immutable once shared: one chunk serves them all
+  }
+  void set(size_t i, const P& value) {
+    std::shared_ptr<Chunk>& c = chunks_[i / kChunk];
+    if (c.use_count() != 1) c = std::make_shared<Chunk>(*c);
+    c->v[i % kChunk] = value;
+  }
+  class const_iterator {
+   public:
+    const_iterator(const CowVec* v, size_t i) : v_(v), i_(i) {}
+    const P& operator*() const { return (*v_)[i_]; }
+    const_iterator& operator++() {
+      ++i_;
+      return *this;
+    }
+    bool operator!=(const const_iterator& o) const { return i_ != o.i_; }
+
+   private:
+    const CowVec* v_;
+    size_t i_;
+  };
+  const_iterator begin() const { return const_iterator(this, 0); }
+  const_iterator end() const { return const_iterator(this, n_); }
+
+ private:
+  size_t n_ = 0;
+  std::vector<std::shared_ptr<Chunk>> chunks_;
+};
+typedef CowVec<PathPtr> PathVec;
+typedef CowVec<ConsPtr> ConsVec;
+
 struct CTNode {               // HighLevelNode (cbs.hpp:175-207, ecbs.hpp:308-342)
-  std::vector<PathPtr> solution;
-  std::vector<ConsPtr> constraints;
+  PathVec solution;
+  ConsVec constraints;
   int32_t cost = 0;
   int32_t LB = 0;
   int32_t focalHeuristic = 0;
@@ -80,7 +131,7 @@ inline void cellAt(const Path& p, int32_t t, int32_t& x, int32_t& y) {
   y = p.xy[2 * k + 1];
 }
 
-inline int32_t maxT(const std::vector<PathPtr>& sol) {
+inline int32_t maxT(const PathVec& sol) {
   int32_t m = 0;
   for (const auto& p : sol) m = std::max<int32_t>(m, p->len() - 1);
   return m;
@@ -104,7 +155,7 @@ struct CellTable {
     return t;
   }
 };
-inline bool fitsCellTable(const std::vector<PathPtr>& sol) {
+inline bool fitsCellTable(const PathVec& sol) {
   for (const auto& p : sol)
     if (!p->fits8) return false;
   return true;
@@ -113,7 +164,7 @@ inline bool fitsCellTable(const std::vector<PathPtr>& sol) {
 // getFirstConflict (ecbs.cpp:401-452): scan order is t ascending; at each t all vertex pairs (i<j) before all
 // swap pairs (i<j); the final time step is never checked (t < max_t).  Quadratic restatement, kept for grids whose
 // coordinates do not fit the cell table and as the cross-check of the linear scan in the CPU tests.
-inline bool firstConflictQuadratic(const std::vector<PathPtr>& sol, Conflict& out, std::vector<int32_t>& scratch) {
+inline bool firstConflictQuadratic(const PathVec& sol, Conflict& out, std::vector<int32_t>& scratch) {
   const int32_t n = static_cast<int32_t>(sol.size());
   const int32_t T = maxT(sol);
   scratch.resize(static_cast<size_t>(n) * 4);
@@ -146,7 +197,7 @@ inline bool firstConflictQuadratic(const std::vector<PathPtr>& sol, Conflict& ou
 //  * swap: reached only when no two agents share a cell at t, so "the agent now standing on i's next cell" is unique;
 //    scanning i upwards, the first i whose partner moves onto i's cell is the first pair in (i<j) order (a partner
 //    j < i would have reported the pair when the scan was at j).
-inline bool firstConflict(const std::vector<PathPtr>& sol, Conflict& out, std::vector<int32_t>& scratch) {
+inline bool firstConflict(const PathVec& sol, Conflict& out, std::vector<int32_t>& scratch) {
   if (!fitsCellTable(sol)) return firstConflictQuadratic(sol, out, scratch);
   const int32_t n = static_cast<int32_t>(sol.size());
   const int32_t T = maxT(sol);
@@ -195,7 +246,7 @@ inline bool firstConflict(const std::vector<PathPtr>& sol, Conflict& out, std::v
 }
 
 // focalHeuristic (ecbs.cpp:315-350): number of vertex + swap conflicts over all pairs and t < max_t
-inline int32_t countConflictsQuadratic(const std::vector<PathPtr>& sol, std::vector<int32_t>& scratch) {
+inline int32_t countConflictsQuadratic(const PathVec& sol, std::vector<int32_t>& scratch) {
   const int32_t n = static_cast<int32_t>(sol.size());
   const int32_t T = maxT(sol);
   scratch.resize(static_cast<size_t>(n) * 4);
@@ -220,7 +271,7 @@ inline int32_t countConflictsQuadratic(const std::vector<PathPtr>& sol, std::vec
 // The same integer with the cell table: agents on one cell are chained (who = last entered, link[] = the one before),
 // an agent entering a cell that already holds c agents adds c vertex conflicts, and the swap partners of agent i are
 // the agents j > i now on i's next cell whose next cell is i's current one.
-inline int32_t countConflicts(const std::vector<PathPtr>& sol, std::vector<int32_t>& scratch) {
+inline int32_t countConflicts(const PathVec& sol, std::vector<int32_t>& scratch) {
   if (!fitsCellTable(sol)) return countConflictsQuadratic(sol, scratch);
   const int32_t n = static_cast<int32_t>(sol.size());
   const int32_t T = maxT(sol);
@@ -267,7 +318,7 @@ inline int32_t countConflicts(const std::vector<PathPtr>& sol, std::vector<int32
 // so while the scan horizon T = max_t is unchanged its focal heuristic is
 //     parent's value - conflictsOfAgent(parent's path of ag) + conflictsOfAgent(new path of ag)
 // which is O(T*N) instead of the reference's O(T*N^2); the integers are the same (sum over the same pairs and steps).
-inline int32_t conflictsOfAgent(const std::vector<PathPtr>& sol, int32_t ag, const Path& p, int32_t T) {
+inline int32_t conflictsOfAgent(const PathVec& sol, int32_t ag, const Path& p, int32_t T) {
   const int32_t n = static_cast<int32_t>(sol.size());
   int32_t total = 0;
   // With 50-100 agents this count (twice per conflict-tree child) was most of a worker thread's time.  When every path

@@ -15,7 +15,8 @@ int main(int argc, char** argv) {
   for (int c = 0; c < cases; ++c) {
     const int n = 1 + rng() % 12;
     const int side = 2 + rng() % 5;  // tiny grids: plenty of vertex and swap conflicts
-    std::vector<PathPtr> sol;
+    PathVec sol;
+    sol.assign(n, PathPtr());
     for (int a = 0; a < n; ++a) {
       auto p = std::make_shared<Path>();
       const int len = 1 + rng() % 9;
@@ -31,7 +32,7 @@ int main(int argc, char** argv) {
       }
       p->cost = len - 1;
       p->fits8 = true;
-      sol.push_back(p);
+      sol.set(a, p);
     }
     Conflict a{}, b{};
     const bool fa = firstConflict(sol, a, s1), fb = firstConflictQuadratic(sol, b, s2);
