@@ -108,6 +108,8 @@ struct TierHbm {
   static constexpr int NAS = 1;  // ... of the node records
   static constexpr bool kWideNodes = true;   // four words per node (the position of its open entry in word 3)
   static constexpr bool kEntryHasX = false;
+  static constexpr bool kEntryXy = false;    // A* tiers: the entry also carries the node's x | y << 8 (TierHybXy)
+  static constexpr bool kHybrid = false;
   typedef uint64_t E;
   typedef u64x2 Pair;
   static constexpr uint32_t kFhCap = kFhMax;
@@ -139,6 +141,8 @@ struct TierLdsT {
   static constexpr int NAS = 3;
   static constexpr bool kWideNodes = false;  // one word per node + a halfword position array
   static constexpr bool kEntryHasX = false;
+  static constexpr bool kEntryXy = false;
+  static constexpr bool kHybrid = false;
   typedef uint32_t E;
   typedef u32x2 Pair;
   static constexpr uint32_t kIdBits = ID, kGB = GBITS, kFB = FBITS, kFhB = FHBITS;
@@ -217,14 +221,27 @@ struct HybPtr {
   uint32_t nTop;
   DEVI HybRef operator[](uint32_t i) const { return HybRef{top, rest, nTop, i}; }
 };
-struct TierHyb : TierHbm {};
+struct TierHyb : TierHbm {
+  static constexpr bool kHybrid = true;
+};
+// ... and, for arenas of at most 65 536 nodes (the conflict-tree drivers' default), the node id takes 16 bits of the
+// entry's low word and the node's x | y << 8 the other 16: the expansion then knows its cell from the entry alone and
+// requests its bitmap word and the other agents' rows TOGETHER with the node record (which it still needs for the open
+// position) instead of after it — one memory round trip less per expansion.
+struct TierHybXy : TierHbm {
+  static constexpr bool kHybrid = true;
+  static constexpr bool kEntryXy = true;
+  DEVI static uint32_t id(E e) { return (uint32_t)e & 0xFFFFu; }
+  DEVI static uint32_t xyOf(E e) { return ((uint32_t)e >> 16) & 0xFFFFu; }
+  DEVI static E withXy(E e, uint32_t xy) { return e | ((uint64_t)(xy & 0xFFFFu) << 16); }
+};
 
-template <class T>
+template <class T, bool HYB = T::kHybrid>
 struct HeapPtr {
   typedef __attribute__((address_space(T::AS))) typename T::E* type;
 };
-template <>
-struct HeapPtr<TierHyb> {
+template <class T>
+struct HeapPtr<T, true> {
   typedef HybPtr type;
 };
 
@@ -311,7 +328,7 @@ DEVI typename T::E ldU(typename Mem<T>::PE p, uint32_t i) { return T::first(p[i]
 // the aligned pair (i, i + 1), i odd: one load
 template <class T>
 DEVI typename T::Pair hLoadPair(typename Mem<T>::PE p, uint32_t i) {
-  if constexpr (std::is_same<T, TierHyb>::value) {
+  if constexpr (T::kHybrid) {
     if (i < p.nTop) return *(__attribute__((address_space(3))) u64x2*)(p.top + i);
     return *(u64x2*)(p.rest + i);
   } else {
@@ -722,7 +739,8 @@ DEVI void initSearch(Mem<T>& m, SState& s, const Ctx& c) {
     n0.w = 0;
     ((typename Mem<T>::PNode4)m.nodes)[0] = n0;
   }
-  const typename T::E e0 = T::pack(0, h0, 0, 0);
+  typename T::E e0 = T::pack(0, h0, 0, 0);
+  if constexpr (T::kEntryXy) e0 = T::withXy(e0, c.sx | (c.sy << 8));
   m.open[0] = e0;
   if (EPS) m.focal[0] = e0;
 }
@@ -760,8 +778,14 @@ DEVI int runSearch(Mem<T>& m, SState& s, const Ctx& c, typename Mem<T>::P32 obst
     const uint32_t curId = T::id(curE);
     const uint32_t t = T::g(curE);
     const uint32_t curFh = T::fh(curE);
-    uint32_t xy, curPos;
-    nodeXyPos<T>(m, curId, xy, curPos);
+    uint32_t xy, curPos = 0;
+    uint32_t curPosV = 0;  // kEntryXy: the open position as loaded (waited for only where popFocalEraseOpen needs it)
+    if constexpr (T::kEntryXy) {
+      xy = T::xyOf(curE);
+      if (EPS) curPosV = m.nodes[curId * 4 + 3];
+    } else {
+      nodeXyPos<T>(m, curId, xy, curPos);
+    }
     const uint32_t x = xy & 0xFF, y = xy >> 8;
     const bool isGoal = (x == c.gx) && (y == c.gy) && ((int32_t)t > c.lastGoal);
     DBG(c, 6, xy | (t << 16));
@@ -836,6 +860,7 @@ DEVI int runSearch(Mem<T>& m, SState& s, const Ctx& c, typename Mem<T>::P32 obst
     {
       PROF_T0();
       if (EPS) {
+        if constexpr (T::kEntryXy) curPos = rfl(curPosV);
         popFocalEraseOpen<T>(m, s.nFocal, s.nOpen, curPos);
       } else {
         heapPop<T, 0, true>(m, m.open, s.nOpen);
@@ -897,7 +922,8 @@ DEVI int runSearch(Mem<T>& m, SState& s, const Ctx& c, typename Mem<T>::P32 obst
       }
       if (T::AS != 3 && ballot64(mine && fh > T::kFhCap)) return ST_CAP_FOCAL;
     }
-    const E eMine = T::pack(fh, f, t1, nid);
+    E eMine = T::pack(fh, f, t1, nid);
+    if constexpr (T::kEntryXy) eMine = T::withXy(eMine, nx | (ny << 8));
     const float bound = __fmul_rn((float)s.bestF, c.w);  // a_star_epsilon.hpp:240, binary32
     const uint32_t maskF = EPS ? (uint32_t)(ballot64(mine && (float)(int32_t)f <= bound) & 0x1Full) : 0u;
     if (mine) {
@@ -1139,6 +1165,11 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     gh.bits = g.bits;
     gh.capNodes = g.capNodes; gh.capHeap = g.capHeap; gh.capRows = g.capRows; gh.rowWords = g.rowWords;
   }
+  const bool xyEntries = P.arena_nodes <= 65536u;  // TierHybXy: 16-bit node ids leave room for the cell in the entry
+  Mem<TierHybXy> ghx;
+  ghx.nodes = gh.nodes; ghx.pos = nullptr; ghx.gOf = nullptr;
+  ghx.open = gh.open; ghx.focal = gh.focal; ghx.aux = gh.aux; ghx.bits = gh.bits;
+  ghx.capNodes = gh.capNodes; ghx.capHeap = gh.capHeap; ghx.capRows = gh.capRows; ghx.rowWords = gh.rowWords;
 
   // the compact tier holds f in 7 bits: every f a search can reach inside its rows must fit
   const bool ldsOk = P.lds_nodes != 0 && c.wpr <= P.lds_row_words &&
@@ -1185,11 +1216,15 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
       }
       for (uint32_t i = lane; i < s.nOpen; i += 64) {
         const uint32_t e = m.open[i];
-        g.open[i] = TierHbm::pack(TierLds::fh(e), TierLds::f(e), TierLds::g(e), TierLds::id(e));
+        uint64_t w = TierHbm::pack(TierLds::fh(e), TierLds::f(e), TierLds::g(e), TierLds::id(e));
+        if (xyEntries) w = TierHybXy::withXy(w, m.nodes[TierLds::id(e)] & 0xFFFFu);
+        g.open[i] = w;
       }
       for (uint32_t i = lane; i < s.nFocal; i += 64) {
         const uint32_t e = m.focal[i];
-        g.focal[i] = TierHbm::pack(TierLds::fh(e), TierLds::f(e), TierLds::g(e), TierLds::id(e));
+        uint64_t w = TierHbm::pack(TierLds::fh(e), TierLds::f(e), TierLds::g(e), TierLds::id(e));
+        if (xyEntries) w = TierHybXy::withXy(w, m.nodes[TierLds::id(e)] & 0xFFFFu);
+        g.focal[i] = w;
       }
       for (uint32_t r = 0; r < s.rowsReady; ++r)
         for (uint32_t wd = lane; wd < c.wpr; wd += 64) g.bits[r * g.rowWords + wd] = m.bits[r * m.rowWords + wd];
@@ -1202,7 +1237,10 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
       for (uint32_t i = lane; i < s.nOpen && i < gh.open.nTop; i += 64) gh.open.top[i] = g.open[i];
       for (uint32_t i = lane; i < s.nFocal && i < gh.focal.nTop; i += 64) gh.focal.top[i] = g.focal[i];
       __syncthreads();
-      rc = runSearch<TierHyb, EPS>(gh, s, c, (Mem<TierHyb>::P32)c.obst, false, res, outPath);
+      if (xyEntries)
+        rc = runSearch<TierHybXy, EPS>(ghx, s, c, (Mem<TierHybXy>::P32)c.obst, false, res, outPath);
+      else
+        rc = runSearch<TierHyb, EPS>(gh, s, c, (Mem<TierHyb>::P32)c.obst, false, res, outPath);
 #ifndef MRP_LL_TRACE
       res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);  // ... in the arena tier after a migration
       res.prof[3] = (uint32_t)(s.expansions - e0h);
@@ -1211,12 +1249,18 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   } else {
     res.tier = 1;
     __syncthreads();  // previous job's LDS reads are done
-    initSearch<TierHyb, EPS>(gh, s, c);
+    if (xyEntries)
+      initSearch<TierHybXy, EPS>(ghx, s, c);
+    else
+      initSearch<TierHyb, EPS>(gh, s, c);
     __syncthreads();
 #ifndef MRP_LL_TRACE
     const uint64_t th0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    rc = runSearch<TierHyb, EPS>(gh, s, c, (Mem<TierHyb>::P32)c.obst, false, res, outPath);
+    if (xyEntries)
+      rc = runSearch<TierHybXy, EPS>(ghx, s, c, (Mem<TierHybXy>::P32)c.obst, false, res, outPath);
+    else
+      rc = runSearch<TierHyb, EPS>(gh, s, c, (Mem<TierHyb>::P32)c.obst, false, res, outPath);
 #ifndef MRP_LL_TRACE
     res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);
     res.prof[3] = (uint32_t)s.expansions;
