@@ -11,6 +11,7 @@ t0 = time.time()
 insts = hl.generate_instances(1000 * agents, n_inst, 32, 32, 204, agents)
 print("generated %d instances in %.2fs" % (n_inst, time.time() - t0), flush=True)
 s = hl.BatchSolver(device=0, n_threads=threads, slots=slots, lds_nodes=int(os.environ.get('MRP_LDS_NODES', '0')),
+                   arena_nodes=int(os.environ.get('MRP_ARENA_NODES', '0')),
                    _lib_path=os.environ.get('MRP_HL_LIB'))  # MRP_HL_LIB: A/B against another build of libmrp_hl.so
 print("solver created %.2fs" % (time.time() - t0), flush=True)
 cpu_n = int(sys.argv[5]) if len(sys.argv) > 5 else 0
