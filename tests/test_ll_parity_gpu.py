@@ -94,17 +94,24 @@ def test_cbs_low_level_calls_8x8(engine, oracle_mod, bench_instances, ref_tests)
 
 
 def test_tiers_agree(oracle_mod, bench_instances):
-    """Same jobs through (a) a tiny LDS tier that forces migration, (b) the HBM tier only: identical results."""
+    """Same jobs through (a) a tiny LDS tier that forces migration, (b) the arena tier only — each with the default arena
+    (131 072 nodes: 32-bit node ids in the heap entries) and with a 65 536-node arena (16-bit ids, the entries carry the
+    node's cell; the conflict-tree drivers' default): identical results.  Agents50 jobs add heaps deeper than the part
+    of them that lives in LDS."""
     from libmultirobotplanning_amd import ll
     cases = _harvest(oracle_mod, bench_instances, ["map_32by32_obst204_agents10_ex%d" % k for k in range(4)],
                      oracle_mod.ECBS, 1.3, 3_000_000)
+    big = _harvest(oracle_mod, bench_instances, ["map_32by32_obst204_agents50_ex1"], oracle_mod.ECBS, 1.3, 3_000_000)
     for lds_nodes in (32, -1):
-        eng = ll.LowLevelEngine(device=0, lds_nodes=lds_nodes, n_tickets=1, slots=256)
-        try:
-            res = _run_and_compare(eng, cases, ll.ASTAR_EPS, 1.3)
-            assert any(r.tier == 1 for r in res)
-        finally:
-            eng.close()
+        for arena_nodes in (0, 65536):
+            eng = ll.LowLevelEngine(device=0, lds_nodes=lds_nodes, arena_nodes=arena_nodes, n_tickets=1, slots=256)
+            try:
+                res = _run_and_compare(eng, cases, ll.ASTAR_EPS, 1.3)
+                assert any(r.tier == 1 for r in res)
+                res = _run_and_compare(eng, big, ll.ASTAR_EPS, 1.3)
+                assert any(r.tier == 1 and r.expanded > 2000 for r in res)
+            finally:
+                eng.close()
 
 
 def test_random_jobs_with_many_constraints(engine, oracle_mod):
