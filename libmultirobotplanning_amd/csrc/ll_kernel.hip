@@ -1828,7 +1828,12 @@ DEVI bool sippCommitPath(const SippView<true>& tv, const uint32_t* path, uint32_
 }
 
 // LDS of a resident SIPP workgroup: TierLdsSipp's nodes, positions, g and open list — or TierMix's open list alone
-constexpr uint32_t kSippLdsBytesC = TierLdsSipp::kMaxNodes * (4 + 2 + 2) + TierLdsSipp::kMaxNodes * 4 + 16;
+#ifndef MRP_LL_SIPP_LDS_NODES
+#define MRP_LL_SIPP_LDS_NODES 2048
+#endif
+constexpr uint32_t kSippLdsCap = MRP_LL_SIPP_LDS_NODES;  // <= TierLdsSipp::kMaxNodes; ids 0 .. kSippLdsCap - 2 are used
+static_assert(kSippLdsCap <= TierLdsSipp::kMaxNodes && kSippLdsCap % 4 == 0, "SIPP LDS tier capacity");
+constexpr uint32_t kSippLdsBytesC = kSippLdsCap * (4 + 2 + 2) + kSippLdsCap * 4 + 16;
 
 template <bool RES>
 DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, uint8_t* ldsTier, uint32_t ldsNodes, DevResult& res,
@@ -2243,7 +2248,7 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_search_kernel(Launch
 
 // One SIPP job whose descriptor is at `jobSrc` (host memory): result + raw A* states back to host memory.
 // `ldsTier` (sessions): kSippLdsNodes node records + the open list, for jobs on device-resident tables.
-constexpr uint32_t kSippLdsNodes = TierLdsSipp::kMaxNodes;                 // 2048 (ids 0..2046)
+constexpr uint32_t kSippLdsNodes = kSippLdsCap;
 constexpr uint32_t kSippLdsBytes = kSippLdsBytesC;
 DEVI void processSippJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* resDst, uint16_t* pathDst,
                          uint8_t* arenaSlot, uint8_t* ldsTier, DevJob& jobS, DevResult& resS) {
