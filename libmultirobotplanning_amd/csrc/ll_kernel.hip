@@ -2463,6 +2463,19 @@ extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, u
   return hipGetLastError();
 }
 
+// Resident workgroups per CU the runtime reports for the persistent kernel of `kind` with `ldsBytes` of dynamic LDS
+// (0 on error): what mrp_ll_configure_tiers tells its caller, who sizes a session with it.
+extern "C" int mrp_ll_persistent_occupancy(int kind, uint32_t ldsBytes) {
+  typedef void (*Kern)(mrp::LaunchParams);
+  const Kern k = kind == 1   ? mrp::mrp_ll_ecbs_persistent_kernel
+                 : kind == 2 ? mrp::mrp_ll_cbs_persistent_kernel
+                             : mrp::mrp_ll_persistent_kernel;
+  if (mrp::allowFullLds(reinterpret_cast<const void*>(k), 3 + kind) != hipSuccess) return 0;
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), 64, ldsBytes) != hipSuccess) return 0;
+  return n;
+}
+
 extern "C" hipError_t mrp_ll_launch_sipp(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream) {
   hipLaunchKernelGGL(mrp::mrp_ll_sipp_kernel, dim3(grid), dim3(64), 0, stream, *P);
   return hipGetLastError();
