@@ -627,6 +627,9 @@ int mrp_hl_solver_create(int32_t device, int32_t nThreads, const mrp_ll_options*
     unsigned hc = std::thread::hardware_concurrency();
     nThreads = static_cast<int32_t>(hc ? std::min<unsigned>(hc, 16) : 8);
   }
+  // One HIP stream (= one resident kernel) per worker: each needs its own hardware queue, the ROCm default is 4.  Only
+  // effective if the HIP runtime has not been initialised yet in this process; never overrides the caller.
+  (void)setenv("GPU_MAX_HW_QUEUES", "24", 0);
   auto* s = new mrp_hl_solver();
   s->device = device;
   std::memset(&s->llOpt, 0, sizeof(s->llOpt));
