@@ -47,7 +47,8 @@ extern "C" {
 #define MRP_LL_ASTAR 0     /* a_star.hpp AStar::search          (CBS low level)  */
 #define MRP_LL_ASTAR_EPS 1 /* a_star_epsilon.hpp AStarEpsilon   (ECBS low level) */
 #define MRP_LL_SIPP 2      /* sipp.hpp SIPP::search over the grid Environment of example/mapf_prioritized_sipp.cpp;  */
-                           /* batch mode only, and a batch holds either SIPP jobs or A-star jobs, not both          */
+                           /* a batch (or a session, mrp_ll_session_begin_sipp) holds either SIPP jobs or A-star     */
+                           /* jobs, not both                                                                         */
 
 /* ---- per-job status (mrp_ll_result.status) ----------------------------------------------------------------- */
 #define MRP_LL_OK 0             /* search() returned true                                                    */
@@ -124,11 +125,15 @@ typedef struct mrp_ll_job {
    * result_path_id >= 0 the kernel ALSO leaves the result path in that store slot, and a later MRP_LL_ASTAR_EPS job names
    * the CT node's paths by their slots — path_ids[n_agents], -1 = no path / the searching agent itself — instead of
    * shipping them (path_xy may then be NULL; path_len is still required).  Slot ids are managed by the caller: a slot
-   * may be reused once no unfinished job names it. */
+   * may be reused once no unfinished job names it.
+   * result_path_id is honoured only when `flags` has MRP_LL_JOB_STORE_RESULT: a zero-initialised job (`mrp_ll_job j{}`,
+   * memset) stores nothing and touches no slot. */
   const int32_t* path_ids;
-  int32_t result_path_id;  /* -1: the result path is only returned to the caller */
-  int32_t reserved2;
+  int32_t result_path_id;  /* with MRP_LL_JOB_STORE_RESULT: the slot (0 .. n_slots-1) that also receives the result path */
+  int32_t flags;           /* MRP_LL_JOB_* bits; 0 = none */
 } mrp_ll_job;
+
+#define MRP_LL_JOB_STORE_RESULT 1 /* mrp_ll_job.flags: also leave the result path in path-store slot result_path_id */
 
 typedef struct mrp_ll_result {
   int32_t status;   /* MRP_LL_OK ... */

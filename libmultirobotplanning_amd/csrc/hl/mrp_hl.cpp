@@ -352,7 +352,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     P.group = group;
     P.outSlot.assign(jobs.size(), -1);
     if (pathSlots > 0)
-      for (size_t q = 0; q < jobs.size(); ++q) jobs[q].result_path_id = P.outSlot[q] = slotPool.take();
+      for (size_t q = 0; q < jobs.size(); ++q) {
+        jobs[q].result_path_id = P.outSlot[q] = slotPool.take();
+        jobs[q].flags |= MRP_LL_JOB_STORE_RESULT;
+      }
     P.res.assign(jobs.size(), mrp_ll_result());
     P.states.resize(jobs.size() * static_cast<size_t>(cap) * 3);
     for (size_t q = 0; q < jobs.size(); ++q) {

@@ -1039,6 +1039,12 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
       // the search that produced it); the time-major table [t][agent] is built here, on the device, instead of being
       // packed by the host and read over PCIe.  One coalesced read per agent (lane = time step).
       const bool inLds = P.lds_nodes != 0 && pathBytes <= P.lds_paths_bytes;
+      if (!inLds && pathBytes > P.arena_paths_bytes) {  // (the host packer refuses such a job; never write past the slot)
+        res.status = ST_BAD;
+        res.expanded = 0;
+        res.nodes_created = 0;
+        return;
+      }
       uint16_t* dst = inLds ? (uint16_t*)ldsPaths : (uint16_t*)pathsArena;
       {
         uint32_t* d32 = (uint32_t*)dst;
@@ -2340,11 +2346,23 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
       // Waiting workgroups poll the published-ticket counts and back off in proportion to how far ahead of the bulk
       // count their ticket is: the next in line looks every ~2 us, the k-th every ~2k us (<= ~100 us), so a thousand
       // idle wavefronts do not saturate PCIe with reads.
-      const uint32_t hd = rfl(__hip_atomic_load(head0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+      // The spin itself uses RELAXED system-scope loads (they go to the host word, not to a cached copy); the ONE acquire
+      // sits behind the generation match.  An acquire load per poll is a buffer_inv on this CU's L1 — the cache the
+      // ten other searches of the CU are working in — for every look of every idle wavefront (MI355X_MICROARCH.md:
+      // "polling with ACQUIRE loads -> correct, 2-3x slower per hop").  -DMRP_LL_RING_POLL_ACQUIRE: the old form (A/B).
+#ifdef MRP_LL_RING_POLL_ACQUIRE
+      constexpr int kPollOrder = __ATOMIC_ACQUIRE;
+#else
+      constexpr int kPollOrder = __ATOMIC_RELAXED;
+#endif
+      const uint32_t hd = rfl(__hip_atomic_load(head0, kPollOrder, __HIP_MEMORY_SCOPE_SYSTEM));
       if ((int32_t)(hd - bulkT) > 0) {
         const uint32_t gen = (bulkT / q0 + 1) & 0x1FFFFFu;
-        const uint32_t e = rfl(__hip_atomic_load(ring0 + bulkT % q0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+        const uint32_t e = rfl(__hip_atomic_load(ring0 + bulkT % q0, kPollOrder, __HIP_MEMORY_SCOPE_SYSTEM));
         if ((e >> kRingSlotBits) == gen) {
+#ifndef MRP_LL_RING_POLL_ACQUIRE
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the job data the host wrote before publishing
+#endif
           slot = e & kRingSlotMask;
           doneVal = ((bulkT + 1u) & 0x3FFFFFFFu) | 0x40000000u;
           haveBulk = false;

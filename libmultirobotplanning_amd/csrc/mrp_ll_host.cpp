@@ -220,6 +220,7 @@ struct mrp_ll_ctx {
   uint32_t pathStoreStride = 0, pathStoreSlots = 0;
   uint8_t* scanDev = nullptr;      // mrp_ll_conflict_scan: device staging (grown on demand)
   size_t scanDevCap = 0;
+  hipStream_t scanStream = nullptr;  // ... and its own stream: a session's resident kernel occupies tickets[0].stream
   std::vector<uint16_t> scanStates;
 };
 
@@ -731,10 +732,12 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   d.n_agents_pad = 0;
   d.t_pad = 0;
   d.path_off = 0;
-  d.store_out_id = (j.result_path_id >= 0 && static_cast<uint32_t>(j.result_path_id) < ctx->pathStoreSlots)
+  // the result path also goes to a path-store slot only when the caller says so (a zero-initialised job names no slot)
+  const bool storeResult = (j.flags & MRP_LL_JOB_STORE_RESULT) != 0;
+  d.store_out_id = (storeResult && j.result_path_id >= 0 && static_cast<uint32_t>(j.result_path_id) < ctx->pathStoreSlots)
                        ? static_cast<uint32_t>(j.result_path_id)
                        : mrp::kNoStoreSlot;
-  if (j.result_path_id >= 0 && d.store_out_id == mrp::kNoStoreSlot) return false;  // no such slot
+  if (storeResult && d.store_out_id == mrp::kNoStoreSlot) return false;  // no such slot (or no store reserved)
   if (j.algo == MRP_LL_ASTAR_EPS && j.n_agents > 0 && j.path_ids) {
     // f2: the CT node's paths by their path-store slots; the workgroup builds the table (ll_kernel.hip runJob)
     if (!j.path_len || !ctx->pathStore) return false;
@@ -744,6 +747,11 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
         if (j.path_ids[a] < 0 || static_cast<uint32_t>(j.path_ids[a]) >= ctx->pathStoreSlots) return false;
         tpad = std::max(tpad, j.path_len[a]);
       }
+    // The workgroup builds the table in LDS or in its arena slot's path area; a table that fits neither (a caller's
+    // path_len beyond max_horizon, a very wide solution) is refused here rather than written past the slot.
+    if (tpad > horizon ||
+        static_cast<uint64_t>(tpad) * ((static_cast<uint32_t>(j.n_agents) + 15u) & ~15u) * 2u > ctx->arenaPathsBytes)
+      return false;
     if (tpad > 0) {
       d.path_off = static_cast<uint32_t>(cs.size());
       for (int a = 0; a < j.n_agents; ++a)
@@ -1034,6 +1042,7 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
   }
   if (ctx->mapsDev) (void)hipFree(ctx->mapsDev);
   if (ctx->scanDev) (void)hipFree(ctx->scanDev);
+  if (ctx->scanStream) (void)hipStreamDestroy(ctx->scanStream);
   if (ctx->pathStore) (void)hipFree(ctx->pathStore);
   for (uint8_t* c : ctx->sippTabChunks) (void)hipFree(c);
   delete ctx;
@@ -1811,7 +1820,24 @@ int mrp_ll_sipp_table_add(mrp_ll_sipp_table* t, int32_t x, int32_t y, int32_t st
 
 void mrp_ll_sipp_table_destroy(mrp_ll_sipp_table* t) {
   if (!t) return;
-  if (t->ctx && t->devIndex >= 0) t->ctx->sippTabFree.push_back(t->devIndex);
+  bool referenced = false;
+  if (t->ctx) {
+    // a job on this table may still be in flight (its slot reports back to the table, and with sipp_commit a workgroup
+    // may still be writing the device copy): forget the slot's reference, and do not hand the device copy to a new
+    // table — its pool index is simply retired (0.8 MB of device memory per such destroy, until the engine goes)
+    for (mrp_ll_sipp_table*& tb : t->ctx->ring.slotTable)
+      if (tb == t) {
+        tb = nullptr;
+        referenced = true;
+      }
+    for (Ticket& tk : t->ctx->tickets)
+      for (mrp_ll_sipp_table*& tb : tk.commitTab)
+        if (tb == t) {
+          tb = nullptr;
+          referenced = true;
+        }
+    if (t->devIndex >= 0 && !referenced && !t->inFlight) t->ctx->sippTabFree.push_back(t->devIndex);
+  }
   delete t;
 }
 
@@ -1869,7 +1895,11 @@ int mrp_ll_conflict_scan(mrp_ll_ctx* ctx, int32_t nSets, const int32_t* setFirst
     HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->scanDev), total * 2));
     ctx->scanDevCap = total * 2;
   }
-  hipStream_t st = ctx->tickets[0].stream;
+  // A stream of its own (non-blocking): during a session tickets[0].stream is held by the resident kernel until
+  // mrp_ll_session_end, and a scan queued behind it would never start (while its caller, blocked here, stops moving the
+  // session's heartbeat).  The scan kernel runs beside the resident wavefronts: they leave wave slots and registers free.
+  if (!ctx->scanStream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->scanStream, hipStreamNonBlocking));
+  hipStream_t st = ctx->scanStream;
   HIPCHK(ctx, hipMemcpyAsync(ctx->scanDev + oSet, setFirstAgent, (nSets + 1) * 4, hipMemcpyHostToDevice, st));
   HIPCHK(ctx, hipMemcpyAsync(ctx->scanDev + oPath, pathFirstState, (nAgents + 1) * 4, hipMemcpyHostToDevice, st));
   if (nStates)

@@ -16,6 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MRP_LL_LIB") or os.path.join(_PKG, "lib", "libmrp_ll.so")
 
 ASTAR, ASTAR_EPS, SIPP = 0, 1, 2
+JOB_STORE_RESULT = 1  # mrp_ll_job.flags (include/mrp_ll.h)
 OK, NO_SOLUTION, CAP_EXPANSIONS, CAP_NODES, CAP_HORIZON, BAD_JOB, PATH_TRUNCATED, CAP_FOCAL = range(8)
 ACTION_NAMES = ["Up", "Down", "Left", "Right", "Wait"]  # example/ecbs.cpp:49-55
 
@@ -39,7 +40,7 @@ class mrp_ll_job(ctypes.Structure):
                 ("n_collision_locations", ctypes.c_int32), ("collision_xy", I32P), ("collision_count", I32P),
                 ("collision_intervals", I32P), ("initial_cost", ctypes.c_int32), ("sipp_commit", ctypes.c_int32),
                 ("sipp_table", ctypes.c_void_p), ("path_ids", I32P), ("result_path_id", ctypes.c_int32),
-                ("reserved2", ctypes.c_int32)]
+                ("flags", ctypes.c_int32)]
 
 
 class mrp_ll_result(ctypes.Structure):
@@ -232,6 +233,7 @@ class LowLevelEngine:
                 cj.sipp_table = j.sipp_table
                 cj.sipp_commit = 1 if j.sipp_commit else 0
             cj.result_path_id = j.result_path_id
+            cj.flags = JOB_STORE_RESULT if j.result_path_id >= 0 else 0
             if j.path_ids is not None:
                 ids = np.ascontiguousarray(np.asarray(j.path_ids, dtype=np.int32))
                 cj.path_ids = ids.ctypes.data_as(I32P)
