@@ -28,6 +28,8 @@
 #include <type_traits>
 
 #include "ll_device.h"
+#include "wave_dev.h"
+#include "ll_compact.h"
 
 namespace mrp {
 
@@ -708,8 +710,8 @@ DEVI void ensureRows(Mem<T>& m, SState& s, const Ctx& c, uint32_t t1, typename M
       m.bits[r * m.rowWords + wd] = useLocal ? obstLocal[wd] : c.obst[wd];
   __syncthreads();
   for (uint32_t j = lane; j < c.nVc; j += 64) {
-    uint32_t v = c.vc[j];
-    uint32_t tt = v >> 16, cell = v & 0xFFFFu;
+    uint32_t v = c.vc[j];  // t << 16 | y << 8 | x
+    uint32_t tt = v >> 16, cell = ((v >> 8) & 0xFFu) * c.dimx + (v & 0xFFu);
     if (tt >= r0 && tt < r1)
       __hip_atomic_fetch_or(m.bits + tt * m.rowWords + (cell >> 5), 1u << (cell & 31), __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -901,11 +903,13 @@ DEVI int runSearch(Mem<T>& m, SState& s, const Ctx& c, typename Mem<T>::P32 obst
       // focalStateHeuristic (ecbs.cpp:282-295) + focalTransitionHeuristic (ecbs.cpp:298-312): lanes hold the other
       // agents' cells at t (a) and t+1 (b); an agent counts once if it stands on the successor's cell at t+1 and once
       // more if it swaps places with this agent
-      const uint64_t swap0 = ballot64(b0 == curCell);
-      const uint64_t swap1 = c.nAgentsPad > 64 ? ballot64(b1 == curCell) : 0ull;
+      // (the path table holds the other agents' cells as x | y << 8)
+      const uint32_t nxyL = nx | (ny << 8);
+      const uint64_t swap0 = ballot64(b0 == xy);
+      const uint64_t swap1 = c.nAgentsPad > 64 ? ballot64(b1 == xy) : 0ull;
       for (uint32_t mm = mask; mm; mm &= mm - 1) {
         const uint32_t k = (uint32_t)__builtin_ctz(mm);
-        const uint32_t cc = __builtin_amdgcn_readlane(ncell, k);
+        const uint32_t cc = __builtin_amdgcn_readlane(nxyL, k);
         uint32_t cnt = (uint32_t)__popcll(ballot64(b0 == cc)) + (uint32_t)__popcll(ballot64(a0 == cc) & swap0);
         if (c.nAgentsPad > 64) {
           cnt += (uint32_t)__popcll(ballot64(b1 == cc)) + (uint32_t)__popcll(ballot64(a1 == cc) & swap1);
@@ -915,7 +919,7 @@ DEVI int runSearch(Mem<T>& m, SState& s, const Ctx& c, typename Mem<T>::P32 obst
               av = rowA[base + lane];
               bv = rowB[base + lane];
             }
-            cnt += (uint32_t)__popcll(ballot64(bv == cc)) + (uint32_t)__popcll(ballot64(av == cc && bv == curCell));
+            cnt += (uint32_t)__popcll(ballot64(bv == cc)) + (uint32_t)__popcll(ballot64(av == cc && bv == xy));
           }
         }
         fh = lane == k ? curFh + cnt : fh;
@@ -978,15 +982,10 @@ DEVI int runSearch(Mem<T>& m, SState& s, const Ctx& c, typename Mem<T>::P32 obst
 }
 
 // ---- LDS layout ------------------------------------------------------------------------------------------------
-constexpr uint32_t kEcLocal = 64;
-__host__ __device__ inline uint32_t ldsHeapBytes(uint32_t capNodes) { return (capNodes / 2) * 4 + 16; }
-__host__ __device__ inline uint32_t ldsBytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes) {
-  // TierLds: node words, position halfwords, three biased heaps of capNodes / 2 32-bit entries (+16 B bias pad each) —
-  // most nodes of a search are closed, so the open list outgrowing half the node capacity is rare and simply
-  // migrates like a full node array; bitmap rows, obstacle row, edge constraints, path table
-  return capNodes * 4 + ((capNodes * 2 + 15u) & ~15u) + 3 * ldsHeapBytes(capNodes) + rows * rowWords * 4 + rowWords * 4 +
-         kEcLocal * 4 + pathBytes;
-}
+// Dynamic LDS of a CBS / ECBS workgroup: the compact tier's window (ll_compact.h: open list, focal list, walk queue,
+// (time, cell) bitmap, obstacle row), then the focal path table.  A search that has left the compact tier keeps the
+// heaps' top entries in the same window (TierHyb).
+__host__ __device__ inline uint32_t ldsBytes(uint32_t pathBytes) { return ct::kLdsBytes + pathBytes; }
 
 // A read of the device path store.  The slot was written by another workgroup (another CU, possibly another XCD) of the
 // same resident launch before its completion was published; an agent-scope load goes past this CU's L1 to the coherent
@@ -1032,7 +1031,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     }
     const uint32_t pathBytes = c.tPad * c.nAgentsPad * 2;  // multiple of 32
     const uint32_t* psrc = (const uint32_t*)(P.paths + J.path_off);
-    uint8_t* ldsPaths = smem + ldsBytes(P.lds_nodes, P.lds_rows, P.lds_row_words, 0);
+    uint8_t* ldsPaths = smem + ldsBytes(0);
     c.pathsLds = nullptr;
     if (pathBytes != 0 && (J.ctx_flags & kCtxById)) {
       // f2: the CT node's paths are named by their slots in the device-resident path store (each was written there by
@@ -1155,7 +1154,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   // LDS (the compact tier's area, free once a search has left it)
   Mem<TierHyb> gh;
   {
-    const uint32_t area = ldsBytes(P.lds_nodes, P.lds_rows, P.lds_row_words, 0);
+    const uint32_t area = ldsBytes(0);
     uint32_t per = (area / 3u) & ~15u;  // bytes per heap, 16-byte aligned starts
     uint32_t nTop = per >= 32u ? ((per - 8u) / 8u) : 0u;
     if (nTop > 4095u) nTop = 4095u;
@@ -1177,84 +1176,53 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   ghx.open = gh.open; ghx.focal = gh.focal; ghx.aux = gh.aux; ghx.bits = gh.bits;
   ghx.capNodes = gh.capNodes; ghx.capHeap = gh.capHeap; ghx.capRows = gh.capRows; ghx.rowWords = gh.rowWords;
 
-  // the compact tier holds f in 7 bits: every f a search can reach inside its rows must fit
-  const bool ldsOk = P.lds_nodes != 0 && c.wpr <= P.lds_row_words &&
-                     (P.lds_rows - 1) + (c.dimx - 1) + (c.dimy - 1) <= TierLds::kFCap;
-  if (ldsOk) {
-    Mem<TierLds> m;
-    uint8_t* p = smem;
-    m.nodes = (Mem<TierLds>::PN32)p;             p += P.lds_nodes * 4;
-    m.pos = (Mem<TierLds>::P16)p;                p += (P.lds_nodes * 2 + 15u) & ~15u;
-    const uint32_t heapBytes = ldsHeapBytes(P.lds_nodes);
-    m.open = (Mem<TierLds>::PE)(p + 4);          p += heapBytes;
-    m.focal = (Mem<TierLds>::PE)(p + 4);         p += heapBytes;
-    m.aux = (Mem<TierLds>::PE)(p + 4);           p += heapBytes;
-    m.bits = (Mem<TierLds>::P32)p;               p += P.lds_rows * P.lds_row_words * 4;
-    Mem<TierLds>::P32 obstLocal = (Mem<TierLds>::P32)p;
-    m.capNodes = P.lds_nodes; m.capHeap = P.lds_nodes / 2; m.capRows = P.lds_rows; m.rowWords = P.lds_row_words;
-
-    __syncthreads();  // previous job's LDS reads are done
-    for (uint32_t wd = lane; wd < c.wpr; wd += 64) obstLocal[wd] = c.obst[wd];
-    __syncthreads();
-
-    initSearch<TierLds, EPS>(m, s, c);
+  // ---- compact tier (ll_compact.h): the whole search in LDS, a state = its 32-bit heap entry.  Maps up to 32 x 32 and
+  // up to 128 agents in the focal context; a search that outgrows the tier (open list, time steps, focalH field) comes
+  // back as C_OVERFLOW with nothing of it observable, and is run again from the start by the arena tier below.
+  const bool compactOk = P.lds_nodes != 0 && c.dimx <= 32u && c.dimy <= 32u && c.nAgentsPad <= 128u &&
+                         (uint64_t)P.arena_nodes * 16u >= ct::kParentBytes;
+  bool done = false;
+  if (compactOk) {
+    ct::CJob cj;
+    cj.dimx = c.dimx; cj.dimy = c.dimy; cj.sx = c.sx; cj.sy = c.sy; cj.gx = c.gx; cj.gy = c.gy;
+    cj.lastGoal = c.lastGoal;
+    cj.w = c.w;
+    cj.nVc = c.nVc; cj.nEc = c.nEc;
+    cj.vc = c.vc; cj.ec = c.ec;
+    cj.obst = c.obst; cj.obstWords = c.wpr;
+    cj.nAgentsPad = EPS ? c.nAgentsPad : 0u; cj.tPad = c.tPad;
+    cj.pathsLds = c.pathsLds ? ct::oPaths : ct::kNoLds;
+    cj.pathsG = c.paths;
+    cj.maxExp = c.maxExp < 0 ? 0xFFFFFFFFu : (c.maxExp > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)c.maxExp);
+    cj.parentTab = arenaSlot;  // the arena's node area: unused while the search is in this tier
+    cj.outPath = outPath;
+    ct::CRes cr;
 #ifndef MRP_LL_TRACE  // (the trace build uses prof[] for its phase counters)
     const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    rc = runSearch<TierLds, EPS>(m, s, c, obstLocal, true, res, outPath);
+    const int32_t crc = ct::compactSearch<EPS>((wv::Lds)smem, cj, cr);
 #ifndef MRP_LL_TRACE
-    res.prof[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);  // 100 MHz ticks / expansions in the LDS tier
-    res.prof[1] = (uint32_t)s.expansions;
+    res.prof[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);  // 100 MHz ticks / expansions in the compact tier
+    res.prof[1] = cr.expanded;                                         // (of a search that was handed over: until then)
 #endif
-    if (rc == RUN_MIGRATE_NODES || rc == RUN_MIGRATE_ROWS) {
-      // migrate the whole search state to the HBM arena (records converted to that tier's formats) and continue with
-      // the same code on global pointers.  A migration happens at the top of an expansion, before anything was popped.
-      res.tier = 1;
-      __syncthreads();
-      for (uint32_t i = lane; i < s.nNodes; i += 64) {
-        const uint32_t w = m.nodes[i];
-        u32x4 nn;
-        nn.x = w & 0xFFFFu;
-        nn.y = w >> 16;
-        nn.z = 0;
-        nn.w = m.pos[i];
-        ((Mem<TierHbm>::PNode4)g.nodes)[i] = nn;
-      }
-      for (uint32_t i = lane; i < s.nOpen; i += 64) {
-        const uint32_t e = m.open[i];
-        uint64_t w = TierHbm::pack(TierLds::fh(e), TierLds::f(e), TierLds::g(e), TierLds::id(e));
-        if (xyEntries) w = TierHybXy::withXy(w, m.nodes[TierLds::id(e)] & 0xFFFFu);
-        g.open[i] = w;
-      }
-      for (uint32_t i = lane; i < s.nFocal; i += 64) {
-        const uint32_t e = m.focal[i];
-        uint64_t w = TierHbm::pack(TierLds::fh(e), TierLds::f(e), TierLds::g(e), TierLds::id(e));
-        if (xyEntries) w = TierHybXy::withXy(w, m.nodes[TierLds::id(e)] & 0xFFFFu);
-        g.focal[i] = w;
-      }
-      for (uint32_t r = 0; r < s.rowsReady; ++r)
-        for (uint32_t wd = lane; wd < c.wpr; wd += 64) g.bits[r * g.rowWords + wd] = m.bits[r * m.rowWords + wd];
-      __syncthreads();
+    if (crc != ct::C_OVERFLOW) {
+      rc = crc;  // C_OK / C_NO_SOLUTION / C_CAP_EXP == ST_OK / ST_NO_SOLUTION / ST_CAP_EXP
+      res.cost = cr.cost;
+      res.fmin = cr.fmin;
+      res.n_states = cr.nStates;
+      s.expansions = cr.expanded;
+      s.nNodes = cr.nodes;
+      done = true;
+    } else {
 #ifndef MRP_LL_TRACE
-      const uint64_t th0 = __builtin_amdgcn_s_memrealtime();
-      const int64_t e0h = s.expansions;
-#endif
-      // the heaps' top entries move (back) into LDS, now as arena-format records; everything staged above is in the arena
-      for (uint32_t i = lane; i < s.nOpen && i < gh.open.nTop; i += 64) gh.open.top[i] = g.open[i];
-      for (uint32_t i = lane; i < s.nFocal && i < gh.focal.nTop; i += 64) gh.focal.top[i] = g.focal[i];
-      __syncthreads();
-      if (xyEntries)
-        rc = runSearch<TierHybXy, EPS>(ghx, s, c, (Mem<TierHybXy>::P32)c.obst, false, res, outPath);
-      else
-        rc = runSearch<TierHyb, EPS>(gh, s, c, (Mem<TierHyb>::P32)c.obst, false, res, outPath);
-#ifndef MRP_LL_TRACE
-      res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);  // ... in the arena tier after a migration
-      res.prof[3] = (uint32_t)(s.expansions - e0h);
+      res.prof[6] = cr.expanded;  // expansions thrown away with the attempt
+      res.prof[7] = 1;
 #endif
     }
-  } else {
+  }
+  if (!done) {
     res.tier = 1;
-    __syncthreads();  // previous job's LDS reads are done
+    __syncthreads();  // previous job's / the compact attempt's LDS accesses are done
     if (xyEntries)
       initSearch<TierHybXy, EPS>(ghx, s, c);
     else
@@ -2180,11 +2148,7 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
     const uint32_t sid = rfl(J.store_out_id);
     if (sid < P.path_store_slots && (uint32_t)res.n_states < P.path_store_stride) {
       uint16_t* slot = P.path_store + (size_t)sid * P.path_store_stride;
-      const uint32_t dimx = rfl(J.dimx);
-      for (uint32_t i = lane; i < (uint32_t)res.n_states; i += 64) {
-        const uint32_t xy = outPath[i];
-        slot[1 + i] = (uint16_t)((xy >> 8) * dimx + (xy & 0xFF));
-      }
+      for (uint32_t i = lane; i < (uint32_t)res.n_states; i += 64) slot[1 + i] = outPath[i];  // x | y << 8
       slot[0] = (uint16_t)res.n_states;
     }
   }
@@ -2465,7 +2429,8 @@ static hipError_t allowFullLds(const void* fn, int which) {
 
 // ---- host-callable launcher (used by mrp_ll_host.cpp) -----------------------------------------------------------
 extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes) {
-  return mrp::ldsBytes(capNodes, rows, rowWords, pathBytes);
+  (void)capNodes; (void)rows; (void)rowWords;
+  return mrp::ldsBytes(pathBytes);
 }
 
 // kind: 0 = mixed, 1 = A*-epsilon jobs only, 2 = A* jobs only (see processJob)

@@ -714,7 +714,7 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
     const int32_t* v = j.vertex_constraints + 3 * i;
     if (v[1] == j.goal_x && v[2] == j.goal_y) lastGoal = std::max(lastGoal, v[0]);
     if (v[0] < 0 || v[0] >= horizon || !inGrid(v[1], v[2])) continue;  // can never match a generated state
-    cs.push((static_cast<uint32_t>(v[0]) << 16) | static_cast<uint32_t>(v[2] * mp.dimx + v[1]));
+    cs.push((static_cast<uint32_t>(v[0]) << 16) | (static_cast<uint32_t>(v[2]) << 8) | static_cast<uint32_t>(v[1]));  // t, y, x
   }
   d.n_vc = static_cast<uint32_t>(cs.size()) - d.vc_off;
   d.last_goal_constraint = lastGoal;
@@ -788,7 +788,7 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
         for (int tt = 0; tt < tpad; ++tt) {
           if (tt < len) {
             int x = xy[2 * tt], y = xy[2 * tt + 1];
-            cell = inGrid(x, y) ? static_cast<uint16_t>(y * mp.dimx + x) : none;
+            cell = inGrid(x, y) ? static_cast<uint16_t>(x | (y << 8)) : none;
           }
           tab[static_cast<size_t>(tt) * npad + a] = cell;
         }
@@ -810,8 +810,8 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
   P.arena_nodes = static_cast<uint32_t>(ctx->opt.arena_nodes);
   P.arena_rows = static_cast<uint32_t>(ctx->opt.max_horizon);
   P.arena_row_words = ctx->arenaRowWords;
-  // LDS tier geometry: rows sized for the widest uploaded map; a workgroup may take up to the CU's whole 160 KiB
-  // (minus the kernel's small static LDS); occupancy is floor(160 KiB / ldsBytes) workgroups per CU
+  // LDS of a workgroup: the compact tier's window (fixed size, ll_compact.h) + the focal path table; occupancy is
+  // floor(160 KiB / ldsBytes) workgroups per CU
   uint32_t ldsNodes = static_cast<uint32_t>(ctx->opt.lds_nodes);
   uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
   uint32_t rows = 0;
@@ -819,16 +819,12 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
   uint32_t ldsPaths = ctx->tierPathBytes;
   if (const char* e = std::getenv("MRP_LL_LDS_PATHS")) ldsPaths = static_cast<uint32_t>(std::max(0, std::atoi(e))) & ~31u;  // tuning knob
   if (ldsNodes) {
-    const uint32_t budget = 160 * 1024 - 512;
-    uint32_t fixed = mrp_ll_lds_bytes(ldsNodes, 0, rowWords, ldsPaths);
-    if (fixed + 16 * rowWords * 4 <= budget) {
-      uint32_t rowsWanted = ctx->tierRows;
-      if (const char* e = std::getenv("MRP_LL_LDS_ROWS")) rowsWanted = std::max(8, std::atoi(e));  // tuning knob
-      rows = std::min<uint32_t>(std::min<uint32_t>(rowsWanted, 64u), (budget - fixed) / (rowWords * 4));
-      rows = std::min<uint32_t>(rows, static_cast<uint32_t>(ctx->opt.max_horizon));
-      ldsBytes = mrp_ll_lds_bytes(ldsNodes, rows, rowWords, ldsPaths);
-    } else {
+    rows = 64;
+    ldsBytes = mrp_ll_lds_bytes(ldsNodes, rows, rowWords, ldsPaths);
+    if (ldsBytes > 160u * 1024u - 512u) {
       ldsNodes = 0;
+      rows = 0;
+      ldsBytes = 0;
     }
   }
   P.path_store = ctx->pathStore;

@@ -1,0 +1,153 @@
+"""The compact search tier (libmultirobotplanning_amd/csrc/ll_compact.h — the source the gfx950 kernels compile) replayed
+on the CPU: the same file built against tests/support/wave_emu.h, a 64-lane lockstep interpretation of its wave vocabulary,
+and run on low-level searches harvested from the oracle's CBS / ECBS conflict trees.  Every search the tier finishes must
+equal the oracle bit for bit (success, cost, fmin, expansions, path); a search it hands over (overflow) is the arena
+tier's business and is only counted."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+I32P = ctypes.POINTER(ctypes.c_int32)
+I64P = ctypes.POINTER(ctypes.c_int64)
+
+
+def _emu_lib():
+    build = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(build, exist_ok=True)
+    groups = os.environ.get("MRP_CT_GROUPS")  # experiments with larger open lists (the product builds the default)
+    lib = os.path.join(build, "libemu_ll%s.so" % ("_g" + groups if groups else ""))
+    deps = [os.path.join(ROOT, "tests", "support", "emu_ll.cpp"), os.path.join(ROOT, "tests", "support", "wave_emu.h"),
+            os.path.join(ROOT, "libmultirobotplanning_amd", "csrc", "ll_compact.h")]
+    if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if os.environ.get("MRP_EMU_SANITIZE") else []
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"] + san +
+                              (["-DMRP_CT_GROUPS=" + groups] if groups else []) + ["-o", lib, deps[0]])
+    L = ctypes.CDLL(lib)
+    L.emu_compact_search.restype = ctypes.c_int
+    L.emu_compact_search.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, I32P, ctypes.c_int, I32P,
+                                     ctypes.c_int, ctypes.c_int, I32P, I32P, ctypes.c_int64, ctypes.c_int, I64P, I32P,
+                                     ctypes.c_int]
+    return L
+
+
+def _arr(a, shape):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(shape))
+    return a, a.ctypes.data_as(I32P)
+
+
+def emu_search(L, eps, inst, agent, start, goal, vc, ec, ctx_paths, w, max_exp=-1, lds_path_bytes=2048):
+    obst, obst_p = _arr(inst["obstacles"], (-1, 2))
+    vca, vc_p = _arr(vc, (-1, 3))
+    eca, ec_p = _arr(ec, (-1, 5))
+    plen, plen_p = _arr([len(p) for p in ctx_paths], (-1,))
+    pxy, pxy_p = _arr([xy for p in ctx_paths for xy in p], (-1, 2))
+    out = np.zeros(8, dtype=np.int64)
+    states = np.zeros((1024, 2), dtype=np.int32)
+    rc = L.emu_compact_search(1 if eps else 0, inst["dimx"], inst["dimy"], len(obst), obst_p, start[0], start[1], goal[0],
+                              goal[1], w, len(vca), vc_p, len(eca), ec_p, len(plen), agent, plen_p, pxy_p, max_exp,
+                              lds_path_bytes, out.ctypes.data_as(I64P), states.ctypes.data_as(I32P), 1024)
+    assert rc == 0, rc
+    return dict(status=int(out[0]), cost=int(out[1]), fmin=int(out[2]), n_states=int(out[3]), expanded=int(out[4]),
+                nodes=int(out[5]), oob_reads=int(out[6]), oob_writes=int(out[7]), states=states[:int(out[3])].tolist())
+
+
+def _replay(L, oracle_mod, inst, algo, w, lds_path_bytes=2048, cap_total=-1):
+    """Every low-level call of the instance's conflict tree through the emulated tier.  Returns (finished, handed over)."""
+    eps = algo == oracle_mod.ECBS
+    _, calls = oracle_mod.mapf_record(algo, inst, w=w, cap_total=cap_total)
+    done = over = 0
+    for c in calls:
+        r = emu_search(L, eps, inst, c["agent"], inst["starts"][c["agent"]], inst["goals"][c["agent"]],
+                       c["vertex_constraints"], c["edge_constraints"], c["ctx_paths"] if eps else [], w,
+                       lds_path_bytes=lds_path_bytes)
+        assert r["oob_writes"] == 0 and r["oob_reads"] == 0, r
+        if r["status"] == -1:
+            over += 1
+            continue
+        done += 1
+        assert (r["status"] == 0) == c["success"], (c["agent"], r["status"])
+        assert r["expanded"] == c["expanded"], (c["agent"], r["expanded"], c["expanded"])
+        if c["success"]:
+            assert (r["cost"], r["fmin"]) == (c["cost"], c["fmin"]), (c["agent"], r, c["cost"], c["fmin"])
+            assert r["states"] == c["states"], c["agent"]
+    return done, over
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return _emu_lib()
+
+
+def test_ecbs_agents10_all_searches(emu, oracle_mod, bench_instances):
+    done = over = 0
+    for k in range(0, 100, 4):
+        d, o = _replay(emu, oracle_mod, bench_instances["map_32by32_obst204_agents10_ex%d" % k], oracle_mod.ECBS, 1.3)
+        done += d
+        over += o
+    assert done > 200 and over < done // 3, (done, over)
+
+
+def test_ecbs_denser_instances_tables_in_lds_and_in_memory(emu, oracle_mod, bench_instances):
+    done = over = 0
+    for name, pb in (("map_32by32_obst204_agents20_ex0", 2048), ("map_32by32_obst204_agents30_ex1", 0),
+                     ("map_32by32_obst204_agents50_ex3", 16384), ("map_32by32_obst204_agents50_ex5", 0),
+                     ("map_32by32_obst204_agents100_ex2", 0)):
+        d, o = _replay(emu, oracle_mod, bench_instances[name], oracle_mod.ECBS, 1.3, lds_path_bytes=pb)
+        done += d
+        over += o
+    assert done > 250, (done, over)
+
+
+def test_ecbs_w1_and_cbs_small_maps(emu, oracle_mod, bench_instances, ref_tests):
+    done = 0
+    for name in ("map_8by8_obst12_agents6_ex1", "map_8by8_obst12_agents8_ex3", "map_8by8_obst12_agents5_ex0"):
+        d, _ = _replay(emu, oracle_mod, bench_instances[name], oracle_mod.CBS, 1.0)
+        done += d
+        d, _ = _replay(emu, oracle_mod, bench_instances[name], oracle_mod.ECBS, 1.0)
+        done += d
+    assert done > 50
+
+
+def test_random_constraint_sets_and_caps(emu, oracle_mod, bench_instances):
+    """Random vertex / edge constraints (more than a wave of edge constraints too), goal constraints, expansion caps."""
+    rng = np.random.default_rng(7)
+    inst = bench_instances["map_32by32_obst204_agents10_ex7"]
+    m = dict(dimx=inst["dimx"], dimy=inst["dimy"], obstacles=inst["obstacles"])
+    n = 0
+    for trial in range(60):
+        a = int(rng.integers(0, 10))
+        s, g = inst["starts"][a], inst["goals"][a]
+        nvc, nec = int(rng.integers(0, 40)), int(rng.choice([0, 3, 20, 70, 130]))
+        vc = [[int(rng.integers(0, 40)), int(rng.integers(0, 32)), int(rng.integers(0, 32))] for _ in range(nvc)]
+        if trial % 3 == 0:
+            vc.append([int(rng.integers(5, 30)), g[0], g[1]])  # m_lastGoalConstraint
+        ec = []
+        for _ in range(nec):
+            x, y = int(rng.integers(0, 32)), int(rng.integers(0, 32))
+            dx, dy = [(0, 0), (1, 0), (-1, 0), (0, 1), (0, -1)][int(rng.integers(0, 5))]
+            ec.append([int(rng.integers(0, 30)), x, y, x + dx, y + dy])
+        ctx = [[] for _ in range(10)]
+        for b in range(10):
+            if b != a and rng.random() < 0.7:
+                ctx[b] = oracle_mod.ll_search(oracle_mod.ASTAR, m, b, inst["starts"][b], inst["goals"][b])["states"]
+                ctx[b] = [st[1:] for st in ctx[b]]
+        cap = int(rng.choice([-1, -1, 5, 40]))
+        for algo, eps, w in ((oracle_mod.ASTAR_EPS, True, 1.3), (oracle_mod.ASTAR, False, 1.0)):
+            o = oracle_mod.ll_search(algo, m, a, s, g, vc, ec, ctx if eps else [], w=w, cap_expansions=cap)
+            r = emu_search(emu, eps, inst, a, s, g, vc, ec, ctx if eps else [], w, max_exp=cap)
+            if r["status"] == -1:
+                continue
+            n += 1
+            if o["rc"] == -1:
+                assert r["status"] == 2, (trial, r)
+                continue
+            assert (r["status"] == 0) == o["success"] and r["expanded"] == o["expanded"], (trial, r, o["expanded"])
+            if o["success"]:
+                assert (r["cost"], r["fmin"]) == (o["cost"], o["fmin"])
+                assert r["states"] == [st[1:] for st in o["states"]]
+    assert n > 60
