@@ -76,7 +76,7 @@ typedef struct mrp_ll_options {
   int32_t arena_nodes;     /* HBM node capacity per search before MRP_LL_CAP_NODES (0 = default 131072)       */
   int32_t max_horizon;     /* largest state time + 1 (0 = default 512, max 1024)                              */
   int32_t max_cells;       /* largest dimx*dimy accepted by mrp_ll_upload_map (0 = default 4096, max 65025)   */
-  int32_t lds_nodes;       /* node capacity of the LDS-resident fast tier (0 = default, <0 = disable LDS tier) */
+  int32_t lds_nodes;       /* 2 x open-list entries of the LDS-resident fast tier (0 = default 2048, <0 = no tier) */
   int32_t reserved;
 } mrp_ll_options;
 
@@ -144,7 +144,7 @@ typedef struct mrp_ll_result {
   int32_t* states_txy; /* caller buffer [states_cap][3] = time, x, y ; may be NULL                            */
   int32_t* actions;    /* caller buffer [states_cap]    = MRP_LL_ACT_* ; may be NULL                          */
   int32_t states_cap;
-  int32_t tier;     /* 0 = finished in the LDS tier, 1 = migrated to the HBM arena (diagnostic)               */
+  int32_t tier;     /* 0 = finished in the LDS tier, 1 = run by the arena tier (diagnostic)                    */
   int32_t* action_costs; /* caller buffer [states_cap] or NULL: PlanResult::actions[k].second (always 1 for the
                           * A-star algorithms; Wait durations for MRP_LL_SIPP, sipp.hpp:105-128)                 */
 } mrp_ll_result;
@@ -202,11 +202,14 @@ void mrp_ll_sipp_table_destroy(mrp_ll_sipp_table* t);
  * one context across many batches of instances.  MRP_LL_E_BUSY while a batch or a session is in flight. */
 int mrp_ll_release_maps(mrp_ll_ctx* ctx);
 
-/* Geometry of the LDS-resident fast tier for the launches / sessions that follow: node capacity (at most 512), (time,
- * cell) bitmap rows (at most 64) and bytes of the focal path table kept in LDS per resident search (0 = keep the
- * current value; lds_nodes < 0 disables the tier).  Smaller tiers let more searches share a CU (occupancy = 160 KiB / tier bytes) at the price of
- * more searches overflowing into the HBM tier; results never depend on it.  *occupancy_out (may be NULL) receives the
- * resulting resident searches per CU.  MRP_LL_E_BUSY while a batch or a session is in flight. */
+/* Limits of the LDS-resident fast tier for the launches / sessions that follow.  The tier keeps a whole search in LDS
+ * (open list, focal list, walk queue, a (time, cell) bitmap of 64 time steps) in a window of fixed size, plus
+ * lds_path_bytes for the focal path table of a search (a larger table is read from the search's arena slot); it serves
+ * maps up to 32 x 32 and focal contexts of up to 128 agents.  lds_nodes / 2 = open-list entries a search may hold inside
+ * the tier (at most 1023), lds_rows = time steps it may use (at most 64); a search that outgrows a limit is run by the
+ * arena tier instead.  0 = keep the current value; lds_nodes < 0 disables the tier.  Results never depend on any of
+ * this.  *occupancy_out (may be NULL) receives the resident searches per CU (160 KiB / window + table).  MRP_LL_E_BUSY
+ * while a batch or a session is in flight. */
 int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t lds_nodes, int32_t lds_rows, int32_t lds_path_bytes,
                            int32_t* occupancy_out);
 

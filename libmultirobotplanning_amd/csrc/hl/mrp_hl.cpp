@@ -784,7 +784,7 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   int32_t occupancy = 4;
   if (s->llOpt.lds_nodes == 0 && opt.mode != 1) {  // the caller did not choose a geometry: pick one for this batch
     int32_t pathBytes = opt.algo == MRP_HL_ECBS ? std::min(16384, std::max(2048, agentsPad * 2 * 64)) : 32;
-    int32_t tierNodes = 400, tierRows = 48;
+    int32_t tierNodes = 2048, tierRows = 64;  // the compact tier at its full size (open list: tierNodes / 2 entries)
     if (const char* e = std::getenv("MRP_HL_TIER")) {  // tuning knob: "nodes,rows,pathBytes"
       int a = 0, b = 0, c = 0;
       if (std::sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {

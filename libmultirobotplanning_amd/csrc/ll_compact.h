@@ -76,6 +76,7 @@ struct CJob {
   uint32_t pathsLds;       // byte offset of the table in LDS, or kNoLds: then it is at pathsG
   const uint16_t* pathsG;
   uint32_t maxExp;         // 0xFFFFFFFF = unlimited
+  uint32_t openCap, maxT;  // limits of this job inside the tier: <= kCap open entries, expanded nodes at t <= maxT <= kMaxT
   uint8_t* parentTab;      // kParentBytes of device memory: action byte per (t, cell)
   uint16_t* outPath;       // x | y << 8 per time step
 };
@@ -326,8 +327,8 @@ WV_FN int32_t compactSearch(Lds lds, const CJob& J, CRes& R) {
     const bool isGoal = cell == goalCell && (int32_t)t > J.lastGoal;
     if (!isGoal) {
       // (R.cost names the limit and R.expanded how far the search got: statistics for the caller, not results)
-      if (nOpen + 5u > kCap || t > kMaxT || (EPS && curFh + 2u * J.nAgentsPad > 511u)) {
-        R.cost = nOpen + 5u > kCap ? 1 : t > kMaxT ? 2 : 3;
+      if (nOpen + 5u > J.openCap || t > J.maxT || (EPS && curFh + 2u * J.nAgentsPad > 511u)) {
+        R.cost = nOpen + 5u > J.openCap ? 1 : t > J.maxT ? 2 : 3;
         R.expanded = expansions;
         return C_OVERFLOW;
       }

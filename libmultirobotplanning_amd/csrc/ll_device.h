@@ -12,12 +12,9 @@ namespace mrp {
 // Entries with equal keys compare EQUAL (the id never takes part), exactly like the reference's comparators; which
 // of two equal entries comes out first is decided by the heap layout, which the kernels replay verbatim.
 constexpr uint32_t kGBits = 10, kFBits = 11, kFhBits = 11;
-// compact LDS tier of the CBS / ECBS kernels: 32-bit heap entries  focalH | f (7 bits) | g (6 bits) | node id
-#ifndef MRP_LL_LDS_ID_BITS
-#define MRP_LL_LDS_ID_BITS 9
-#endif
-constexpr uint32_t kLdsIdBits = MRP_LL_LDS_ID_BITS;
-constexpr uint32_t kLdsMaxNodes = 1u << kLdsIdBits;
+// compact LDS tier of the CBS / ECBS kernels (ll_compact.h): mrp_ll_options.lds_nodes / 2 = open-list entries a search may
+// hold inside it, at most 1023
+constexpr uint32_t kLdsMaxNodes = 2048;
 constexpr uint32_t kGMask = (1u << kGBits) - 1;
 constexpr uint32_t kFMax = (1u << kFBits) - 1;
 constexpr uint32_t kFhMax = (1u << kFhBits) - 1;                   // focalH beyond this -> MRP_LL_CAP_FOCAL (loud)

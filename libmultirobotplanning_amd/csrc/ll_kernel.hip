@@ -170,8 +170,7 @@ struct TierLdsT {
   DEVI static E fromLane(E v, uint32_t srcLane) { return __builtin_amdgcn_readlane(v, srcLane); }
   DEVI static E shr1(E v) { return waveShr1(v); }
 };
-// CBS / ECBS fast tier: [31:22] 1023 - focalH, [21:15] 127 - f, [14:9] g, [8:0] node
-typedef TierLdsT<kLdsIdBits, 6, 7, 32 - 6 - 7 - kLdsIdBits> TierLds;
+// (the CBS / ECBS fast tier is ll_compact.h: its 32-bit entries name the state itself, there are no node records)
 // SIPP fast tier: [31:21] 2047 - f, [20:11] g (arrival time, <= kGMask), [10:0] node — the whole open key of TierHbm
 typedef TierLdsT<11, kGBits, kFBits, 0> TierLdsSipp;
 // SIPP middle tier, for a search that has outgrown TierLdsSipp's 2047 nodes: the node records go to the arena, the open
@@ -1194,6 +1193,9 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     cj.pathsLds = c.pathsLds ? ct::oPaths : ct::kNoLds;
     cj.pathsG = c.paths;
     cj.maxExp = c.maxExp < 0 ? 0xFFFFFFFFu : (c.maxExp > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)c.maxExp);
+    // mrp_ll_configure_tiers: lds_nodes / 2 = open-list entries, lds_rows = time steps a search may use inside the tier
+    cj.openCap = P.lds_nodes / 2u < ct::kCap ? P.lds_nodes / 2u : ct::kCap;
+    cj.maxT = P.lds_rows >= 3u && P.lds_rows - 2u < ct::kMaxT ? P.lds_rows - 2u : ct::kMaxT;
     cj.parentTab = arenaSlot;  // the arena's node area: unused while the search is in this tier
     cj.outPath = outPath;
     ct::CRes cr;

@@ -964,10 +964,10 @@ int mrp_ll_create(const mrp_ll_options* optIn, mrp_ll_ctx** out) {
   if (o.max_horizon > static_cast<int32_t>(mrp::kMaxHorizon)) o.max_horizon = mrp::kMaxHorizon;
   if (o.max_cells <= 0) o.max_cells = 4096;
   if (o.max_cells > 255 * 255) o.max_cells = 255 * 255;
-  if (o.lds_nodes == 0) o.lds_nodes = 512;
+  if (o.lds_nodes == 0) o.lds_nodes = mrp::kLdsMaxNodes;
   if (o.lds_nodes < 0) o.lds_nodes = 0;
-  o.lds_nodes = std::min<int32_t>(o.lds_nodes, mrp::kLdsMaxNodes);  // node-id bits in the compact tier's heap entries
-  o.lds_nodes &= ~3;  // heap arrays hold lds_nodes / 2 entries and stay 8-byte aligned
+  o.lds_nodes = std::min<int32_t>(o.lds_nodes, mrp::kLdsMaxNodes);  // the compact tier's open list holds lds_nodes / 2 entries
+  o.lds_nodes &= ~3;
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || o.device < 0 || o.device >= ndev) {
@@ -1098,7 +1098,7 @@ int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t ldsNodes, int32_t ldsRows, i
   for (const Ticket& t : ctx->tickets)
     if (t.inFlight) return MRP_LL_E_BUSY;
   if (ldsNodes < 0) ctx->opt.lds_nodes = 0;
-  // the compact LDS tier addresses 512 nodes and 64 time steps (9-bit node ids and 6-bit g in its 32-bit heap entries)
+  // the compact LDS tier holds up to 1023 open entries (lds_nodes / 2) and 64 time steps; its LDS window has a fixed size
   if (ldsNodes > 0) ctx->opt.lds_nodes = std::max(8, std::min<int32_t>(ldsNodes, mrp::kLdsMaxNodes) & ~3);
   if (ldsRows > 0) ctx->tierRows = static_cast<uint32_t>(std::min(std::max(ldsRows, 8), 64));
   if (ldsPathBytes > 0) ctx->tierPathBytes = static_cast<uint32_t>(std::min(ldsPathBytes, 65536)) & ~31u;

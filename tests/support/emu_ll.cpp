@@ -25,13 +25,14 @@ extern "C" {
 
 // One low-level search through the compact tier.  Inputs as in include/mrp_ll.h's mrp_ll_job (constraints [n][3] / [n][5],
 // context paths flattened: path_len[n_agents], path_xy = all states back to back); lds_path_bytes = room for the focal
-// path table in the LDS window (a larger table is read from "global" memory, as on the device).
+// path table in the LDS window (a larger table is read from "global" memory, as on the device); open_cap / max_t > 0:
+// tighter limits of the tier for this job (what mrp_ll_configure_tiers' lds_nodes / lds_rows set on the device).
 // out[0..5] = status (ct::C_*: 0 ok, 1 no solution, 2 expansion cap, -1 overflow: not a search of this tier), cost, fmin,
 // n_states, expanded, nodes created;  out[6] = out-of-window LDS reads, out[7] = out-of-window LDS writes.
 int emu_compact_search(int eps, int dimx, int dimy, int n_obst, const int32_t* obst_xy, int sx, int sy, int gx, int gy,
                        float w, int n_vc, const int32_t* vc, int n_ec, const int32_t* ec, int n_agents, int agent_idx,
                        const int32_t* path_len, const int32_t* path_xy, int64_t max_exp, int lds_path_bytes,
-                       int64_t* out, int32_t* states_xy, int states_cap) {
+                       int open_cap, int max_t, int64_t* out, int32_t* states_xy, int states_cap) {
   using namespace mrp::ct;
   if (dimx < 1 || dimy < 1 || dimx > 32 || dimy > 32) return -2;
   const uint32_t cells = (uint32_t)dimx * dimy;
@@ -107,6 +108,8 @@ int emu_compact_search(int eps, int dimx, int dimy, int n_obst, const int32_t* o
   J.pathsLds = tableInLds ? oPaths : kNoLds;
   J.pathsG = table.data();
   J.maxExp = max_exp < 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(max_exp, 0xFFFFFFFEll);
+  J.openCap = open_cap > 0 ? std::min<uint32_t>((uint32_t)open_cap, kCap) : kCap;
+  J.maxT = max_t > 0 ? std::min<uint32_t>((uint32_t)max_t, kMaxT) : kMaxT;
   J.parentTab = parentTab.data();
   J.outPath = outPath.data();
   CRes R;

@@ -30,8 +30,8 @@ def _emu_lib():
     L.emu_compact_search.restype = ctypes.c_int
     L.emu_compact_search.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, I32P, ctypes.c_int, I32P,
-                                     ctypes.c_int, ctypes.c_int, I32P, I32P, ctypes.c_int64, ctypes.c_int, I64P, I32P,
-                                     ctypes.c_int]
+                                     ctypes.c_int, ctypes.c_int, I32P, I32P, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, I64P, I32P, ctypes.c_int]
     return L
 
 
@@ -40,7 +40,8 @@ def _arr(a, shape):
     return a, a.ctypes.data_as(I32P)
 
 
-def emu_search(L, eps, inst, agent, start, goal, vc, ec, ctx_paths, w, max_exp=-1, lds_path_bytes=2048):
+def emu_search(L, eps, inst, agent, start, goal, vc, ec, ctx_paths, w, max_exp=-1, lds_path_bytes=2048, open_cap=0,
+               max_t=0):
     obst, obst_p = _arr(inst["obstacles"], (-1, 2))
     vca, vc_p = _arr(vc, (-1, 3))
     eca, ec_p = _arr(ec, (-1, 5))
@@ -50,13 +51,13 @@ def emu_search(L, eps, inst, agent, start, goal, vc, ec, ctx_paths, w, max_exp=-
     states = np.zeros((1024, 2), dtype=np.int32)
     rc = L.emu_compact_search(1 if eps else 0, inst["dimx"], inst["dimy"], len(obst), obst_p, start[0], start[1], goal[0],
                               goal[1], w, len(vca), vc_p, len(eca), ec_p, len(plen), agent, plen_p, pxy_p, max_exp,
-                              lds_path_bytes, out.ctypes.data_as(I64P), states.ctypes.data_as(I32P), 1024)
+                              lds_path_bytes, open_cap, max_t, out.ctypes.data_as(I64P), states.ctypes.data_as(I32P), 1024)
     assert rc == 0, rc
     return dict(status=int(out[0]), cost=int(out[1]), fmin=int(out[2]), n_states=int(out[3]), expanded=int(out[4]),
                 nodes=int(out[5]), oob_reads=int(out[6]), oob_writes=int(out[7]), states=states[:int(out[3])].tolist())
 
 
-def _replay(L, oracle_mod, inst, algo, w, lds_path_bytes=2048, cap_total=-1):
+def _replay(L, oracle_mod, inst, algo, w, lds_path_bytes=2048, cap_total=-1, open_cap=0, max_t=0):
     """Every low-level call of the instance's conflict tree through the emulated tier.  Returns (finished, handed over)."""
     eps = algo == oracle_mod.ECBS
     _, calls = oracle_mod.mapf_record(algo, inst, w=w, cap_total=cap_total)
@@ -64,7 +65,7 @@ def _replay(L, oracle_mod, inst, algo, w, lds_path_bytes=2048, cap_total=-1):
     for c in calls:
         r = emu_search(L, eps, inst, c["agent"], inst["starts"][c["agent"]], inst["goals"][c["agent"]],
                        c["vertex_constraints"], c["edge_constraints"], c["ctx_paths"] if eps else [], w,
-                       lds_path_bytes=lds_path_bytes)
+                       lds_path_bytes=lds_path_bytes, open_cap=open_cap, max_t=max_t)
         assert r["oob_writes"] == 0 and r["oob_reads"] == 0, r
         if r["status"] == -1:
             over += 1
@@ -151,3 +152,13 @@ def test_random_constraint_sets_and_caps(emu, oracle_mod, bench_instances):
                 assert (r["cost"], r["fmin"]) == (o["cost"], o["fmin"])
                 assert r["states"] == [st[1:] for st in o["states"]]
     assert n > 60
+
+
+def test_tight_limits_hand_over_cleanly(emu, oracle_mod, bench_instances):
+    """Small open-list / time-step limits (mrp_ll_configure_tiers): what still finishes inside the tier is exact, the rest
+    is handed over."""
+    inst = bench_instances["map_32by32_obst204_agents10_ex9"]
+    d1, o1 = _replay(emu, oracle_mod, inst, oracle_mod.ECBS, 1.3, open_cap=40)
+    d2, o2 = _replay(emu, oracle_mod, inst, oracle_mod.ECBS, 1.3, max_t=12)
+    d3, o3 = _replay(emu, oracle_mod, inst, oracle_mod.ECBS, 1.3, open_cap=4)
+    assert o1 > 0 and o2 > 0 and d1 > 0 and d3 == 0, (d1, o1, d2, o2, d3, o3)

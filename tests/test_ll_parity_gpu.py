@@ -71,7 +71,7 @@ def test_ecbs_low_level_calls_100_agents(engine, oracle_mod, bench_instances):
     cases = _harvest(oracle_mod, bench_instances, ["map_32by32_obst204_agents100_ex0"], oracle_mod.ECBS, 1.3, 3_000_000)
     from libmultirobotplanning_amd import ll
     res = _run_and_compare(engine, cases, ll.ASTAR_EPS, 1.3)
-    assert any(r.tier == 1 for r in res) or max(r.expanded for r in res) < 300  # big searches leave the LDS tier
+    assert any(r.tier == 0 for r in res)  # (searches of thousands of expansions stay in the compact tier too)
 
 
 def test_ecbs_w1_low_level_calls(engine, oracle_mod, bench_instances, ref_tests):
@@ -178,8 +178,8 @@ def test_more_than_128_agents_in_the_focal_context(engine, oracle_mod):
 
 
 def test_configure_tiers_changes_nothing_but_the_tier(oracle_mod, bench_instances):
-    """mrp_ll_configure_tiers: any LDS geometry (heaps hold nodes/2 entries, so a tiny tier also overflows through the
-    open-list bound) gives the same bits; occupancy follows the tier size."""
+    """mrp_ll_configure_tiers: any limits (open list nodes/2 entries, time steps) give the same bits — a search that
+    outgrows them is run by the arena tier; occupancy follows the LDS bytes."""
     from libmultirobotplanning_amd import ll
     cases = _harvest(oracle_mod, bench_instances, ["map_32by32_obst204_agents10_ex%d" % k for k in range(10, 14)],
                      oracle_mod.ECBS, 1.3, 3_000_000)
@@ -191,7 +191,7 @@ def test_configure_tiers_changes_nothing_but_the_tier(oracle_mod, bench_instance
             res = _run_and_compare(eng, cases, ll.ASTAR_EPS, 1.3)
             if geom[0] <= 64:
                 assert any(r.tier == 1 for r in res)
-        assert occ[0] >= 8 and occ[2] < occ[0]  # compact tier: ~13 KB per search -> 11-12 searches per CU
+        assert occ[0] >= 6 and occ[2] < occ[0]  # the tier's window is fixed (~18 KB); the path table comes on top
         eng.session_begin(64)
         try:
             with pytest.raises(RuntimeError):
