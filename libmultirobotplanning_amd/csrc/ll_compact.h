@@ -12,19 +12,26 @@
 //     names the node completely: there are no node records, no node ids and no handle table.  A larger entry (under the
 //     list's key mask) is a BETTER node in the reference's orders (open a_star_epsilon.hpp:312-323: f asc, g desc; focal
 //     :346-366: focalH, f asc, g desc); equal keys compare equal, the layout decides, and the layout is replayed verbatim.
-//   * openSet.erase(handle) (a_star_epsilon.hpp:216) needs the position of the popped node in the open array: ONE
-//     ds_read_b128 per lane looks at all (<= 255) entries at once.  No position array, no stores to keep one current.
+//   * openSet.erase(handle) (a_star_epsilon.hpp:216) needs the position of the popped node in the open array: one
+//     ds_read_b128 per lane looks at 256 entries at once.  No position array, no stores to keep one current.
 //   * The open list lives in lanes 0..31 and the focal list in lanes 32..63 of every heap step: the pop of one and the
 //     erase from the other (sift-downs, five levels per round trip each), and the two pushes of a successor (sift-ups),
 //     are one instruction stream.
+//   * Every heap slot that holds no element holds kEmpty, whose key is smaller than any real key, and the word in front
+//     of element 0 holds the largest key: a sift-down that looks at the children of a leaf, or past the end of the array,
+//     and a sift-up lane beyond the root, read a value that makes them do nothing — no bounds tests, no masked loads.
 //   * cameFrom (a_star_epsilon.hpp:275-279) is one byte (the action) per discovered state in a (time, cell) table in the
 //     search's arena slot, written and forgotten; the goal branch reads it back eight time steps per round trip.
 //   * The (time, cell) bitmap — obstacles | vertex constraints | discovered — answers stateValid (ecbs.cpp:497-503),
-//     closedSet.find and stateToHeap.find (a_star_epsilon.hpp:224-227) with one bit, as before; all 64 rows are set up at
-//     job start, eight rows per instruction.
+//     closedSet.find and stateToHeap.find (a_star_epsilon.hpp:224-227) with one bit; all rows are set up at job start,
+//     eight rows per instruction.
+//   * The job arrives, and the result leaves, through a block of the LDS window; compactSearch is a real function (not
+//     inlined into the kernels), so nothing of the kernels' own state occupies scalar registers while a search runs.
 // Limits of the tier (a search that would exceed one returns C_OVERFLOW before touching anything of that expansion and is
-// run again by the arena tier, ll_kernel.hip): maps up to 32 x 32, 255 open entries, t <= 61 for an expanded node, focalH <= 511.
+// run again by the arena tier, ll_kernel.hip): maps up to 32 x 32, 1023 open entries, t <= 61 for an expanded node,
+// focalH <= 511, at most 64 edge constraints, at most 128 agents in the focal context.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace mrp {
@@ -33,57 +40,72 @@ namespace ct {
 using namespace wv;
 
 // ---- LDS window of one search (byte offsets) ------------------------------------------------------------------
-// A heap: element i sits at byte 4 * (i + 1) of its area, so that
-// the children (2i + 1, 2i + 2) of any node are one aligned 8-byte pair and lane L's 16-byte group holds elements
-// 4L - 1 .. 4L + 2 (element "-1" is the bias word, kept at 0xFFFFFFFF).
-#ifndef MRP_CT_GROUPS
-#define MRP_CT_GROUPS 4
-#endif
-constexpr uint32_t kGroups = MRP_CT_GROUPS;       // 256-entry groups of the open / focal arrays (one scan instruction each)
+// A heap area: element i at byte 4 * (i + 1), so that the children (2i + 1, 2i + 2) of any node are one aligned 8-byte
+// pair and lane L's 16-byte group of 256-entry group g holds elements 256 g + 4L - 1 .. 256 g + 4L + 2.
+constexpr uint32_t kGroups = 4;                   // 256-entry groups of the open / focal arrays (one scan instruction each)
 constexpr uint32_t kCap = 256u * kGroups - 1u;    // entries of the open / focal list
 constexpr uint32_t kHeapBytes = 1024u * kGroups + 16u;
-constexpr uint32_t kAuxCap = 128u * kGroups + 4u; // walk queue of the ordered walk: at most (n + 1) / 2 + 1 entries
+constexpr uint32_t kHeapClamp = kCap + 2u;        // odd; elements kCap .. kCap + 3 exist and always hold kEmpty
+constexpr uint32_t kAuxCap = 128u * kGroups + 2u; // walk queue of the ordered walk: at most (n + 1) / 2 + 1 entries
 constexpr uint32_t kAuxBytes = 512u * kGroups + 32u;
+constexpr uint32_t kAuxClamp = kAuxCap + 1u;      // odd; elements kAuxCap .. kAuxCap + 4 always hold kEmpty
 constexpr uint32_t kRows = 64, kRowBytes = 128;   // (time, cell) bitmap: 32 words (one per y) of 32 bits (x) per time step
-constexpr uint32_t oOpen = 0;
+constexpr uint32_t oCtl = 0;                      // 256 bytes for the kernel that hosts the tier (job descriptor, result)
+constexpr uint32_t oJob = 256;                    // CJob
+constexpr uint32_t oRes = 384;                    // CRes
+constexpr uint32_t oOpen = 416;
 constexpr uint32_t oFocal = oOpen + kHeapBytes;
 constexpr uint32_t oAux = oFocal + kHeapBytes;
 constexpr uint32_t oBits = oAux + kAuxBytes;
 constexpr uint32_t oObst = oBits + kRows * kRowBytes;
 constexpr uint32_t oPaths = oObst + kRowBytes;    // the focal path table follows (size chosen by the launcher)
 constexpr uint32_t kLdsBytes = oPaths;
-static_assert(oBits % 16 == 0 && oObst % 16 == 0 && oPaths % 16 == 0, "LDS areas are 16-byte aligned");
+static_assert(oOpen % 16 == 0 && oFocal % 16 == 0 && oAux % 16 == 0 && oBits % 16 == 0 && oObst % 16 == 0 && oPaths % 16 == 0,
+              "LDS areas are 16-byte aligned");
+static_assert((kHeapClamp & 1u) == 1u && 4u * (kHeapClamp + 3u) <= kHeapBytes, "clamped child pair stays inside the heap area");
+static_assert((kAuxClamp & 1u) == 1u && 4u * (kAuxClamp + 3u) <= kAuxBytes, "clamped child pair stays inside the walk queue");
+static_assert(kGroups >= 1 && kGroups <= 4, "the walk queue keeps an open index in the ten bits below the key");
 
 constexpr uint32_t kMO = 0x007FFC00u;             // open key:  f, g
 constexpr uint32_t kMF = 0xFFFFFC00u;             // focal key: focalH, f, g
-constexpr uint32_t kEmpty = 0xFFFFFFFFu;          // never matches a state: g = 63 is never pushed (kMaxT)
+constexpr uint32_t kEmpty = 0x0000FFFFu;          // "no element": its key is below every real key (f <= 124 in this tier) and
+                                                  // its low half never names a state (g = 63 is never pushed: kMaxT)
+constexpr uint32_t kFront = 0xFFFFFFFFu;          // the word in front of element 0: above every key, names no state
 constexpr uint32_t kMaxT = 61;                    // the last time step whose nodes are expanded here (successors: g <= 62)
 constexpr uint32_t kParentBytes = kRows * 1024;   // cameFrom table in the arena slot
-constexpr uint32_t kNoLds = 0xFFFFFFFFu;
 
 enum : int32_t { C_OK = 0, C_NO_SOLUTION = 1, C_CAP_EXP = 2, C_OVERFLOW = -1 };
 
-struct CJob {
+struct CJob {              // at oJob of the window; pointers as two words
   uint32_t dimx, dimy, sx, sy, gx, gy;
   int32_t lastGoal;        // Environment::m_lastGoalConstraint (ecbs.cpp:268-273)
   float w;                 // AStarEpsilon::m_w, binary32 (a_star_epsilon.hpp:386)
-  uint32_t nVc, nEc;
-  const uint32_t* vc;      // t << 16 | y << 8 | x
-  const uint32_t* ec;      // t << 19 | (y * dimx + x) << 3 | k   (k = index in Wait, Left, Right, Up, Down)
-  const uint32_t* obst;    // the map's obstacle bitmap, bit y * dimx + x
+  uint32_t nVc, nEc;       // nEc <= 64
   uint32_t obstWords;
-  uint32_t nAgentsPad, tPad;  // focal context: table [tPad][nAgentsPad] of x | y << 8 halfwords (0xFFFF = nobody)
-  uint32_t pathsLds;       // byte offset of the table in LDS, or kNoLds: then it is at pathsG
-  const uint16_t* pathsG;
+  uint32_t nAgentsPad, tPad;  // focal context: table [tPad][nAgentsPad] of x | y << 8 halfwords (0xFFFF = nobody); <= 128 agents
   uint32_t maxExp;         // 0xFFFFFFFF = unlimited
   uint32_t openCap, maxT;  // limits of this job inside the tier: <= kCap open entries, expanded nodes at t <= maxT <= kMaxT
-  uint8_t* parentTab;      // kParentBytes of device memory: action byte per (t, cell)
-  uint16_t* outPath;       // x | y << 8 per time step
+  uint64_t vc;             // const uint32_t*: t << 16 | y << 8 | x
+  uint64_t ec;             // const uint32_t*: t << 19 | (y * dimx + x) << 3 | k   (k = index in Wait, Left, Right, Up, Down)
+  uint64_t obst;           // const uint32_t*: the map's obstacle bitmap, bit y * dimx + x
+  uint64_t pathsG;         // const uint16_t*: the path table when it is not in the window (PLDS = false)
+  uint64_t parentTab;      // uint8_t*: kParentBytes of device memory, action byte per (t, cell)
+  uint64_t outPath;        // uint16_t*: x | y << 8 per time step
 };
-struct CRes {
+static_assert(sizeof(CJob) <= oRes - oJob && sizeof(CJob) % 4 == 0, "CJob fits its block of the window");
+struct CRes {              // at oRes
   int32_t status, cost, fmin, nStates;
   uint32_t expanded, nodes;
 };
+static_assert(sizeof(CRes) <= oOpen - oRes, "CRes fits its block of the window");
+
+#define MRP_CT_JOB_U32(lds, field) ldsLoadS(lds, oJob + (uint32_t)offsetof(CJob, field))
+template <class T>
+WV_FN T* jobPtr(Lds lds, uint32_t off) {
+  const uint64_t lo = ldsLoadS(lds, oJob + off), hi = ldsLoadS(lds, oJob + off + 4u);
+  return (T*)(uintptr_t)(lo | (hi << 32));
+}
+#define MRP_CT_JOB_PTR(T, lds, field) jobPtr<T>(lds, (uint32_t)offsetof(CJob, field))
 
 WV_FN uint32_t popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
 WV_FN uint32_t ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
@@ -98,7 +120,7 @@ WV_FN uint32_t hi32(uint64_t v) { return (uint32_t)(v >> 32); }
 struct Sides {
   V lane, l5;
   B isB;
-  V lvl, off;      // level of node l5 inside the subtree, position inside that level
+  V lvl, off1;     // level of node l5 inside the subtree; position inside that level, minus one (lane 31: far outside)
   V anc, needR;    // bit a set <=> node a is an ancestor of node l5 / ... and the way to l5 leaves a through its RIGHT child
 };
 WV_FN Sides makeSides() {
@@ -108,7 +130,7 @@ WV_FN Sides makeSides() {
   s.isB = (s.lane >> 5) != 0u;
   const V n = s.l5 + 1u;
   s.lvl = 31u - clz(n);
-  s.off = n - (splat(1u) << s.lvl);
+  s.off1 = sel(s.l5 == 31u, splat(0x100000u), n - (splat(1u) << s.lvl) - 1u);
   s.anc = splat(0u);
   s.needR = splat(0u);
   for (uint32_t k = 1; k <= 4; ++k) {
@@ -119,114 +141,113 @@ WV_FN Sides makeSides() {
   }
   return s;
 }
+WV_FN V bothSides(const Sides& S, uint32_t a, uint32_t b) { return sel(S.isB, splat(b), splat(a)); }  // side A: a, side B: b
 
-// Sift-downs of two heaps at once, five levels per LDS round trip.  Side X (A: lanes 0..31, B: lanes 32..63) moves the
-// hole at idxX down its heap of nX elements (element 0 at byte address hb of that side's lanes, keys under mask km):
+// Sift-downs of two heaps at once, five levels per LDS round trip.  Each side moves a hole, starting at its root, down
+// its heap (element 0 at byte address hb, keys under mask km, child pairs clamped to element cMax):
 //   STL = false (boost siftdown): prefer the FIRST maximal child; stop in front of a child that is less than x (key xk);
 //   STL = true  (libstdc++ __adjust_heap): prefer the right child unless it is less than the left one; descend to a leaf.
 // Which child is the larger one does not depend on the element being sifted, so a lane decides from two ballots whether
 // its node is on the path (every ancestor let the hole pass and turned towards it), and the nodes on the path pull their
-// chosen child up in one store.  nX == 0 or idx past the last parent: nothing happens on that side.  Returns the holes.
+// chosen child up in one store.  Slots past a heap's end hold kEmpty: the hole stops by itself at a leaf, and a side with
+// nothing (left) to do repeats a block in which nothing moves.  Returns the holes (per lane: the hole of the lane's side).
 template <bool STL>
-WV_FN void dualDescend(Lds lds, const Sides& S, V hb, V km, uint32_t nA, uint32_t nB, uint32_t& idxA, uint32_t& idxB,
-                       V xk) {
-  bool moreA = nA > 1u, moreB = nB > 1u;
-  const V nV = sel(S.isB, splat(nB), splat(nA));
-  while (moreA | moreB) {
-    const V idx = sel(S.isB, splat(idxB), splat(idxA));
-    const B more = sel(S.isB, splat(moreB ? 1u : 0u), splat(moreA ? 1u : 0u)) != 0u;
-    const V node = ((idx + 1u) << S.lvl) - 1u + S.off;
-    const V c = node * 2u + 1u;
-    const B has = (S.l5 < 31u) & (c < nV) & more;
-    const V2 pr = ldsLoad64m(lds, hb + c * 4u, has);  // children (c, c + 1): one aligned pair
+WV_FN V dualDescend(Lds lds, const Sides& S, V hb, V km, V cMax, V xk) {
+  V idx = splat(0u);
+  const V tiny = km & kEmpty;
+  for (;;) {
+    const V node = ((idx + 1u) << S.lvl) + S.off1;
+    V c = node * 2u + 1u;
+    c = sel(c < cMax, c, cMax);
+    const V2 pr = ldsLoad64(lds, hb + c * 4u);          // children (c, c + 1): one aligned pair
     const V kl = pr.x & km, kr = pr.y & km;
-    const B hasR = has & ((c + 1u) < nV);
-    const B right = STL ? (hasR & !(kr < kl)) : (hasR & (kl < kr));
+    const B right = STL ? (kr >= kl) : (kl < kr);
     const V pe = sel(right, pr.y, pr.x);
     const V pk = sel(right, kr, kl);
-    const B go = STL ? has : (has & !(pk < xk));       // the hole moves below this node
+    const B go = STL ? (kl > tiny) : (pk >= xk);        // the hole moves below this node (a missing child: key `tiny`)
     const uint64_t goM = ballot(go), rM = ballot(right);
-    const V g32 = sel(S.isB, splat(hi32(goM)), splat(lo32(goM)));
-    const V r32 = sel(S.isB, splat(hi32(rM)), splat(lo32(rM)));
+    const V g32 = bothSides(S, lo32(goM), hi32(goM));
+    const V r32 = bothSides(S, lo32(rM), hi32(rM));
     const B reached = ((g32 & S.anc) == S.anc) & (((r32 ^ S.needR) & S.anc) == 0u);
     const B onPath = reached & go;
     const uint64_t pM = ballot(onPath);
-    ldsStore32m(lds, hb + node * 4u, pe, onPath);      // every node on the path pulls its chosen child up
-    {
-      const uint32_t pm = lo32(pM), rm = lo32(rM);
-      const uint32_t steps = (uint32_t)__builtin_popcount(pm);
-      if (pm) {
-        const uint32_t d = lg2(pm);                    // deepest node on the path (levels are index-ordered)
-        const uint32_t rel = 2u * d + 1u + ((rm >> d) & 1u);
-        idxA = ((idxA + 1u) << steps) - 1u + (rel + 1u - (1u << steps));
-      }
-      moreA = moreA && steps == 5u;
-    }
-    {
-      const uint32_t pm = hi32(pM), rm = hi32(rM);
-      const uint32_t steps = (uint32_t)__builtin_popcount(pm);
-      if (pm) {
-        const uint32_t d = lg2(pm);
-        const uint32_t rel = 2u * d + 1u + ((rm >> d) & 1u);
-        idxB = ((idxB + 1u) << steps) - 1u + (rel + 1u - (1u << steps));
-      }
-      moreB = moreB && steps == 5u;
-    }
+    ldsStore32m(lds, hb + node * 4u, pe, onPath);       // every node on the path pulls its chosen child up
+    // the new hole of this lane's side: below the deepest node on the path (levels are index-ordered), on the side it chose
+    const V pm = bothSides(S, lo32(pM), hi32(pM));
+    const V steps = popc(pm);
+    const V d = 31u - clz(pm | 1u);
+    const V rel = d * 2u + 1u + ((r32 >> d) & 1u);
+    idx = sel(pm != 0u, ((idx + 1u) << steps) + rel - (splat(1u) << steps), idx);
+    if (ballot(steps == 5u) == 0ull) break;
   }
+  return idx;
 }
 
-// Sift-ups of two heaps at once (boost siftup / libstdc++ __push_heap: while less(parent, e) the parent moves down):
-// side X inserts eX at position pX of its heap when actX.  Lane l5 of a side loads the chain's ancestor l5; one ballot
-// finds where the sequential loop would have stopped; the ancestors below that point move down one level and the new
-// element lands above them — one load, one store.
-WV_FN void dualSiftUp(Lds lds, const Sides& S, V hb, V km, uint32_t pA, uint32_t pB, bool actA, bool actB, V e) {
-  const V p1 = sel(S.isB, splat(pB + 1u), splat(pA + 1u));
-  const B act = sel(S.isB, splat(actB ? 1u : 0u), splat(actA ? 1u : 0u)) != 0u;
-  const V depth = 31u - clz(p1);                        // number of ancestors of p
-  const B isAnc = act & (S.l5 < depth);
+// Sift-ups of two heaps at once (boost siftup / libstdc++ __push_heap: while less(parent, e) the parent moves down): a
+// side inserts e at position p = p1 - 1 of its heap; a side that has nothing to insert passes p1 = 1 and idle = true.
+// Lane l5 of a side loads the chain's ancestor l5 (lanes beyond the root read the word in front of the array, which no
+// element is better than); one ballot finds where the sequential loop would have stopped; the ancestors below that point
+// move down one level and the new element lands above them — one load, one store.
+WV_FN void dualSiftUp(Lds lds, const Sides& S, V hb, V km, V p1, uint32_t e, bool idleA, bool idleB) {
   const V ancPos = (p1 >> (S.l5 + 1u)) - 1u;
-  const V ae = ldsLoad32m(lds, hb + ancPos * 4u, isAnc);
-  const uint64_t worse = ballot(isAnc & ((ae & km) < (e & km)));
-  const uint32_t stopA = ctz32(~lo32(worse)), stopB = ctz32(~hi32(worse));  // first ancestor that is not worse than e
-  const V stop = sel(S.isB, splat(stopB), splat(stopA));
+  const V ae = ldsLoad32(lds, hb + ancPos * 4u);
+  const uint64_t worse = ballot((ae & km) < (km & e));
+  // first ancestor that is not worse than e, plus one (0: this side inserts nothing)
+  const uint32_t stopA = idleA ? 0u : ctz32(~lo32(worse)) + 1u, stopB = idleB ? 0u : ctz32(~hi32(worse)) + 1u;
+  const V stop1 = bothSides(S, stopA, stopB);
   const V dest = (p1 >> S.l5) - 1u;                     // lane l5 < stop: ancestor l5 moves down to here; lane == stop: e
-  ldsStore32m(lds, hb + dest * 4u, sel(S.l5 == stop, e, ae), act & (S.l5 <= stop));
+  ldsStore32m(lds, hb + dest * 4u, sel((S.l5 + 1u) == stop1, splat(e), ae), S.l5 < stop1);
 }
 
 // ---- one search ------------------------------------------------------------------------------------------------
-template <bool EPS>
-WV_FN int32_t compactSearch(Lds lds, const CJob& J, CRes& R) {
+// The job is the CJob at oJob of the window, the result the CRes at oRes.  PLDS: the focal path table is in the window at
+// oPaths (else at CJob::pathsG); the search loop of a PLDS instance issues no vector-memory LOAD at all — its only
+// vector-memory instruction is the cameFrom store — so nothing in it ever waits on vmcnt.
+template <bool EPS, bool PLDS>
+WV_ENTRY int32_t compactSearch(Lds window) {
+  const Lds lds = windowBase(window);
   const Sides S = makeSides();
   const V lane = S.lane;
-  const V hb = sel(S.isB, splat(oFocal + 4u), splat(oOpen + 4u));  // side A = open list, side B = focal list
-  const V km = sel(S.isB, splat(kMF), splat(kMO));
-  const V hbAux = splat(oAux + 4u), kmAux = splat(kMO);            // the walk queue is worked on by side A alone
-  R.status = C_NO_SOLUTION;
-  R.cost = 0; R.fmin = 0; R.nStates = 0; R.expanded = 0; R.nodes = 1;
+  const V hb = bothSides(S, oOpen + 4u, oFocal + 4u);  // side A = open list, side B = focal list
+  const V km = bothSides(S, kMO, kMF);
+  const V hbAux = splat(oAux + 4u), kmAux = splat(kMO);  // the walk queue: both sides do the same work on it
+  const uint32_t dimx = MRP_CT_JOB_U32(lds, dimx), dimy = MRP_CT_JOB_U32(lds, dimy);
+  const uint32_t gx = MRP_CT_JOB_U32(lds, gx), gy = MRP_CT_JOB_U32(lds, gy);
+  const uint32_t nEc = MRP_CT_JOB_U32(lds, nEc);
+  const uint32_t nAgentsPad = EPS ? MRP_CT_JOB_U32(lds, nAgentsPad) : 0u;
+  int32_t status = C_NO_SOLUTION, cost = 0, fmin = 0, nStates = 0;
+  uint32_t nOpen = 1, nFocal = EPS ? 1u : 0u, nodes = 1, expansions = 0;
 
   // ---- job set-up -------------------------------------------------------------------------------------------
-  sync();  // the previous job's LDS reads are done
+  sync();  // the previous job's LDS reads are done; the CJob block is written
   {  // obstacle row with a stride of 32 bits per y (the map's bitmap has a stride of dimx): lane y builds word y
+    const uint32_t* obst = MRP_CT_JOB_PTR(const uint32_t, lds, obst);
+    const uint32_t obstWords = MRP_CT_JOB_U32(lds, obstWords);
     const V y = S.l5;
-    const V bitOff = y * J.dimx;
+    const V bitOff = y * dimx;
     const V wi = bitOff >> 5, sh = bitOff & 31u;
-    const B rowIn = (y < J.dimy) & !S.isB;
-    const V lo = gLoad32m(J.obst, wi, rowIn & (wi < J.obstWords));
-    const V hi = gLoad32m(J.obst, wi + 1u, rowIn & ((wi + 1u) < J.obstWords));
+    const B rowIn = (y < dimy) & !S.isB;
+    const V lo = gLoad32m(obst, wi, rowIn & (wi < obstWords));
+    const V hi = gLoad32m(obst, wi + 1u, rowIn & ((wi + 1u) < obstWords));
     V w = sel(sh == 0u, lo, (lo >> sh) | (hi << (splat(32u) - sh)));
-    const uint32_t colMask = J.dimx >= 32u ? 0xFFFFFFFFu : ((1u << J.dimx) - 1u);
+    const uint32_t colMask = dimx >= 32u ? 0xFFFFFFFFu : ((1u << dimx) - 1u);
     w = (w & colMask) | ~colMask;                       // columns beyond the map: blocked
     w = sel(rowIn, w, splat(0xFFFFFFFFu));              // rows beyond the map: blocked
     ldsStore32m(lds, splat(oObst) + y * 4u, w, !S.isB);
   }
-  {  // heaps: every slot "no state" (the position scan must never meet a stale copy of a live entry)
-    const V4 ones{splat(kEmpty), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
-    for (uint32_t g = 0; g < kGroups; ++g) {
-      ldsStore128(lds, splat(oOpen + g * 1024u) + lane * 16u, ones);
-      ldsStore128(lds, splat(oFocal + g * 1024u) + lane * 16u, ones);
+  {  // heaps and walk queue: every slot "no element", the words in front of element 0 the largest key
+    const V4 none{splat(kEmpty), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
+    const V4 head{sel(lane == 0u, splat(kFront), splat(kEmpty)), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
+    ldsStore128(lds, splat(oOpen) + lane * 16u, head);
+    ldsStore128(lds, splat(oFocal) + lane * 16u, head);
+    ldsStore128(lds, splat(oAux) + lane * 16u, head);
+    for (uint32_t g = 1; g < kGroups; ++g) {
+      ldsStore128(lds, splat(oOpen + g * 1024u) + lane * 16u, none);
+      ldsStore128(lds, splat(oFocal + g * 1024u) + lane * 16u, none);
     }
-    ldsStore128m(lds, splat(oOpen + kGroups * 1024u), ones, lane == 0u);
-    ldsStore128m(lds, splat(oFocal + kGroups * 1024u), ones, lane == 0u);
+    ldsStore128m(lds, splat(oOpen + kGroups * 1024u), none, lane == 0u);
+    ldsStore128m(lds, splat(oFocal + kGroups * 1024u), none, lane == 0u);
+    for (uint32_t b = 1024u; b < kAuxBytes; b += 1024u) ldsStore128m(lds, splat(oAux + b) + lane * 16u, none, (lane * 16u + b) < kAuxBytes);
   }
   sync();
   {  // bitmap rows: row t = obstacles (| vertex constraints at t, below | states discovered, during the search)
@@ -235,37 +256,57 @@ WV_FN int32_t compactSearch(Lds lds, const CJob& J, CRes& R) {
       ldsStore128(lds, splat(oBits + i * 8u * kRowBytes) + (lane >> 3) * kRowBytes + (lane & 7u) * 16u, chunk);
   }
   sync();
-  for (uint32_t j0 = 0; j0 < J.nVc; j0 += 64u) {  // stateValid's vertex constraints (ecbs.cpp:499-502)
-    const B in = (lane + j0) < J.nVc;
-    const V v = gLoad32m(J.vc, lane + j0, in);
-    const V tt = v >> 16, yy = (v >> 8) & 0xFFu, xx = v & 0xFFu;
-    ldsOr32m(lds, splat(oBits) + tt * kRowBytes + yy * 4u, splat(1u) << xx, in & (tt < kRows) & (yy < 32u) & (xx < 32u));
+  {  // stateValid's vertex constraints (ecbs.cpp:499-502)
+    const uint32_t nVc = MRP_CT_JOB_U32(lds, nVc);
+    const uint32_t* vc = MRP_CT_JOB_PTR(const uint32_t, lds, vc);
+    for (uint32_t j0 = 0; j0 < nVc; j0 += 64u) {
+      const B in = (lane + j0) < nVc;
+      const V v = gLoad32m(vc, lane + j0, in);
+      const V tt = v >> 16, yy = (v >> 8) & 0xFFu, xx = v & 0xFFu;
+      ldsOr32m(lds, splat(oBits) + tt * kRowBytes + yy * 4u, splat(1u) << xx, in & (tt < kRows) & (yy < 32u) & (xx < 32u));
+    }
   }
-  // edge-constraint keys, one per lane (lists longer than a wave keep their tail in memory)
-  const V ecReg = sel(lane < J.nEc, gLoad32m(J.ec, lane, lane < J.nEc), splat(0xFFFFFFFFu));
+  // edge-constraint keys, one per lane.  They pass through the window (the walk queue's area, restored afterwards) so that
+  // the loop below holds no register a vector-memory load is still writing.
+  V ecReg = splat(0xFFFFFFFFu);
+  if (nEc) {
+    const uint32_t* ec = MRP_CT_JOB_PTR(const uint32_t, lds, ec);
+    ldsStore32(lds, splat(oAux + 16u) + lane * 4u, sel(lane < nEc, gLoad32m(ec, lane, lane < nEc), splat(0xFFFFFFFFu)));
+    sync();
+    ecReg = ldsLoad32(lds, splat(oAux + 16u) + lane * 4u);
+    sync();
+    const V4 none{splat(kEmpty), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
+    ldsStore128m(lds, splat(oAux + 16u) + lane * 16u, none, lane < 16u);
+  }
   // successor of this lane in the reference's order Wait, Left, Right, Up, Down (ecbs.cpp:365-398) on lanes 0..4; the other
   // lanes look at a cell far outside every map
   const V dx = sel(lane == 1u, splat(0xFFFFFFFFu), sel(lane == 2u, splat(1u), sel(lane < 5u, splat(0u), splat(0x4000u))));
   const V dy = sel(lane == 3u, splat(1u), sel(lane == 4u, splat(0xFFFFFFFFu), splat(0u)));
   // focal context: this lane's agents (columns of the path table)
-  const B in0 = lane < J.nAgentsPad, in1 = (lane + 64u) < J.nAgentsPad;
-  const V col0 = sel(in0, lane, splat(J.nAgentsPad ? J.nAgentsPad - 1u : 0u));
-  const V col1 = sel(in1, lane + 64u, splat(J.nAgentsPad ? J.nAgentsPad - 1u : 0u));
-  sync();
-
-  const uint32_t goalCell = J.gx | (J.gy << 5);
-  const uint32_t h0 = (J.sx > J.gx ? J.sx - J.gx : J.gx - J.sx) + (J.sy > J.gy ? J.sy - J.gy : J.gy - J.sy);
-  uint32_t nOpen = 1, nFocal = EPS ? 1u : 0u, nodes = 1, expansions = 0;
-  int32_t bestF = (int32_t)h0;
+  const B in0 = lane < nAgentsPad, in1 = (lane + 64u) < nAgentsPad;
+  const V col0 = sel(in0, lane, splat(nAgentsPad ? nAgentsPad - 1u : 0u));
+  const V col1 = sel(in1, lane + 64u, splat(nAgentsPad ? nAgentsPad - 1u : 0u));
+  const uint32_t tPad = EPS ? MRP_CT_JOB_U32(lds, tPad) : 0u;
+  const uint16_t* pathsG = PLDS ? nullptr : MRP_CT_JOB_PTR(const uint16_t, lds, pathsG);
+  const int32_t lastGoal = (int32_t)MRP_CT_JOB_U32(lds, lastGoal);
+  const float wBound = uintAsFloat(MRP_CT_JOB_U32(lds, w));
+  const uint32_t maxExp = MRP_CT_JOB_U32(lds, maxExp), openCap = MRP_CT_JOB_U32(lds, openCap), maxT = MRP_CT_JOB_U32(lds, maxT);
+  uint8_t* parentTab = MRP_CT_JOB_PTR(uint8_t, lds, parentTab);
+  const uint32_t goalCell = gx | (gy << 5);
+  int32_t bestF;
   {
-    const uint32_t e0 = (511u << 23) | ((127u - h0) << 16) | (0u << 10) | (J.sx | (J.sy << 5));
+    const uint32_t sx = MRP_CT_JOB_U32(lds, sx), sy = MRP_CT_JOB_U32(lds, sy);
+    const uint32_t h0 = (sx > gx ? sx - gx : gx - sx) + (sy > gy ? sy - gy : gy - sy);
+    bestF = (int32_t)h0;
+    const uint32_t e0 = (511u << 23) | ((127u - h0) << 16) | (0u << 10) | (sx | (sy << 5));
     ldsStoreS(lds, oOpen + 4u, e0);
     if (EPS) ldsStoreS(lds, oFocal + 4u, e0);
   }
+  sync();
 
   for (;;) {
     if (nOpen == 0u) {
-      R.status = C_NO_SOLUTION;
+      status = C_NO_SOLUTION;
       break;
     }
     const V tops = ldsLoad32(lds, hb);                   // lanes 0..31: open.top(), lanes 32..63: focal.top()
@@ -279,31 +320,32 @@ WV_FN int32_t compactSearch(Lds lds, const CJob& J, CRes& R) {
         // ---- a_star_epsilon.hpp:134-154: bestFScore grew -> every open node with old * w < f <= new * w joins the focal
         // list, in the order of open.ordered_begin(): a best-first walk of the open array through a std::priority_queue
         // (libstdc++ push_heap / pop_heap restated: push = sift-up, pop = hole down to a leaf, then sift-up)
-        const float lo = fmulRn((float)oldBest, J.w), hi = fmulRn((float)fTop, J.w);  // binary32, no contraction
-        uint32_t npq = 0;
+        const float lo = fmulRn((float)oldBest, wBound), hi = fmulRn((float)fTop, wBound);  // binary32, no contraction
+        uint32_t npq = 0, npqHigh = 0;
         uint32_t curA = (topO & kMO) | 0u;               // walk-queue entry: open key | index in the open array
         for (;;) {
-          const uint32_t cur = curA & 0x3FFu;              // (ten bits below the key: up to 1023 entries)
+          const uint32_t cur = curA & 0x3FFu;            // (ten bits below the key: up to 1023 entries)
           const uint32_t firstC = 2u * cur + 1u;
           if (firstC < nOpen) {                          // discover the children (index order) before the node is tested
             if (npq + 2u > kAuxCap) {
-              R.cost = 4;
-              R.expanded = expansions;
-              return C_OVERFLOW;
+              status = C_OVERFLOW;
+              cost = 4;
+              break;
             }
             const V pr = ldsLoad32(lds, splat(oOpen + 4u + 4u * firstC) + (lane & 1u) * 4u);
             const uint32_t e1 = readlane(pr, 0), e2 = readlane(pr, 1);
-            dualSiftUp(lds, S, hbAux, kmAux, npq, 0u, true, false, splat((e1 & kMO) | firstC));
+            dualSiftUp(lds, S, hbAux, kmAux, splat(npq + 1u), (e1 & kMO) | firstC, false, false);
             npq += 1u;
             if (firstC + 1u < nOpen) {
-              dualSiftUp(lds, S, hbAux, kmAux, npq, 0u, true, false, splat((e2 & kMO) | (firstC + 1u)));
+              dualSiftUp(lds, S, hbAux, kmAux, splat(npq + 1u), (e2 & kMO) | (firstC + 1u), false, false);
               npq += 1u;
             }
+            npqHigh = npq > npqHigh ? npq : npqHigh;
           }
           const float fv = (float)(int32_t)(127u - ((curA >> 16) & 127u));
           if (fv > lo && fv <= hi) {
             const uint32_t e = ldsLoadS(lds, oOpen + 4u + 4u * cur);
-            dualSiftUp(lds, S, hb, km, 0u, nFocal, false, true, splat(e));
+            dualSiftUp(lds, S, hb, km, bothSides(S, 1u, nFocal + 1u), e, true, false);
             nFocal += 1u;
           }
           if (fv > hi) break;
@@ -311,43 +353,51 @@ WV_FN int32_t compactSearch(Lds lds, const CJob& J, CRes& R) {
           // std::priority_queue::pop
           curA = ldsLoadS(lds, oAux + 4u);
           npq -= 1u;
+          const uint32_t value = ldsLoadS(lds, oAux + 4u + 4u * npq);
+          ldsStoreS(lds, oAux + 4u + 4u * npq, kEmpty);  // (the vacated slot: "no element")
           if (npq > 0u) {
-            const uint32_t value = ldsLoadS(lds, oAux + 4u + 4u * npq);
-            uint32_t hole = 0, unused = 0;
-            dualDescend<true>(lds, S, hbAux, kmAux, npq, 0u, hole, unused, splat(0u));
-            dualSiftUp(lds, S, hbAux, kmAux, hole, 0u, true, false, splat(value));
+            const V hole = dualDescend<true>(lds, S, hbAux, kmAux, splat(kAuxClamp), splat(0u));
+            dualSiftUp(lds, S, hbAux, kmAux, hole + 1u, value, false, false);
           }
         }
+        // what the walk leaves in its queue is dropped: every slot "no element" again
+        for (uint32_t b = 0; b <= 4u * npqHigh; b += 1024u) {
+          const V4 none{splat(kEmpty), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
+          const V4 head{sel(lane == 0u, splat(kFront), splat(kEmpty)), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
+          ldsStore128m(lds, splat(oAux + b) + lane * 16u, b == 0u ? head : none, (lane * 16u + b) < kAuxBytes);
+        }
+        if (status == C_OVERFLOW) break;
         curE = ldsLoadS(lds, oFocal + 4u);
       }
     }
     // f, g (== time) and focalH of the popped node are in its entry
     const uint32_t cell = curE & 1023u, t = (curE >> 10) & 63u, curFh = 511u - (curE >> 23);
     const uint32_t x = cell & 31u, y = cell >> 5;
-    const bool isGoal = cell == goalCell && (int32_t)t > J.lastGoal;
+    const bool isGoal = cell == goalCell && (int32_t)t > lastGoal;
     if (!isGoal) {
-      // (R.cost names the limit and R.expanded how far the search got: statistics for the caller, not results)
-      if (nOpen + 5u > J.openCap || t > J.maxT || (EPS && curFh + 2u * J.nAgentsPad > 511u)) {
-        R.cost = nOpen + 5u > J.openCap ? 1 : t > J.maxT ? 2 : 3;
-        R.expanded = expansions;
-        return C_OVERFLOW;
+      // (cost names the limit and `expanded` how far the search got: statistics for the caller, not results)
+      if (nOpen + 5u > openCap || t > maxT || (EPS && curFh + 2u * nAgentsPad > 511u)) {
+        status = C_OVERFLOW;
+        cost = nOpen + 5u > openCap ? 1 : t > maxT ? 2 : 3;
+        break;
       }
     }
     expansions += 1u;  // onExpandNode (a_star_epsilon.hpp:193 / a_star.hpp:87) — counts the goal pop too
-    if (expansions > J.maxExp) {
-      R.status = C_CAP_EXP;
+    if (expansions > maxExp) {
+      status = C_CAP_EXP;
       break;
     }
     if (isGoal) {
       // ---- a_star_epsilon.hpp:195-213: follow cameFrom back to the start.  The action bytes of eight time steps (eight
       // 1 KB rows of the table) are fetched per round trip into the bitmap's LDS area, which the search no longer needs
-      R.status = C_OK;
-      R.cost = (int32_t)t;
-      R.fmin = (int32_t)(127u - (((EPS ? topO : curE) >> 16) & 127u));
-      R.nStates = (int32_t)t + 1;
+      status = C_OK;
+      cost = (int32_t)t;
+      fmin = (int32_t)(127u - (((EPS ? topO : curE) >> 16) & 127u));
+      nStates = (int32_t)t + 1;
+      uint16_t* outPath = MRP_CT_JOB_PTR(uint16_t, lds, outPath);
       sync();  // this wave's action stores have left the CU
       uint32_t c = cell;
-      const uint32_t* tab32 = (const uint32_t*)J.parentTab;
+      const uint32_t* tab32 = (const uint32_t*)parentTab;
       for (int32_t k0 = (int32_t)t; k0 >= 1; k0 -= 8) {
         V rowW[8][4];
         for (int32_t r = 0; r < 8; ++r)
@@ -358,14 +408,14 @@ WV_FN int32_t compactSearch(Lds lds, const CJob& J, CRes& R) {
         sync();
         for (int32_t r = 0; r < 8 && k0 - r >= 1; ++r) {
           const uint32_t k = (uint32_t)(k0 - r);
-          gStoreU16m(J.outPath, splat(k), splat((c & 31u) | ((c >> 5) << 8)), lane == 0u);
+          gStoreU16m(outPath, splat(k), splat((c & 31u) | ((c >> 5) << 8)), lane == 0u);
           const uint32_t a = first(ldsLoadU8(lds, splat(oBits + (uint32_t)r * 1024u + c)));
           // the parent's cell: undo Wait, Left, Right, Up, Down
           c = a == 1u ? c + 1u : a == 2u ? c - 1u : a == 3u ? c - 32u : a == 4u ? c + 32u : c;
         }
         sync();
       }
-      gStoreU16m(J.outPath, splat(0u), splat((c & 31u) | ((c >> 5) << 8)), lane == 0u);
+      gStoreU16m(outPath, splat(0u), splat((c & 31u) | ((c >> 5) << 8)), lane == 0u);
       break;
     }
 
@@ -373,39 +423,45 @@ WV_FN int32_t compactSearch(Lds lds, const CJob& J, CRes& R) {
     // the five successor probes: bounds, then ONE bit of the (time, cell) bitmap = obstacle | vertex constraint | already
     // discovered; requested before the pops so that the latency hides behind them
     const V nx = splat(x) + dx, ny = splat(y) + dy;
-    const B inb = (nx < J.dimx) & (ny < J.dimy);
+    const B inb = (nx < dimx) & (ny < dimy);
     const V ncell = (nx & 31u) | ((ny & 31u) << 5);
     const V wordAddr = splat(oBits + t1 * kRowBytes) + ((ny & 31u) << 2);
     const V word = ldsLoad32(lds, wordAddr);
     // other agents' positions at t (a) and t + 1 (b), one agent per lane
     V a0 = splat(0xFFFFu), b0 = splat(0xFFFFu), a1 = splat(0xFFFFu), b1 = splat(0xFFFFu);
-    if (EPS && J.nAgentsPad) {
-      const uint32_t ra = t < J.tPad ? t : J.tPad - 1u;
-      const uint32_t rb = t1 < J.tPad ? t1 : J.tPad - 1u;
+    if (EPS && nAgentsPad) {
+      const uint32_t ra = t < tPad ? t : tPad - 1u;
+      const uint32_t rb = t1 < tPad ? t1 : tPad - 1u;
       // (lanes beyond a row's end look at the row's last agent instead, and are masked: every read stays inside the table)
-      if (J.pathsLds != kNoLds) {
-        a0 = sel(in0, ldsLoadU16(lds, splat(J.pathsLds + ra * J.nAgentsPad * 2u) + col0 * 2u), splat(0xFFFFu));
-        b0 = sel(in0, ldsLoadU16(lds, splat(J.pathsLds + rb * J.nAgentsPad * 2u) + col0 * 2u), splat(0xFFFFu));
-        if (J.nAgentsPad > 64u) {
-          a1 = sel(in1, ldsLoadU16(lds, splat(J.pathsLds + ra * J.nAgentsPad * 2u) + col1 * 2u), splat(0xFFFFu));
-          b1 = sel(in1, ldsLoadU16(lds, splat(J.pathsLds + rb * J.nAgentsPad * 2u) + col1 * 2u), splat(0xFFFFu));
+      if (PLDS) {
+        a0 = sel(in0, ldsLoadU16(lds, splat(oPaths + ra * nAgentsPad * 2u) + col0 * 2u), splat(0xFFFFu));
+        b0 = sel(in0, ldsLoadU16(lds, splat(oPaths + rb * nAgentsPad * 2u) + col0 * 2u), splat(0xFFFFu));
+        if (nAgentsPad > 64u) {
+          a1 = sel(in1, ldsLoadU16(lds, splat(oPaths + ra * nAgentsPad * 2u) + col1 * 2u), splat(0xFFFFu));
+          b1 = sel(in1, ldsLoadU16(lds, splat(oPaths + rb * nAgentsPad * 2u) + col1 * 2u), splat(0xFFFFu));
         }
       } else {
-        a0 = sel(in0, gLoadU16m(J.pathsG, splat(ra * J.nAgentsPad) + col0, in0), splat(0xFFFFu));
-        b0 = sel(in0, gLoadU16m(J.pathsG, splat(rb * J.nAgentsPad) + col0, in0), splat(0xFFFFu));
-        if (J.nAgentsPad > 64u) {
-          a1 = sel(in1, gLoadU16m(J.pathsG, splat(ra * J.nAgentsPad) + col1, in1), splat(0xFFFFu));
-          b1 = sel(in1, gLoadU16m(J.pathsG, splat(rb * J.nAgentsPad) + col1, in1), splat(0xFFFFu));
+        a0 = sel(in0, gLoadU16m(pathsG, splat(ra * nAgentsPad) + col0, in0), splat(0xFFFFu));
+        b0 = sel(in0, gLoadU16m(pathsG, splat(rb * nAgentsPad) + col0, in0), splat(0xFFFFu));
+        if (nAgentsPad > 64u) {
+          a1 = sel(in1, gLoadU16m(pathsG, splat(ra * nAgentsPad) + col1, in1), splat(0xFFFFu));
+          b1 = sel(in1, gLoadU16m(pathsG, splat(rb * nAgentsPad) + col1, in1), splat(0xFFFFu));
         }
       }
     }
 
     // ---- a_star_epsilon.hpp:215-216: focalSet.pop(), openSet.erase(handle of the same node)   (a_star.hpp:109: pop)
     {
+      const uint32_t nOld = nOpen;
+      nOpen -= 1u;
+      if (EPS) nFocal -= 1u;
+      // the elements that pop() moves to the roots: the last ones
+      const V lastAddr = hb + bothSides(S, nOpen, nFocal) * 4u;
+      const V lastV = ldsLoad32(lds, lastAddr);
       uint32_t p = 0;
       if (EPS) {  // where is the popped node in the open array?  Lane L looks at elements 4L - 1 .. 4L + 2 of a group.
         const V key = splat(curE & 0xFFFFu);
-        for (uint32_t g = 0; g < kGroups && g * 256u <= nOpen; ++g) {
+        for (uint32_t g = 0; g < kGroups && g * 256u < nOld; ++g) {
           const V4 grp = ldsLoad128(lds, splat(oOpen + g * 1024u) + lane * 16u);
           const B m0 = (grp.x & 0xFFFFu) == key, m1 = (grp.y & 0xFFFFu) == key, m2 = (grp.z & 0xFFFFu) == key,
                   m3 = (grp.w & 0xFFFFu) == key;
@@ -417,90 +473,89 @@ WV_FN int32_t compactSearch(Lds lds, const CJob& J, CRes& R) {
           }
         }
       }
-      const uint32_t nOld = nOpen;
-      nOpen -= 1u;
-      if (EPS) nFocal -= 1u;
-      // the elements that pop() moves to the roots: the last ones
-      const V lastV = ldsLoad32(lds, hb + sel(S.isB, splat(nFocal), splat(nOpen)) * 4u);
       uint32_t lastO = readlane(lastV, 0);
-      const uint32_t lastF = EPS ? readlane(lastV, 32) : 0u;
+      const uint32_t lastF = EPS ? readlane(lastV, 32) : kFront;  // (no focal list: a key nothing is better than)
+      ldsStore32m(lds, lastAddr, splat(kEmpty), S.l5 == 0u);  // the vacated slots: "no element"
       if (EPS) {  // boost erase = bubble to the root (every ancestor of p moves down one level), then pop
         const uint32_t depth = lg2(p + 1u);
         const B act = !S.isB & (S.l5 < depth);
         const V ancPos = (splat(p + 1u) >> (S.l5 + 1u)) - 1u;
-        const V ae = ldsLoad32m(lds, splat(oOpen + 4u) + ancPos * 4u, act);
+        const V ae = ldsLoad32(lds, splat(oOpen + 4u) + ancPos * 4u);
         ldsStore32m(lds, splat(oOpen + 4u) + ((splat(p + 1u) >> S.l5) - 1u) * 4u, ae, act);
-        // ... which has just overwritten the last element if the erased node WAS the last one: it is the node's parent then
-        if (p == nOld - 1u && depth != 0u) lastO = readlane(ae, 0);
+        // ... which has just overwritten the last element if the erased node WAS the last one: it is the node's parent
+        // then, and the slot it sat in is vacated after all
+        if (p == nOld - 1u && depth != 0u) {
+          lastO = readlane(ae, 0);
+          ldsStoreS(lds, oOpen + 4u + 4u * p, kEmpty);
+        }
       }
-      uint32_t idxO = 0, idxF = 0;
-      const V xk = sel(S.isB, splat(lastF & kMF), splat(lastO & kMO));
-      dualDescend<false>(lds, S, hb, km, nOpen, EPS ? nFocal : 0u, idxO, idxF, xk);
-      ldsStore32m(lds, hb + sel(S.isB, splat(idxF), splat(idxO)) * 4u, sel(S.isB, splat(lastF), splat(lastO)),
-                  (S.l5 == 0u) & (sel(S.isB, splat(EPS ? nFocal : 0u), splat(nOpen)) != 0u));
-      ldsStoreS(lds, oOpen + 4u + 4u * nOpen, kEmpty);   // the vacated slot must not show a stale copy to the scan
+      const V xk = bothSides(S, lastO & kMO, lastF & kMF);
+      const V hole = dualDescend<false>(lds, S, hb, km, splat(kHeapClamp), xk);
+      ldsStore32m(lds, hb + hole * 4u, bothSides(S, lastO, lastF), (S.l5 == 0u) & (bothSides(S, nOpen, EPS ? nFocal : 0u) != 0u));
     }
 
     const B okV = inb & (((word >> (nx & 31u)) & 1u) == 0u);
     uint32_t mask = lo32(ballot(okV)) & 0x1Fu;
-    if (J.nEc) {  // transitionValid (ecbs.cpp:505-510): lane j holds edge-constraint key j = t << 19 | cell << 3 | action
-      const uint32_t base = (t << 19) | ((y * J.dimx + x) << 3);
+    if (nEc) {  // transitionValid (ecbs.cpp:505-510): lane j holds edge-constraint key j = t << 19 | cell << 3 | action
+      const uint32_t base = (t << 19) | ((y * dimx + x) << 3);
       const V d = ecReg - base;
       if (ballot(d < 5u)) {  // rare: some constraint names a move out of this very state
         uint32_t blocked = 0;
         for (uint32_t k = 0; k < 5u; ++k) blocked |= ballot(d == k) ? (1u << k) : 0u;
         mask &= ~blocked;
       }
-      for (uint32_t j = 64u; j < J.nEc; ++j) {  // lists longer than a wave: the rest one by one
-        const uint32_t dd = first(gLoad32m(J.ec, splat(j), bsplat(true))) - base;
-        if (dd < 5u) mask &= ~(1u << dd);
-      }
     }
     if (mask == 0u) continue;
 
     // ---- the successors' entries, one per lane 0..4
     const B mine = (lane < 5u) & (((splat(mask) >> lane) & 1u) != 0u);
-    const V f = sad(nx, splat(J.gx), sad(ny, splat(J.gy), splat(t1)));  // g + admissibleHeuristic (ecbs.cpp:276-279)
+    const V f = sad(nx, splat(gx), sad(ny, splat(gy), splat(t1)));  // g + admissibleHeuristic (ecbs.cpp:276-279)
     V fhV = splat(curFh);
-    if (EPS && J.nAgentsPad) {
+    if (EPS && nAgentsPad) {
       // focalStateHeuristic (ecbs.cpp:282-295) + focalTransitionHeuristic (ecbs.cpp:298-312): an agent counts once if it
       // stands on the successor's cell at t + 1 and once more if it swaps places with this agent
       const V nxy = nx | (ny << 8);
       const uint32_t curXy = x | (y << 8);
       const uint64_t swap0 = ballot(b0 == curXy);
-      const uint64_t swap1 = J.nAgentsPad > 64u ? ballot(b1 == curXy) : 0ull;
+      const uint64_t swap1 = nAgentsPad > 64u ? ballot(b1 == curXy) : 0ull;
       for (uint32_t mm = mask; mm; mm &= mm - 1u) {
         const uint32_t k = ctz32(mm);
         const uint32_t cc = readlane(nxy, k);
         uint32_t cnt = popc64(ballot(b0 == cc)) + popc64(ballot(a0 == cc) & swap0);
-        if (J.nAgentsPad > 64u) cnt += popc64(ballot(b1 == cc)) + popc64(ballot(a1 == cc) & swap1);
+        if (nAgentsPad > 64u) cnt += popc64(ballot(b1 == cc)) + popc64(ballot(a1 == cc) & swap1);
         fhV = writelane(fhV, curFh + cnt, k);
       }
     }
     const V eV = ((splat(511u) - fhV) << 23) | ((splat(127u) - f) << 16) | (t1 << 10) | ncell;
     uint32_t maskF = 0;
     if (EPS) {
-      const float bound = fmulRn((float)bestF, J.w);  // a_star_epsilon.hpp:240, binary32
+      const float bound = fmulRn((float)bestF, wBound);  // a_star_epsilon.hpp:240, binary32
       maskF = lo32(ballot(mine & leF32(cvtF32(f), bound)));
     }
     // discovered: stands for stateToHeap / closedSet membership (a_star_epsilon.hpp:224-227)
     ldsOr32m(lds, wordAddr, splat(1u) << (nx & 31u), mine);
     // cameFrom (a_star_epsilon.hpp:275-279): the action that led here
-    gStore8m(J.parentTab, splat(t1 << 10) + ncell, lane, mine);
+    gStore8m(parentTab, splat(t1 << 10) + ncell, lane, mine);
     nodes += (uint32_t)__builtin_popcount(mask);
     // ---- openSet.push for every successor, focalSet.push for those within the bound, in successor order
     for (uint32_t mm = mask; mm; mm &= mm - 1u) {
       const uint32_t k = ctz32(mm);
       const uint32_t e = readlane(eV, k);
       const bool inF = EPS && ((maskF >> k) & 1u);
-      dualSiftUp(lds, S, hb, km, nOpen, nFocal, true, inF, splat(e));
+      dualSiftUp(lds, S, hb, km, bothSides(S, nOpen + 1u, inF ? nFocal + 1u : 1u), e, false, !inF);
       nOpen += 1u;
       nFocal += inF ? 1u : 0u;
     }
   }
-  R.expanded = expansions;
-  R.nodes = nodes;
-  return R.status;
+  // the result block of the window
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, status), (uint32_t)status);
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, cost), (uint32_t)cost);
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, fmin), (uint32_t)fmin);
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, nStates), (uint32_t)nStates);
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, expanded), expansions);
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, nodes), nodes);
+  sync();
+  return status;
 }
 
 }  // namespace ct

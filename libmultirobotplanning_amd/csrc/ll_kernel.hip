@@ -1153,13 +1153,13 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   // LDS (the compact tier's area, free once a search has left it)
   Mem<TierHyb> gh;
   {
-    const uint32_t area = ldsBytes(0);
+    const uint32_t area = ct::kLdsBytes - ct::oOpen;  // (the window's control blocks in front of it stay as they are)
     uint32_t per = (area / 3u) & ~15u;  // bytes per heap, 16-byte aligned starts
     uint32_t nTop = per >= 32u ? ((per - 8u) / 8u) : 0u;
     if (nTop > 4095u) nTop = 4095u;
     nTop = nTop ? ((nTop - 1u) | 1u) : 0u;  // odd (or 0: no LDS tier configured)
     if (P.lds_nodes == 0) nTop = 0;
-    auto l8 = (__attribute__((address_space(3))) uint8_t*)smem;
+    auto l8 = (__attribute__((address_space(3))) uint8_t*)smem + ct::oOpen;
     gh.nodes = g.nodes;
     gh.pos = nullptr;
     gh.gOf = nullptr;
@@ -1178,31 +1178,45 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   // ---- compact tier (ll_compact.h): the whole search in LDS, a state = its 32-bit heap entry.  Maps up to 32 x 32 and
   // up to 128 agents in the focal context; a search that outgrows the tier (open list, time steps, focalH field) comes
   // back as C_OVERFLOW with nothing of it observable, and is run again from the start by the arena tier below.
-  const bool compactOk = P.lds_nodes != 0 && c.dimx <= 32u && c.dimy <= 32u && c.nAgentsPad <= 128u &&
+  const bool compactOk = P.lds_nodes != 0 && c.dimx <= 32u && c.dimy <= 32u && c.nAgentsPad <= 128u && c.nEc <= 64u &&
                          (uint64_t)P.arena_nodes * 16u >= ct::kParentBytes;
   bool done = false;
   if (compactOk) {
+    // the job goes into its block of the LDS window (every lane stores the same words), the result comes back from there:
+    // ct::compactSearch is a real function with its own register allocation
     ct::CJob cj;
     cj.dimx = c.dimx; cj.dimy = c.dimy; cj.sx = c.sx; cj.sy = c.sy; cj.gx = c.gx; cj.gy = c.gy;
     cj.lastGoal = c.lastGoal;
     cj.w = c.w;
     cj.nVc = c.nVc; cj.nEc = c.nEc;
-    cj.vc = c.vc; cj.ec = c.ec;
-    cj.obst = c.obst; cj.obstWords = c.wpr;
+    cj.obstWords = c.wpr;
     cj.nAgentsPad = EPS ? c.nAgentsPad : 0u; cj.tPad = c.tPad;
-    cj.pathsLds = c.pathsLds ? ct::oPaths : ct::kNoLds;
-    cj.pathsG = c.paths;
     cj.maxExp = c.maxExp < 0 ? 0xFFFFFFFFu : (c.maxExp > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)c.maxExp);
     // mrp_ll_configure_tiers: lds_nodes / 2 = open-list entries, lds_rows = time steps a search may use inside the tier
     cj.openCap = P.lds_nodes / 2u < ct::kCap ? P.lds_nodes / 2u : ct::kCap;
     cj.maxT = P.lds_rows >= 3u && P.lds_rows - 2u < ct::kMaxT ? P.lds_rows - 2u : ct::kMaxT;
-    cj.parentTab = arenaSlot;  // the arena's node area: unused while the search is in this tier
-    cj.outPath = outPath;
-    ct::CRes cr;
+    cj.vc = (uint64_t)c.vc; cj.ec = (uint64_t)c.ec;
+    cj.obst = (uint64_t)c.obst;
+    cj.pathsG = (uint64_t)c.paths;
+    cj.parentTab = (uint64_t)arenaSlot;  // the arena's node area: unused while the search is in this tier
+    cj.outPath = (uint64_t)outPath;
+    {
+      auto w32 = (__attribute__((address_space(3))) uint32_t*)((wv::Lds)smem + ct::oJob);
+      const uint32_t* src = (const uint32_t*)&cj;
+#pragma unroll
+      for (uint32_t q = 0; q < sizeof(ct::CJob) / 4; ++q) w32[q] = src[q];
+    }
+    const bool tableInLds = !EPS || c.nAgentsPad == 0u || c.pathsLds != nullptr;
 #ifndef MRP_LL_TRACE  // (the trace build uses prof[] for its phase counters)
     const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int32_t crc = ct::compactSearch<EPS>((wv::Lds)smem, cj, cr);
+    const int32_t crc = tableInLds ? ct::compactSearch<EPS, true>((wv::Lds)smem) : ct::compactSearch<EPS, false>((wv::Lds)smem);
+    ct::CRes cr;
+    {
+      auto r32 = (__attribute__((address_space(3))) const uint32_t*)((wv::Lds)smem + ct::oRes);
+      cr.status = (int32_t)rfl(r32[0]); cr.cost = (int32_t)rfl(r32[1]); cr.fmin = (int32_t)rfl(r32[2]);
+      cr.nStates = (int32_t)rfl(r32[3]); cr.expanded = rfl(r32[4]); cr.nodes = rfl(r32[5]);
+    }
 #ifndef MRP_LL_TRACE
     res.prof[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);  // 100 MHz ticks / expansions in the compact tier
     res.prof[1] = cr.expanded;                                         // (of a search that was handed over: until then)
@@ -2157,27 +2171,15 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
 }
 
 // Batch mode.  One workgroup == one wavefront; pulls jobs from the batch's queue (exit: queue exhausted).
-// The launch parameters (45 dwords) stay in SGPRs.  -DMRP_LL_PARAMS_IN_LDS keeps them in LDS instead: they are needed
-// only at the start and at the end of a job, and with them out of the way the ECBS resident kernel has 100 SGPR spill
-// slots instead of 229 — but it then keeps wave-uniform values in VGPRs (135 instead of 113) and was 5-6 % SLOWER in an
-// A/B on one box (busy workgroup time 787 s vs 736 s per 65 536 agents10 instances; scripts/r2m.sh): a spilled SGPR is
-// one v_readlane when it is needed, a uniform held in a VGPR costs a v_readfirstlane or a VALU compare at every use.
-#ifndef MRP_LL_PARAMS_IN_LDS
 #define MRP_LL_STAGE_PARAMS(P, Parg) const LaunchParams& P = Parg
-#else
-#define MRP_LL_STAGE_PARAMS(P, Parg) \
-  __shared__ LaunchParams P;         \
-  stageParams(P, Parg)
-#endif
-// One coalesced copy of the kernel arguments into LDS (read back with ds_read where they are needed).
-DEVI void stageParams(LaunchParams& dst, const LaunchParams& src) {
-  const uint32_t lane = threadIdx.x;
-  constexpr uint32_t n = sizeof(LaunchParams) / 4;
-  static_assert(sizeof(LaunchParams) % 4 == 0 && n <= 64, "LaunchParams is staged by one wavefront instruction");
-  if (lane < n) ((uint32_t*)&dst)[lane] = ((const uint32_t*)&src)[lane];
-  __syncthreads();
-}
-
+// The CBS / ECBS kernels declare NO static LDS: their dynamic window then starts at LDS address 0, which is what makes
+// every address inside ll_compact.h's window a constant of the ds_ instructions (wave_dev.h windowBase).  The job
+// descriptor and the result record they stage through LDS live in the window's control block instead.
+static_assert(sizeof(DevJob) + sizeof(DevResult) <= ct::oJob, "control block of the window");
+#define MRP_LL_WINDOW_BLOCKS(smem, jobS, resS)                                                        \
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem != 0u) __builtin_trap(); \
+  DevJob& jobS = *(DevJob*)(smem + ct::oCtl);                                                         \
+  DevResult& resS = *(DevResult*)(smem + ct::oCtl + sizeof(DevJob))
 template <int KIND>
 DEVI void batchLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevResult& resS) {
   const uint32_t lane = threadIdx.x;
@@ -2198,23 +2200,20 @@ DEVI void batchLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevResul
 
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_search_kernel(LaunchParams Parg) {  // mixed batches
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ DevJob jobS;
-  __shared__ DevResult resS;
-  MRP_LL_STAGE_PARAMS(P, Parg);
+  MRP_LL_WINDOW_BLOCKS(smem, jobS, resS);
+  const LaunchParams& P = Parg;
   batchLoop<0>(P, smem, jobS, resS);
 }
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_search_kernel(LaunchParams Parg) {  // A*-epsilon jobs only
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ DevJob jobS;
-  __shared__ DevResult resS;
-  MRP_LL_STAGE_PARAMS(P, Parg);
+  MRP_LL_WINDOW_BLOCKS(smem, jobS, resS);
+  const LaunchParams& P = Parg;
   batchLoop<1>(P, smem, jobS, resS);
 }
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_search_kernel(LaunchParams Parg) {  // A* jobs only
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ DevJob jobS;
-  __shared__ DevResult resS;
-  MRP_LL_STAGE_PARAMS(P, Parg);
+  MRP_LL_WINDOW_BLOCKS(smem, jobS, resS);
+  const LaunchParams& P = Parg;
   batchLoop<2>(P, smem, jobS, resS);
 }
 
@@ -2382,23 +2381,20 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
 
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_persistent_kernel(LaunchParams Parg) {  // mixed sessions
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ DevJob jobS;
-  __shared__ DevResult resS;
-  MRP_LL_STAGE_PARAMS(P, Parg);
+  MRP_LL_WINDOW_BLOCKS(smem, jobS, resS);
+  const LaunchParams& P = Parg;
   residentLoop<false, 0>(P, smem, jobS, resS);
 }
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_persistent_kernel(LaunchParams Parg) {  // A*-epsilon only
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ DevJob jobS;
-  __shared__ DevResult resS;
-  MRP_LL_STAGE_PARAMS(P, Parg);
+  MRP_LL_WINDOW_BLOCKS(smem, jobS, resS);
+  const LaunchParams& P = Parg;
   residentLoop<false, 1>(P, smem, jobS, resS);
 }
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_persistent_kernel(LaunchParams Parg) {  // A* only
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ DevJob jobS;
-  __shared__ DevResult resS;
-  MRP_LL_STAGE_PARAMS(P, Parg);
+  MRP_LL_WINDOW_BLOCKS(smem, jobS, resS);
+  const LaunchParams& P = Parg;
   residentLoop<false, 2>(P, smem, jobS, resS);
 }
 

@@ -13,6 +13,7 @@
 namespace wv {
 
 #define WV_FN __device__ __forceinline__
+#define WV_ENTRY __device__ __attribute__((noinline))  // a real function: its own register allocation
 
 typedef uint32_t V;   // one 32-bit value per lane
 typedef bool B;       // one predicate per lane
@@ -23,6 +24,9 @@ struct V4 { V x, y, z, w; };
 
 typedef __attribute__((address_space(3))) uint8_t* Lds;  // the workgroup's LDS window, byte addressed
 
+// The window starts at LDS address 0: the kernels that host the tier declare no static LDS (ll_kernel.hip checks it), so
+// every address inside the window is a compile-time constant of the ds_ instructions.
+WV_FN Lds windowBase(Lds) { return (Lds)(uintptr_t)0; }
 WV_FN V laneId() { return threadIdx.x; }
 WV_FN V splat(uint32_t s) { return s; }
 WV_FN V sel(B c, V a, V b) { return c ? a : b; }
@@ -35,6 +39,8 @@ extern "C" __device__ int mrp_llvm_writelane(int val, int lane, int old) __asm("
 WV_FN V writelane(V v, uint32_t val, uint32_t lane) { return (uint32_t)mrp_llvm_writelane((int)val, (int)lane, (int)v); }
 WV_FN V shr1(V v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }
 WV_FN V clz(V v) { return (uint32_t)__builtin_clz(v); }          // v != 0
+WV_FN V popc(V v) { return (uint32_t)__builtin_popcount(v); }
+WV_FN float uintAsFloat(uint32_t v) { return __uint_as_float(v); }
 WV_FN V sad(V a, V b, V c) { return ((a > b ? a : b) - (a > b ? b : a)) + c; }  // |a - b| + c  (v_sad_u32)
 WV_FN float fmulRn(float a, float b) { return __fmul_rn(a, b); }  // binary32 product, no contraction
 WV_FN V cvtF32(V v) { return __float_as_uint((float)v); }        // (float)v as bits
@@ -53,6 +59,10 @@ WV_FN V2 ldsLoad64m(Lds l, V addr, B m) {
     r.y = t.y;
   }
   return r;
+}
+WV_FN V2 ldsLoad64(Lds l, V addr) {
+  const v2u t = *(__attribute__((address_space(3))) v2u*)(l + addr);
+  return V2{t.x, t.y};
 }
 WV_FN V4 ldsLoad128(Lds l, V addr) {
   const v4u t = *(__attribute__((address_space(3))) v4u*)(l + addr);
@@ -82,23 +92,21 @@ WV_FN void ldsOr32m(Lds l, V addr, V bits, B m) {
 WV_FN uint32_t ldsLoadS(Lds l, uint32_t addr) { return first(*(__attribute__((address_space(3))) uint32_t*)(l + addr)); }
 WV_FN void ldsStoreS(Lds l, uint32_t addr, uint32_t val) { *(__attribute__((address_space(3))) uint32_t*)(l + addr) = val; }
 
-// ---- global memory ----
+// ---- global memory (the pointers name device or host-mapped memory, never LDS: global_ instructions, which count in
+// vmcnt only — a flat_ access would also hold up every wait for an LDS read) ----
+#define WV_G(T, p) ((__attribute__((address_space(1))) T*)(p))
 WV_FN void gStore8m(uint8_t* base, V off, V val, B m) {
-  if (m) base[off] = (uint8_t)val;
+  if (m) WV_G(uint8_t, base)[off] = (uint8_t)val;
 }
-WV_FN V gLoadU16m(const uint16_t* base, V idx, B m) { return m ? (uint32_t)base[idx] : 0u; }
-WV_FN V gLoad32m(const uint32_t* base, V idx, B m) { return m ? base[idx] : 0u; }
-WV_FN V4 gLoad128(const uint8_t* base, V byteOff) {
-  const v4u t = *(const v4u*)(base + byteOff);
-  return V4{t.x, t.y, t.z, t.w};
-}
+WV_FN V gLoadU16m(const uint16_t* base, V idx, B m) { return m ? (uint32_t)WV_G(const uint16_t, base)[idx] : 0u; }
+WV_FN V gLoad32m(const uint32_t* base, V idx, B m) { return m ? WV_G(const uint32_t, base)[idx] : 0u; }
 // a load that must see what other lanes of this wave (or other workgroups, earlier) stored: an agent-scope load goes
 // past this CU's L1 to the coherent level
 WV_FN V gLoad32Coherent(const uint32_t* base, V idx) {
-  return __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(WV_G(const uint32_t, base) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 WV_FN void gStoreU16m(uint16_t* base, V idx, V val, B m) {
-  if (m) base[idx] = (uint16_t)val;
+  if (m) WV_G(uint16_t, base)[idx] = (uint16_t)val;
 }
 WV_FN void sync() { __syncthreads(); }
 

@@ -98,22 +98,28 @@ int emu_compact_search(int eps, int dimx, int dimy, int n_obst, const int32_t* o
   std::vector<uint16_t> outPath(1024, 0);
   table.resize(table.size() + 256, 0xFFFFu);  // (lanes beyond a row's end are masked, but keep reads in bounds)
   CJob J;
+  std::memset(&J, 0, sizeof(J));
   J.dimx = dimx; J.dimy = dimy; J.sx = sx; J.sy = sy; J.gx = gx; J.gy = gy;
   J.lastGoal = lastGoal;
   J.w = w;
   J.nVc = (uint32_t)vcw.size() - 1; J.nEc = (uint32_t)ecw.size() - 1;
-  J.vc = vcw.data(); J.ec = ecw.data();
-  J.obst = obst.data(); J.obstWords = (uint32_t)obst.size();
+  J.vc = (uint64_t)(uintptr_t)vcw.data(); J.ec = (uint64_t)(uintptr_t)ecw.data();
+  J.obst = (uint64_t)(uintptr_t)obst.data(); J.obstWords = (uint32_t)obst.size();
   J.nAgentsPad = npad; J.tPad = tpad;
-  J.pathsLds = tableInLds ? oPaths : kNoLds;
-  J.pathsG = table.data();
+  J.pathsG = (uint64_t)(uintptr_t)table.data();
   J.maxExp = max_exp < 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(max_exp, 0xFFFFFFFEll);
   J.openCap = open_cap > 0 ? std::min<uint32_t>((uint32_t)open_cap, kCap) : kCap;
   J.maxT = max_t > 0 ? std::min<uint32_t>((uint32_t)max_t, kMaxT) : kMaxT;
-  J.parentTab = parentTab.data();
-  J.outPath = outPath.data();
+  J.parentTab = (uint64_t)(uintptr_t)parentTab.data();
+  J.outPath = (uint64_t)(uintptr_t)outPath.data();
+  if (J.nEc > 64) return -2;  // (the kernel starts such a job in the arena tier)
+  std::memcpy(ldsMem.data() + oJob, &J, sizeof(J));
+  const int32_t rc = !eps         ? compactSearch<false, true>(&win)
+                     : tableInLds ? compactSearch<true, true>(&win)
+                                  : compactSearch<true, false>(&win);
   CRes R;
-  const int32_t rc = eps ? compactSearch<true>(&win, J, R) : compactSearch<false>(&win, J, R);
+  std::memcpy(&R, ldsMem.data() + oRes, sizeof(R));
+  if (rc != R.status) return -3;
   out[0] = rc;
   out[1] = R.cost; out[2] = R.fmin; out[3] = R.nStates; out[4] = R.expanded; out[5] = R.nodes;
   out[6] = (int64_t)win.oobReads;

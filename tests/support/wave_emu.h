@@ -18,6 +18,7 @@
 namespace wv {
 
 #define WV_FN inline
+#define WV_ENTRY inline
 
 constexpr int kLanes = 64;
 
@@ -89,6 +90,7 @@ struct LdsWindow {
 };
 typedef LdsWindow* Lds;
 
+WV_FN Lds windowBase(Lds w) { return w; }
 WV_FN V laneId() {
   V r;
   for (int i = 0; i < kLanes; ++i) r.l[i] = (uint32_t)i;
@@ -119,6 +121,16 @@ WV_FN V clz(const V& v) {
   V r;
   for (int i = 0; i < kLanes; ++i) r.l[i] = v.l[i] ? (uint32_t)__builtin_clz(v.l[i]) : 32u;
   return r;
+}
+WV_FN V popc(const V& v) {
+  V r;
+  for (int i = 0; i < kLanes; ++i) r.l[i] = (uint32_t)__builtin_popcount(v.l[i]);
+  return r;
+}
+WV_FN float uintAsFloat(uint32_t v) {
+  float f;
+  memcpy(&f, &v, 4);
+  return f;
 }
 WV_FN V sad(const V& a, const V& b, const V& c) {
   V r;
@@ -200,6 +212,7 @@ WV_FN V2 ldsLoad64m(Lds l, const V& addr, const B& m) {
   }
   return r;
 }
+WV_FN V2 ldsLoad64(Lds l, const V& addr) { return ldsLoad64m(l, addr, B{~0ull}); }
 WV_FN V4 ldsLoad128(Lds l, const V& addr) {
   V4 r;
   for (int i = 0; i < kLanes; ++i) {

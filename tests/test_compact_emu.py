@@ -52,6 +52,8 @@ def emu_search(L, eps, inst, agent, start, goal, vc, ec, ctx_paths, w, max_exp=-
     rc = L.emu_compact_search(1 if eps else 0, inst["dimx"], inst["dimy"], len(obst), obst_p, start[0], start[1], goal[0],
                               goal[1], w, len(vca), vc_p, len(eca), ec_p, len(plen), agent, plen_p, pxy_p, max_exp,
                               lds_path_bytes, open_cap, max_t, out.ctypes.data_as(I64P), states.ctypes.data_as(I32P), 1024)
+    if rc == -2:  # not a job of the compact tier (more than 64 edge constraints, more than 128 agents)
+        return dict(status=-1, cost=0, expanded=0, oob_reads=0, oob_writes=0)
     assert rc == 0, rc
     return dict(status=int(out[0]), cost=int(out[1]), fmin=int(out[2]), n_states=int(out[3]), expanded=int(out[4]),
                 nodes=int(out[5]), oob_reads=int(out[6]), oob_writes=int(out[7]), states=states[:int(out[3])].tolist())
