@@ -2427,8 +2427,9 @@ static hipError_t allowFullLds(const void* fn, int which) {
 
 // ---- host-callable launcher (used by mrp_ll_host.cpp) -----------------------------------------------------------
 extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes) {
-  (void)capNodes; (void)rows; (void)rowWords;
-  return mrp::ldsBytes(pathBytes);
+  (void)rows; (void)rowWords;
+  // without the compact tier a workgroup still stages its job descriptor and result through the window's control block
+  return capNodes ? mrp::ldsBytes(pathBytes) : mrp::ct::oJob;
 }
 
 // kind: 0 = mixed, 1 = A*-epsilon jobs only, 2 = A* jobs only (see processJob)

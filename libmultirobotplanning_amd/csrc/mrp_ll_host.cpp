@@ -824,9 +824,9 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
     if (ldsBytes > 160u * 1024u - 512u) {
       ldsNodes = 0;
       rows = 0;
-      ldsBytes = 0;
     }
   }
+  if (!ldsNodes) ldsBytes = mrp_ll_lds_bytes(0, 0, 0, 0);  // the control block alone
   P.path_store = ctx->pathStore;
   P.path_store_stride = ctx->pathStoreStride;
   P.path_store_slots = ctx->pathStore ? ctx->pathStoreSlots : 0;
@@ -1243,7 +1243,7 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
     HIPCHK(ctx, mrp_ll_launch_persistent(&P, g.grid, ldsBytes, kind, t.stream));
   g.kind = sipp ? 0 : kind;
   g.grid2 = 0;
-  if (!sipp && ldsBytes != 0) {
+  if (!sipp && P.lds_nodes != 0) {
     uint32_t extra = ctx->extraHbmWgs;
     if (const char* e = std::getenv("MRP_LL_EXTRA_HBM_WGS")) extra = static_cast<uint32_t>(std::max(0, std::atoi(e)));
     extra = std::min<uint32_t>(extra, static_cast<uint32_t>(ctx->opt.slots) - g.grid);
@@ -1259,7 +1259,7 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
       P2.arena = t.arena + static_cast<uint64_t>(g.grid) * ctx->arenaStride;  // arena slots behind the first launch's
       // the counters the workgroups take tickets from are zeroed on t.stream: order this launch behind that
       HIPCHK(ctx, hipStreamWaitEvent(g.stream2, g.ev0, 0));
-      HIPCHK(ctx, mrp_ll_launch_persistent(&P2, extra, 0, kind, g.stream2));
+      HIPCHK(ctx, mrp_ll_launch_persistent(&P2, extra, mrp_ll_lds_bytes(0, 0, 0, 0), kind, g.stream2));
       HIPCHK(ctx, hipEventRecord(g.ev2, g.stream2));
       g.grid2 = extra;
       ctx->stats.launches += 1;
