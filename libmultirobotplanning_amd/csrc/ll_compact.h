@@ -461,7 +461,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       uint32_t p = 0;
       if (EPS) {  // where is the popped node in the open array?  Lane L looks at elements 4L - 1 .. 4L + 2 of a group.
         const V key = splat(curE & 0xFFFFu);
-        for (uint32_t g = 0; g < kGroups && g * 256u < nOld; ++g) {
+        for (uint32_t g = 0; g < kGroups && g * 256u <= nOld; ++g) {  // (element 256 g - 1 belongs to group g)
           const V4 grp = ldsLoad128(lds, splat(oOpen + g * 1024u) + lane * 16u);
           const B m0 = (grp.x & 0xFFFFu) == key, m1 = (grp.y & 0xFFFFu) == key, m2 = (grp.z & 0xFFFFu) == key,
                   m3 = (grp.w & 0xFFFFu) == key;
