@@ -19,7 +19,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-f
 
 TARGETS = {
     "libmrp_ll.so": dict(srcs=["ll_kernel.hip", "conflict_kernel.hip", "mrp_ll_host.cpp"],
-                         deps=["ll_device.h", "../../include/mrp_ll.h"],
+                         deps=["ll_device.h", "ll_compact.h", "wave_dev.h", "../../include/mrp_ll.h"],
                          extra=[]),
     "libmrp_hl.so": dict(srcs=["hl/mrp_hl.cpp"], deps=["hl/exact_heap.hpp", "hl/grid_mapf.hpp", "hl/ct_solver.hpp",
                                                        "hl/instance_io.hpp", "../../include/mrp_ll.h",
