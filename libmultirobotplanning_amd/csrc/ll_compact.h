@@ -199,6 +199,63 @@ WV_FN void dualSiftUp(Lds lds, const Sides& S, V hb, V km, V p1, uint32_t e, boo
   ldsStore32m(lds, hb + dest * 4u, sel((S.l5 + 1u) == stop1, splat(e), ae), S.l5 < stop1);
 }
 
+// Per-lane constants of the four-chains-in-one-wave step: the wave as four rows of 16 lanes.  A sift-up chain of these
+// heaps has at most nine ancestors, so a row holds one chain: lane l4 of a row owns ancestor l4.
+struct Rows {
+  V l4;
+  B isY, isSecond;   // rows 2, 3 / rows 1, 3
+};
+WV_FN Rows makeRows() {
+  Rows r;
+  const V lane = laneId();
+  r.l4 = lane & 15u;
+  r.isY = (lane >> 5) != 0u;
+  r.isSecond = ((lane >> 4) & 1u) != 0u;
+  return r;
+}
+WV_FN V perRow(const Rows& R, uint32_t x1, uint32_t x2, uint32_t y1, uint32_t y2) {  // rows 0, 1, 2, 3
+  return sel(R.isY, sel(R.isSecond, splat(y2), splat(y1)), sel(R.isSecond, splat(x2), splat(x1)));
+}
+
+// Up to two consecutive pushes into heap X (elements eX1, eX2 at positions pX, pX + 1: rows 0, 1) and up to two into heap
+// Y (rows 2, 3) — each a sift-up as in dualSiftUp — with ONE load and one or two stores.  All chains are loaded before
+// anything moves; the second push of a heap must see what the first one left on the part of its chain that the two
+// chains share (everything from their lowest common ancestor up; with p = 0 the first element itself): there an ancestor is either untouched, or the first
+// push's element, or its own parent moved down one level — all of which the second chain's lanes hold already (the parent
+// is the next lane of the row), so the fix-up is a row shift and two selects.
+WV_FN void pushPairs(Lds lds, const Rows& R, uint32_t hbX, uint32_t kmX, uint32_t pX, uint32_t nX, uint32_t eX1, uint32_t eX2,
+                     uint32_t hbY, uint32_t kmY, uint32_t pY, uint32_t nY, uint32_t eY1, uint32_t eY2) {
+  const V hb = sel(R.isY, splat(hbY), splat(hbX));
+  const V km = sel(R.isY, splat(kmY), splat(kmX));
+  // position + 1 of this row's push (1: the row has nothing to push: no ancestors)
+  const V p1 = perRow(R, nX >= 1u ? pX + 1u : 1u, nX >= 2u ? pX + 2u : 1u, nY >= 1u ? pY + 1u : 1u, nY >= 2u ? pY + 2u : 1u);
+  const V e = perRow(R, eX1, eX2, eY1, eY2);
+  const V ek = e & km;
+  const V ancIdx = p1 >> (R.l4 + 1u);
+  const V ae = ldsLoad32(lds, hb + ancIdx * 4u - 4u);   // (lanes beyond the root: the word in front of the array)
+  const V dest = hb + (p1 >> R.l4) * 4u - 4u;           // lane l4 < stop: ancestor l4 moves down to here; lane == stop: e
+  const uint64_t worse1 = ballot((ae & km) < ek);
+  // first ancestor that is not worse than the element, plus one (0: nothing to push)
+  const uint32_t sX1 = nX >= 1u ? ctz32(~lo32(worse1)) + 1u : 0u, sY1 = nY >= 1u ? ctz32(~hi32(worse1)) + 1u : 0u;
+  const V stop1 = sel(R.isY, splat(sY1), splat(sX1));
+  ldsStore32m(lds, dest, sel((R.l4 + 1u) == stop1, e, ae), (!R.isSecond) & (R.l4 < stop1));
+  if (nX >= 2u || nY >= 2u) {
+    // chains of p and p + 1 have the same depth unless p + 2 is a power of two (p + 1 starts a new level)
+    const uint32_t ddX = lg2(pX + 2u) - lg2(pX + 1u), ddY = lg2(pY + 2u) - lg2(pY + 1u);
+    const V dd = sel(R.isY, splat(ddY), splat(ddX));
+    const V e1 = sel(R.isY, splat(eY1), splat(eX1));
+    const V j1p1 = R.l4 + 1u - dd;                      // index + 1 of the same position on the first chain
+    const B shared = (R.l4 >= dd) & (ancIdx == ((p1 - 1u) >> j1p1));
+    const V up = rowShl1(ae, kFront);                   // the parent of this lane's ancestor
+    // (p = 0: the first push IS the root, the parent of position 1)
+    const V now = sel(shared, sel((j1p1 + 1u) < stop1, up, sel((j1p1 + 1u) == stop1, e1, ae)), sel((p1 == 2u) & (R.l4 == 0u), e1, ae));
+    const uint64_t worse2 = ballot((now & km) < ek);
+    const uint32_t sX2 = nX >= 2u ? ctz32(~(lo32(worse2) >> 16)) + 1u : 0u, sY2 = nY >= 2u ? ctz32(~(hi32(worse2) >> 16)) + 1u : 0u;
+    const V stop2 = sel(R.isY, splat(sY2), splat(sX2));
+    ldsStore32m(lds, dest, sel((R.l4 + 1u) == stop2, e, now), R.isSecond & (R.l4 < stop2));
+  }
+}
+
 // ---- one search ------------------------------------------------------------------------------------------------
 // The job is the CJob at oJob of the window, the result the CRes at oRes.  PLDS: the focal path table is in the window at
 // oPaths (else at CJob::pathsG); the search loop of a PLDS instance issues no vector-memory LOAD at all — its only
@@ -207,6 +264,7 @@ template <bool EPS, bool PLDS>
 WV_ENTRY int32_t compactSearch(Lds window) {
   const Lds lds = windowBase(window);
   const Sides S = makeSides();
+  const Rows Rw = makeRows();
   const V lane = S.lane;
   const V hb = bothSides(S, oOpen + 4u, oFocal + 4u);  // side A = open list, side B = focal list
   const V km = bothSides(S, kMO, kMF);
@@ -322,42 +380,73 @@ WV_ENTRY int32_t compactSearch(Lds window) {
         // (libstdc++ push_heap / pop_heap restated: push = sift-up, pop = hole down to a leaf, then sift-up)
         const float lo = fmulRn((float)oldBest, wBound), hi = fmulRn((float)fTop, wBound);  // binary32, no contraction
         uint32_t npq = 0, npqHigh = 0;
-        uint32_t curA = (topO & kMO) | 0u;               // walk-queue entry: open key | index in the open array
+        uint32_t cur = 0, curKey = topO & kMO, eCur = topO;  // the node being visited: open index, open key, entry
+        // lanes 0, 1: the children of the node in the open array (past the end of the list: "no element"); lane 2: the node
+        V trio = ldsLoad32(lds, splat(oOpen + 4u) + sel(lane == 2u, splat(cur), splat(2u * cur + 1u) + (lane & 1u)) * 4u);
         for (;;) {
-          const uint32_t cur = curA & 0x3FFu;            // (ten bits below the key: up to 1023 entries)
           const uint32_t firstC = 2u * cur + 1u;
-          if (firstC < nOpen) {                          // discover the children (index order) before the node is tested
-            if (npq + 2u > kAuxCap) {
-              status = C_OVERFLOW;
-              cost = 4;
-              break;
-            }
-            const V pr = ldsLoad32(lds, splat(oOpen + 4u + 4u * firstC) + (lane & 1u) * 4u);
-            const uint32_t e1 = readlane(pr, 0), e2 = readlane(pr, 1);
-            dualSiftUp(lds, S, hbAux, kmAux, splat(npq + 1u), (e1 & kMO) | firstC, false, false);
-            npq += 1u;
-            if (firstC + 1u < nOpen) {
-              dualSiftUp(lds, S, hbAux, kmAux, splat(npq + 1u), (e2 & kMO) | (firstC + 1u), false, false);
-              npq += 1u;
-            }
-            npqHigh = npq > npqHigh ? npq : npqHigh;
+          const uint32_t nCh = firstC + 1u < nOpen ? 2u : firstC < nOpen ? 1u : 0u;
+          if (npq + 2u > kAuxCap) {
+            status = C_OVERFLOW;
+            cost = 4;
+            break;
           }
-          const float fv = (float)(int32_t)(127u - ((curA >> 16) & 127u));
-          if (fv > lo && fv <= hi) {
-            const uint32_t e = ldsLoadS(lds, oOpen + 4u + 4u * cur);
-            dualSiftUp(lds, S, hb, km, bothSides(S, 1u, nFocal + 1u), e, true, false);
-            nFocal += 1u;
-          }
+          // discover the children (index order) before the node is tested; the node joins the focal list if it is in the band
+          const uint32_t e1 = readlane(trio, 0), e2 = readlane(trio, 1);
+          const float fv = (float)(int32_t)(127u - ((curKey >> 16) & 127u));
+          const bool inBand = fv > lo && fv <= hi;
+          pushPairs(lds, Rw, oAux + 4u, kMO, npq, nCh, (e1 & kMO) | firstC, (e2 & kMO) | (firstC + 1u), oFocal + 4u, kMF, nFocal,
+                    inBand ? 1u : 0u, eCur, 0u);
+          npq += nCh;
+          nFocal += inBand ? 1u : 0u;
+          npqHigh = npq > npqHigh ? npq : npqHigh;
           if (fv > hi) break;
           if (npq == 0u) break;
-          // std::priority_queue::pop
-          curA = ldsLoadS(lds, oAux + 4u);
+          // std::priority_queue::pop == pop_heap: the last element goes into the hole the top leaves behind, i.e. the
+          // hole moves down to a leaf (__adjust_heap) and the element up again from there (__push_heap).  The next node
+          // (the top) and the last element are fetched together with the first block of the hole's way down, which does
+          // not depend on them.
           npq -= 1u;
-          const uint32_t value = ldsLoadS(lds, oAux + 4u + 4u * npq);
-          ldsStoreS(lds, oAux + 4u + 4u * npq, kEmpty);  // (the vacated slot: "no element")
+          const V two = ldsLoad32(lds, splat(oAux + 4u) + sel(lane == 0u, splat(0u), splat(npq)) * 4u);
+          ldsStoreS(lds, oAux + 4u + 4u * npq, kEmpty);    // the vacated slot: "no element" (before the hole's way down looks)
+          uint32_t hole = 0, above = kFront;  // `above`: what now sits in the hole's parent
+          bool first = true;
+          uint32_t value = 0;
+          for (;;) {
+            const V node = ((splat(hole) + 1u) << S.lvl) + S.off1;
+            V c = node * 2u + 1u;
+            c = sel(c < kAuxClamp, c, splat(kAuxClamp));
+            const V2 pr = ldsLoad64(lds, splat(oAux + 4u) + c * 4u);
+            if (first) {
+              first = false;
+              const uint32_t curA = readlane(two, 0);
+              value = readlane(two, 1);
+              cur = curA & 0x3FFu;                           // (ten bits below the key: up to 1023 entries)
+              curKey = curA & kMO;
+              // the next node's entry and children, for the next turn of the loop
+              trio = ldsLoad32(lds, splat(oOpen + 4u) + sel(lane == 2u, splat(cur), splat(2u * cur + 1u) + (lane & 1u)) * 4u);
+              if (npq == 0u) break;
+            }
+            const V kl = pr.x & kMO, kr = pr.y & kMO;
+            const B right = kr >= kl;                        // prefer the right child unless it is less than the left one
+            const V pe = sel(right, pr.y, pr.x);
+            const B go = kl > (kEmpty & kMO);                // down to a leaf: as long as there is a child
+            const uint32_t goM = lo32(ballot(go)), rM = lo32(ballot(right));
+            const B onPath = ((S.anc & goM) == S.anc) & (((S.needR ^ rM) & S.anc) == 0u) & go;
+            const uint32_t pm = lo32(ballot(onPath & !S.isB));
+            ldsStore32m(lds, splat(oAux + 4u) + node * 4u, pe, onPath);
+            if (pm == 0u) break;
+            const uint32_t steps = (uint32_t)__builtin_popcount(pm), d = lg2(pm);
+            hole = ((hole + 1u) << steps) + 2u * d + 1u + ((rM >> d) & 1u) - (1u << steps);
+            above = readlane(pe, d);
+            if (steps < 5u) break;
+          }
+          eCur = readlane(trio, 2);
           if (npq > 0u) {
-            const V hole = dualDescend<true>(lds, S, hbAux, kmAux, splat(kAuxClamp), splat(0u));
-            dualSiftUp(lds, S, hbAux, kmAux, hole + 1u, value, false, false);
+            if (hole == 0u || !((above & kMO) < (value & kMO)))
+              ldsStoreS(lds, oAux + 4u + 4u * hole, value);  // the usual case: the last element stays at the leaf
+            else
+              dualSiftUp(lds, S, hbAux, kmAux, splat(hole + 1u), value, false, false);
           }
         }
         // what the walk leaves in its queue is dropped: every slot "no element" again
@@ -537,14 +626,20 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     // cameFrom (a_star_epsilon.hpp:275-279): the action that led here
     gStore8m(parentTab, splat(t1 << 10) + ncell, lane, mine);
     nodes += (uint32_t)__builtin_popcount(mask);
-    // ---- openSet.push for every successor, focalSet.push for those within the bound, in successor order
-    for (uint32_t mm = mask; mm; mm &= mm - 1u) {
-      const uint32_t k = ctz32(mm);
-      const uint32_t e = readlane(eV, k);
-      const bool inF = EPS && ((maskF >> k) & 1u);
-      dualSiftUp(lds, S, hb, km, bothSides(S, nOpen + 1u, inF ? nFocal + 1u : 1u), e, false, !inF);
-      nOpen += 1u;
-      nFocal += inF ? 1u : 0u;
+    // ---- openSet.push for every successor, focalSet.push for those within the bound, in successor order — two successors
+    // per step (pushes into different lists do not see each other, so the four chains of a step are loaded together)
+    for (uint32_t mm = mask; mm;) {
+      const uint32_t k1 = ctz32(mm);
+      mm &= mm - 1u;
+      const bool two = mm != 0u;
+      const uint32_t k2 = two ? ctz32(mm) : 0u;
+      mm &= mm - 1u;  // (0 stays 0)
+      const uint32_t e1 = readlane(eV, k1), e2 = readlane(eV, k2);
+      const bool f1 = EPS && ((maskF >> k1) & 1u), f2 = EPS && two && ((maskF >> k2) & 1u);
+      const uint32_t nX = two ? 2u : 1u, nY = (f1 ? 1u : 0u) + (f2 ? 1u : 0u);
+      pushPairs(lds, Rw, oOpen + 4u, kMO, nOpen, nX, e1, e2, oFocal + 4u, kMF, nFocal, nY, f1 ? e1 : e2, e2);
+      nOpen += nX;
+      nFocal += nY;
     }
   }
   // the result block of the window

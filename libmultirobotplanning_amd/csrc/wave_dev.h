@@ -38,6 +38,8 @@ WV_FN uint32_t first(V v) { return __builtin_amdgcn_readfirstlane(v); }
 extern "C" __device__ int mrp_llvm_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 WV_FN V writelane(V v, uint32_t val, uint32_t lane) { return (uint32_t)mrp_llvm_writelane((int)val, (int)lane, (int)v); }
 WV_FN V shr1(V v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }
+// lane i of every 16-lane row receives lane i + 1's value; the last lane of a row receives `fill`
+WV_FN V rowShl1(V v, uint32_t fill) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xF, 0xF, false); }
 WV_FN V clz(V v) { return (uint32_t)__builtin_clz(v); }          // v != 0
 WV_FN V popc(V v) { return (uint32_t)__builtin_popcount(v); }
 WV_FN float uintAsFloat(uint32_t v) { return __uint_as_float(v); }

@@ -117,6 +117,11 @@ WV_FN V shr1(const V& v) {
   for (int i = 1; i < kLanes; ++i) r.l[i] = v.l[i - 1];
   return r;
 }
+WV_FN V rowShl1(const V& v, uint32_t fill) {  // DPP row_shl:1
+  V r;
+  for (int i = 0; i < kLanes; ++i) r.l[i] = (i & 15) == 15 ? fill : v.l[i + 1];
+  return r;
+}
 WV_FN V clz(const V& v) {
   V r;
   for (int i = 0; i < kLanes; ++i) r.l[i] = v.l[i] ? (uint32_t)__builtin_clz(v.l[i]) : 32u;
