@@ -399,12 +399,16 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   if (const char* e = std::getenv("MRP_HL_RING_DEPTH"))
     if (std::atoll(e) > 0) ringTarget = std::atoll(e);  // tuning knob
   typedef std::pair<int64_t, size_t> Waiting;  // (priority, live index)
+  static const bool prioExp = std::getenv("MRP_HL_PRIO_EXPANSIONS") != nullptr;  // A/B: round 2's priority (expansions only)
   std::priority_queue<Waiting> backlog;
   auto enqueue = [&](size_t k) {
     Live& L = live[k];
     if (!L.queued) {
       L.queued = true;
-      backlog.push(Waiting(L.inst->llExpanded(), k));
+      // priority: the work an instance has consumed so far, in searches — a long chain of tiny searches (a deadlocked
+      // pair of agents grows its conflict tree by two 10-expansion searches per round, thousands of rounds deep) is as
+      // latency-critical as one huge search, and its expansions alone would never say so
+      backlog.push(Waiting(prioExp ? L.inst->llExpanded() : L.inst->llExpanded() / 64 + L.inst->llSearches(), k));
     }
   };
   // Submits groups of live[k] while the device queue has room; false on error.  Leaves it in the backlog if some remain.
@@ -436,7 +440,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   bool exhausted = false;
   // shared pool: no worker may hold more than its fair share at a time, or a small batch is drained by the first few
   size_t activeLimit =
-      shared ? std::max<size_t>(1, std::min<size_t>(1536, (static_cast<size_t>(nTotal) + nWorkers - 1) / nWorkers)) : n;
+      shared ? std::max<size_t>(1, std::min<size_t>(16384, (static_cast<size_t>(nTotal) + nWorkers - 1) / nWorkers)) : n;
   if (const char* e = std::getenv("MRP_HL_ACTIVE_LIMIT")) activeLimit = std::max(1, std::atoi(e));
   auto admit = [&]() -> bool {  // next instance of the pool, false when it is empty
     int32_t k, mid;

@@ -52,8 +52,8 @@ constexpr uint32_t kAuxClamp = kAuxCap + 1u;      // odd; elements kAuxCap .. kA
 constexpr uint32_t kRows = 64, kRowBytes = 128;   // (time, cell) bitmap: 32 words (one per y) of 32 bits (x) per time step
 constexpr uint32_t oCtl = 0;                      // 256 bytes for the kernel that hosts the tier (job descriptor, result)
 constexpr uint32_t oJob = 256;                    // CJob
-constexpr uint32_t oRes = 384;                    // CRes
-constexpr uint32_t oOpen = 416;
+constexpr uint32_t oRes = 384;                    // CRes (+ eight profile words in the diagnostic build)
+constexpr uint32_t oOpen = 448;
 constexpr uint32_t oFocal = oOpen + kHeapBytes;
 constexpr uint32_t oAux = oFocal + kHeapBytes;
 constexpr uint32_t oBits = oAux + kAuxBytes;
@@ -97,7 +97,21 @@ struct CRes {              // at oRes
   int32_t status, cost, fmin, nStates;
   uint32_t expanded, nodes;
 };
-static_assert(sizeof(CRes) <= oOpen - oRes, "CRes fits its block of the window");
+// -DMRP_CT_PROF (diagnostic build): shader cycles per phase of the search loop, in eight words behind the CRes:
+// 0 loop top + goal test, 1 ordered walk, 2 successor probes / row loads issued, 3 pop + erase, 4 successor entries,
+// 5 pushes, 6 nodes visited by walks, 7 set-up
+#ifdef MRP_CT_PROF
+#define MRP_CT_PROF_DECL uint32_t prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t profT_ = wv::clock64()
+#define MRP_CT_PROF_MARK(k) do { const uint64_t n_ = wv::clock64(); prof_[k] += (uint32_t)(n_ - profT_); profT_ = n_; } while (0)
+#define MRP_CT_PROF_ADD(k, v) prof_[k] += (v)
+#define MRP_CT_PROF_STORE(lds) do { for (uint32_t q_ = 0; q_ < 8; ++q_) ldsStoreS(lds, oRes + 32u + 4u * q_, prof_[q_]); } while (0)
+#else
+#define MRP_CT_PROF_DECL do { } while (0)
+#define MRP_CT_PROF_MARK(k) do { } while (0)
+#define MRP_CT_PROF_ADD(k, v) do { } while (0)
+#define MRP_CT_PROF_STORE(lds) do { } while (0)
+#endif
+static_assert(sizeof(CRes) <= 32 && oRes + 64 <= oOpen, "CRes fits its block of the window");
 
 #define MRP_CT_JOB_U32(lds, field) ldsLoadS(lds, oJob + (uint32_t)offsetof(CJob, field))
 template <class T>
@@ -276,6 +290,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
   int32_t status = C_NO_SOLUTION, cost = 0, fmin = 0, nStates = 0;
   uint32_t nOpen = 1, nFocal = EPS ? 1u : 0u, nodes = 1, expansions = 0;
 
+  MRP_CT_PROF_DECL;
   // ---- job set-up -------------------------------------------------------------------------------------------
   sync();  // the previous job's LDS reads are done; the CJob block is written
   {  // obstacle row with a stride of 32 bits per y (the map's bitmap has a stride of dimx): lane y builds word y
@@ -361,6 +376,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     if (EPS) ldsStoreS(lds, oFocal + 4u, e0);
   }
   sync();
+  MRP_CT_PROF_MARK(7);
 
   for (;;) {
     if (nOpen == 0u) {
@@ -375,6 +391,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       const int32_t oldBest = bestF;
       bestF = fTop;                                      // bestFScore = openSet.top().fScore (a_star_epsilon.hpp:136)
       if (fTop > oldBest) {
+        MRP_CT_PROF_MARK(0);
         // ---- a_star_epsilon.hpp:134-154: bestFScore grew -> every open node with old * w < f <= new * w joins the focal
         // list, in the order of open.ordered_begin(): a best-first walk of the open array through a std::priority_queue
         // (libstdc++ push_heap / pop_heap restated: push = sift-up, pop = hole down to a leaf, then sift-up)
@@ -384,6 +401,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
         // lanes 0, 1: the children of the node in the open array (past the end of the list: "no element"); lane 2: the node
         V trio = ldsLoad32(lds, splat(oOpen + 4u) + sel(lane == 2u, splat(cur), splat(2u * cur + 1u) + (lane & 1u)) * 4u);
         for (;;) {
+          MRP_CT_PROF_ADD(6, 1u);
           const uint32_t firstC = 2u * cur + 1u;
           const uint32_t nCh = firstC + 1u < nOpen ? 2u : firstC < nOpen ? 1u : 0u;
           if (npq + 2u > kAuxCap) {
@@ -457,6 +475,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
         }
         if (status == C_OVERFLOW) break;
         curE = ldsLoadS(lds, oFocal + 4u);
+        MRP_CT_PROF_MARK(1);
       }
     }
     // f, g (== time) and focalH of the popped node are in its entry
@@ -508,6 +527,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       break;
     }
 
+    MRP_CT_PROF_MARK(0);
     const uint32_t t1 = t + 1u;
     // the five successor probes: bounds, then ONE bit of the (time, cell) bitmap = obstacle | vertex constraint | already
     // discovered; requested before the pops so that the latency hides behind them
@@ -539,6 +559,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       }
     }
 
+    MRP_CT_PROF_MARK(2);
     // ---- a_star_epsilon.hpp:215-216: focalSet.pop(), openSet.erase(handle of the same node)   (a_star.hpp:109: pop)
     {
       const uint32_t nOld = nOpen;
@@ -583,6 +604,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       ldsStore32m(lds, hb + hole * 4u, bothSides(S, lastO, lastF), (S.l5 == 0u) & (bothSides(S, nOpen, EPS ? nFocal : 0u) != 0u));
     }
 
+    MRP_CT_PROF_MARK(3);
     const B okV = inb & (((word >> (nx & 31u)) & 1u) == 0u);
     uint32_t mask = lo32(ballot(okV)) & 0x1Fu;
     if (nEc) {  // transitionValid (ecbs.cpp:505-510): lane j holds edge-constraint key j = t << 19 | cell << 3 | action
@@ -594,7 +616,10 @@ WV_ENTRY int32_t compactSearch(Lds window) {
         mask &= ~blocked;
       }
     }
-    if (mask == 0u) continue;
+    if (mask == 0u) {
+      MRP_CT_PROF_MARK(4);
+      continue;
+    }
 
     // ---- the successors' entries, one per lane 0..4
     const B mine = (lane < 5u) & (((splat(mask) >> lane) & 1u) != 0u);
@@ -626,6 +651,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     // cameFrom (a_star_epsilon.hpp:275-279): the action that led here
     gStore8m(parentTab, splat(t1 << 10) + ncell, lane, mine);
     nodes += (uint32_t)__builtin_popcount(mask);
+    MRP_CT_PROF_MARK(4);
     // ---- openSet.push for every successor, focalSet.push for those within the bound, in successor order — two successors
     // per step (pushes into different lists do not see each other, so the four chains of a step are loaded together)
     for (uint32_t mm = mask; mm;) {
@@ -637,10 +663,16 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       const uint32_t e1 = readlane(eV, k1), e2 = readlane(eV, k2);
       const bool f1 = EPS && ((maskF >> k1) & 1u), f2 = EPS && two && ((maskF >> k2) & 1u);
       const uint32_t nX = two ? 2u : 1u, nY = (f1 ? 1u : 0u) + (f2 ? 1u : 0u);
-      pushPairs(lds, Rw, oOpen + 4u, kMO, nOpen, nX, e1, e2, oFocal + 4u, kMF, nFocal, nY, f1 ? e1 : e2, e2);
+#ifndef MRP_CT_NO_SINGLE_PUSH
+      if (!two)  // one successor (the usual case): its two chains side by side, half the bookkeeping
+        dualSiftUp(lds, S, hb, km, bothSides(S, nOpen + 1u, f1 ? nFocal + 1u : 1u), e1, false, !f1);
+      else
+#endif
+        pushPairs(lds, Rw, oOpen + 4u, kMO, nOpen, nX, e1, e2, oFocal + 4u, kMF, nFocal, nY, f1 ? e1 : e2, e2);
       nOpen += nX;
       nFocal += nY;
     }
+    MRP_CT_PROF_MARK(5);
   }
   // the result block of the window
   ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, status), (uint32_t)status);
@@ -649,6 +681,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
   ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, nStates), (uint32_t)nStates);
   ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, expanded), expansions);
   ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, nodes), nodes);
+  MRP_CT_PROF_STORE(lds);
   sync();
   return status;
 }

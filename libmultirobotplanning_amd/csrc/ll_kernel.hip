@@ -1221,6 +1221,12 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     res.prof[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);  // 100 MHz ticks / expansions in the compact tier
     res.prof[1] = cr.expanded;                                         // (of a search that was handed over: until then)
 #endif
+#ifdef MRP_CT_PROF  // diagnostic build: the compact tier's own phase counters instead of the tier statistics
+    {
+      auto r32 = (__attribute__((address_space(3))) const uint32_t*)((wv::Lds)smem + ct::oRes + 32u);
+      for (uint32_t q = 0; q < 8; ++q) res.prof[q] = rfl(r32[q]);
+    }
+#endif
     if (crc != ct::C_OVERFLOW) {
       rc = crc;  // C_OK / C_NO_SOLUTION / C_CAP_EXP == ST_OK / ST_NO_SOLUTION / ST_CAP_EXP
       res.cost = cr.cost;
@@ -2144,7 +2150,7 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
     if (algo == 0) runJob<false>(P, J, smem, arenaSlot, res, outPath);
   }
   PROF_ADD(res, 5);
-#ifndef MRP_LL_TRACE
+#if !defined(MRP_LL_TRACE) && !defined(MRP_CT_PROF)
   res.prof[4] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tj0);  // the whole job on the device (tables, search)
   res.prof[5] = 1;
 #endif

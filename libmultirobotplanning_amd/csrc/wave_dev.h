@@ -28,6 +28,7 @@ typedef __attribute__((address_space(3))) uint8_t* Lds;  // the workgroup's LDS 
 // every address inside the window is a compile-time constant of the ds_ instructions.
 WV_FN Lds windowBase(Lds) { return (Lds)(uintptr_t)0; }
 WV_FN V laneId() { return threadIdx.x; }
+WV_FN uint64_t clock64() { return __builtin_amdgcn_s_memtime(); }  // shader cycles (diagnostic builds)
 WV_FN V splat(uint32_t s) { return s; }
 WV_FN V sel(B c, V a, V b) { return c ? a : b; }
 WV_FN B bsplat(bool s) { return s; }

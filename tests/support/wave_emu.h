@@ -91,6 +91,7 @@ struct LdsWindow {
 typedef LdsWindow* Lds;
 
 WV_FN Lds windowBase(Lds w) { return w; }
+WV_FN uint64_t clock64() { return 0; }
 WV_FN V laneId() {
   V r;
   for (int i = 0; i < kLanes; ++i) r.l[i] = (uint32_t)i;
