@@ -14,9 +14,9 @@ starts, as the reference constructs its Environment before its Timer (example/ec
 
 Extra objects in the same line:
   by_workload  — N = 1 only: one timed step each of the other shapes north_star names, after the headline region:
-                 agents50, agents100 (synthetic, same generator) and "shipped" (the 150 committed
-                 benchmark/32x32_obst204 inputs of tests/golden/bench_instances.json as ONE batch, checked against
-                 tests/golden/oracle_expected.json).  Each carries value (expansions/s), instances_per_s, capped,
+                 agents50, agents100 (synthetic, same generator) and "shipped" (ALL 1000 shipped
+                 benchmark/32x32_obst204 inputs, tests/golden/shipped_32x32.npz, as ONE batch, every result checked against
+                 tests/golden/shipped_32x32_expected.json).  Each carries value (expansions/s), instances_per_s, capped,
                  cpu_baseline (the CPU port, one thread, on a bounded sample of the SAME instances) and
                  parity_mismatches_vs_gpu over that sample.  sipp50 / sipp100 / sipp200: prioritized SIPP (config 5) on
                  synthetic 64x64 maps with 410 obstacles, CPU leg = 512 instances timed inside the oracle.
@@ -345,6 +345,14 @@ def main():
                 if do_cpu:
                     leg["cpu_baseline"] = cpu_leg(oracle, ia, res, cap, ncpu, hl)
                     leg["vs_cpu_port_1core"] = leg["value"] / max(leg["cpu_baseline"]["value"], 1e-12)
+                    n_all = min(nb, 8 * hc if ag <= 50 else 4 * hc)  # a bounded sample: ~10 s of wall clock on all cores
+                    per, wall = oracle.mapf_solve_batch(oracle.ECBS, 32, 32, ia.obstacles[:n_all], ia.starts[:n_all],
+                                                        ia.goals[:n_all], w=1.3, cap_total=cap, n_threads=hc)
+                    leg["cpu_baseline_all_cores"] = {
+                        "value": float(per[:, 4].sum()) / max(wall, 1e-12), "unit": "expansions/s", "cores": hc,
+                        "kind": "port", "pool_wall_seconds": wall,
+                        "sample": "first %d instances of the leg's batch, one per thread on %d threads" % (n_all, hc)}
+                    leg["vs_cpu_port_all_cores"] = leg["value"] / max(leg["cpu_baseline_all_cores"]["value"], 1e-12)
                 by[name] = leg
             elif name in sipp_specs:
                 # BASELINE.json config 5 / SURVEY.md §8(d)(iv): prioritized planning over MRP_LL_SIPP searches, 64x64 with
@@ -381,13 +389,15 @@ def main():
                     leg["vs_cpu_port_1core"] = leg["value"] / max(leg["cpu_baseline"]["value"], 1e-12)
                 by[name] = leg
             elif name == "shipped":
-                with open(os.path.join(ROOT, "tests", "golden", "bench_instances.json")) as f:
-                    shipped = json.load(f)
-                with open(os.path.join(ROOT, "tests", "golden", "oracle_expected.json")) as f:
+                # the corpus north_star names: ALL 1000 shipped benchmark/32x32_obst204 inputs (agents10..100 x ex0..99) as
+                # ONE batch, every result checked against tests/golden/shipped_32x32_expected.json (our oracle at the same
+                # cap; agents100_ex36 runs into it on both sides)
+                corpus = hl.load_shipped_corpus(os.path.join(ROOT, "tests", "golden", "shipped_32x32.npz"))
+                with open(os.path.join(ROOT, "tests", "golden", "shipped_32x32_expected.json")) as f:
                     expected = json.load(f)
-                names = [n for n in sorted(shipped) if "32by32" in n]
-                insts = [shipped[n] for n in names]
-                cap = 3000000  # the cap oracle_expected.json was produced with (tests/golden/make_fixtures.py)
+                names = [n for n, _ in corpus]
+                insts = [i for _, i in corpus]
+                cap = 3000000  # the cap the golden vectors were produced with (tests/golden/make_fixtures.py)
                 prep = solver.prepare(insts, want_paths=False)
                 solver.solve_prepared(prep, algo=hl.ECBS, w=1.3, max_ll_expansions=cap, raw=True)  # warm-up
                 torch.cuda.synchronize()
@@ -399,7 +409,7 @@ def main():
                 solver.release(prep)
                 mism = 0
                 for n, r in zip(names, res):
-                    e = expected[n]["ecbs_w1.3"]
+                    e = expected[n]
                     if e["rc"] == 1:
                         mism += (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) != (
                             hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"])
@@ -408,20 +418,46 @@ def main():
                 leg = {"value": st["ll_expansions"] / dt, "unit": "expansions/s", "instances_per_s": len(insts) / dt,
                        "instances": len(insts), "seconds": dt, "solved": int(st["solved"]),
                        "capped": sum(1 for r in res if r["status"] == hl.CAP), "cap_per_instance": cap,
-                       "parity_mismatches_vs_golden": int(mism),
-                       "workload": "the %d committed benchmark/32x32_obst204 inputs (agents10 x100, 20 x10, 30 x10, 50 x20, "
-                                   "100 x10) as one batch, ECBS w=1.3" % len(insts)}
-                if do_cpu:  # the whole shipped set on one CPU thread
+                       "ll_searches": int(st["ll_searches"]),
+                       "parity_mismatches_vs_golden": int(mism), "parity_checked": len(insts),
+                       "workload": "all %d shipped benchmark/32x32_obst204 inputs (agents10..100 x ex0..99) as one batch, "
+                                   "ECBS w=1.3" % len(insts)}
+                if do_cpu:
+                    # one core: every tenth input of every agent count (100 instances, ~15 s of CPU; agents100_ex36, which
+                    # alone costs the port ~20 s to reach the cap, is not among them), each checked against the golden vector
                     t_cpu = 0.0
                     e_cpu = 0
-                    for inst in insts:
+                    n_cpu = 0
+                    cpu_mism = 0
+                    for n, inst in corpus:
+                        if int(n.rsplit("_ex", 1)[1]) % 10 != 0:
+                            continue
                         o = oracle.mapf_solve(oracle.ECBS, inst, w=1.3, cap_total=cap, path_cap=1024)
                         t_cpu += o["elapsed_ns"] / 1e9
                         e_cpu += o["ll_expanded"]
+                        n_cpu += 1
+                        e = expected[n]
+                        cpu_mism += (o["rc"], o.get("cost"), o["ll_expanded"]) != (1, e.get("cost"), e.get("ll"))
                     leg["cpu_baseline"] = {"value": e_cpu / max(t_cpu, 1e-12), "unit": "expansions/s", "cores": 1,
-                                           "kind": "port", "sample": "all %d instances" % len(insts),
-                                           "instances_per_s": len(insts) / max(t_cpu, 1e-12), "seconds": t_cpu}
+                                           "kind": "port", "sample": "ex0, ex10, .. ex90 of every agent count (%d instances)" % n_cpu,
+                                           "instances_per_s": n_cpu / max(t_cpu, 1e-12), "seconds": t_cpu,
+                                           "golden_mismatches": int(cpu_mism)}
                     leg["vs_cpu_port_1core"] = leg["value"] / max(leg["cpu_baseline"]["value"], 1e-12)
+                    # every core: the whole corpus, one instance per thread, heaviest agent counts first (wall clock)
+                    wall_all = 0.0
+                    e_all = 0
+                    for nag in range(100, 9, -10):
+                        grp = [i for n, i in corpus if ("agents%d_" % nag) in n]
+                        ob = [i["obstacles"] for i in grp]
+                        per, wall = oracle.mapf_solve_batch(oracle.ECBS, 32, 32, ob, [i["starts"] for i in grp],
+                                                            [i["goals"] for i in grp], w=1.3, cap_total=cap, n_threads=hc)
+                        wall_all += wall
+                        e_all += int(per[:, 4].sum())
+                    leg["cpu_baseline_all_cores"] = {"value": e_all / max(wall_all, 1e-12), "unit": "expansions/s",
+                                                     "cores": hc, "kind": "port", "pool_wall_seconds": wall_all,
+                                                     "sample": "all %d instances, one per thread on %d threads, agent "
+                                                               "counts one after the other" % (len(insts), hc)}
+                    leg["vs_cpu_port_all_cores"] = leg["value"] / max(leg["cpu_baseline_all_cores"]["value"], 1e-12)
                 by[name] = leg
         if sharded_ct is not None:
             by["sharded_conflict_tree"] = sharded_ct

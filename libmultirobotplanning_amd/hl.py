@@ -178,6 +178,20 @@ class InstanceArrays:
         return (self[k] for k in range(len(self)))
 
 
+def load_shipped_corpus(path: str) -> List[Dict]:
+    """The 1000 shipped benchmark/32x32_obst204 inputs from tests/golden/shipped_32x32.npz (uint8 arrays per agent count),
+    as (name, instance dict) pairs in the order agents10_ex0 .. agents100_ex99."""
+    z = np.load(path)
+    out = []
+    for n in range(10, 101, 10):
+        ob, st, go = z["obst%d" % n], z["starts%d" % n], z["goals%d" % n]
+        for k in range(ob.shape[0]):
+            out.append(("map_32by32_obst204_agents%d_ex%d" % (n, k),
+                        dict(dimx=32, dimy=32, obstacles=ob[k].astype(int).tolist(), starts=st[k].astype(int).tolist(),
+                             goals=go[k].astype(int).tolist())))
+    return out
+
+
 def generate_instances(seed0: int, n: int, dimx: int = 32, dimy: int = 32, n_obstacles: int = 204,
                        n_agents: int = 10) -> InstanceArrays:
     """Seeds seed0 .. seed0+n-1 in ONE native call (SURVEY.md §8d generator); identical to n generate_instance calls."""

@@ -37,3 +37,18 @@ def oracle_mod():
     import oracle
     oracle.build()
     return oracle
+
+
+@pytest.fixture(scope="session")
+def shipped_corpus():
+    """(name, instance) pairs of all 1000 shipped benchmark/32x32_obst204 inputs + the oracle's golden results."""
+    from libmultirobotplanning_amd import hl
+    with open(os.path.join(GOLDEN, "shipped_32x32_expected.json")) as f:
+        exp = json.load(f)
+    return hl.load_shipped_corpus(os.path.join(GOLDEN, "shipped_32x32.npz")), exp
+
+
+@pytest.fixture(scope="session")
+def ll_jobs_golden():
+    with open(os.path.join(GOLDEN, "ll_jobs.json")) as f:
+        return json.load(f)

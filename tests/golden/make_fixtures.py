@@ -15,6 +15,15 @@ What is produced, and from what:
                               HIP path, NOT reference outputs: the reference is unbuildable here (no Boost / yaml-cpp),
                               see DESIGN.md "Oracle pinning".
 
+* ``shipped_32x32.npz``     — ALL 1000 shipped benchmark/32x32_obst204 inputs (agents10..100 x ex0..99) as uint8 arrays
+                              (obstacles, starts, goals per agent count): the corpus BASELINE.json's north_star names.
+* ``shipped_32x32_expected.json`` — our oracle's ECBS w=1.3 results on every one of them at a cap of 3 000 000 low-level
+                              expansions per instance (agents100_ex36 runs into it), same status as oracle_expected.json.
+* ``cbs_8x8_cap1e6.json``   — our oracle's CBS results on shipped 8x8_obst12 inputs at SURVEY.md §8(d)(iii)'s cap of
+                              1 000 000 low-level expansions per instance (agents 10, 12, 16, 20).
+* ``ll_jobs.json``          — ~200 low-level searches harvested from the oracle's conflict trees (inputs AND outputs), so
+                              that a box without a compiler for the oracle still has low-level parity vectors.
+
 No reference source text is copied; only data files are converted.
 """
 import hashlib
@@ -131,7 +140,98 @@ def summarize(r):
                 digest=path_digest(r["paths"]))
 
 
+def shipped_corpus():
+    """All 1000 shipped 32x32_obst204 instances, compactly, + oracle vectors at cap 3e6 (a process pool: ~2 CPU-minutes)."""
+    import numpy as np
+    from concurrent.futures import ProcessPoolExecutor
+    arrays = {}
+    jobs = []
+    for n in range(10, 101, 10):
+        obst = np.zeros((100, 204, 2), dtype=np.uint8)
+        starts = np.zeros((100, n, 2), dtype=np.uint8)
+        goals = np.zeros((100, n, 2), dtype=np.uint8)
+        for k in range(100):
+            inst = load_mapf_yaml(os.path.join(REF, "benchmark", "32x32_obst204", "map_32by32_obst204_agents%d_ex%d.yaml" % (n, k)))
+            assert inst["dimx"] == 32 and inst["dimy"] == 32 and len(inst["obstacles"]) == 204 and len(inst["starts"]) == n
+            obst[k] = inst["obstacles"]
+            starts[k] = inst["starts"]
+            goals[k] = inst["goals"]
+            jobs.append(("map_32by32_obst204_agents%d_ex%d" % (n, k), inst))
+        arrays["obst%d" % n] = obst
+        arrays["starts%d" % n] = starts
+        arrays["goals%d" % n] = goals
+    np.savez_compressed(os.path.join(OUT, "shipped_32x32.npz"), **arrays)
+    jobs.sort(key=lambda j: -len(j[1]["starts"]))  # the heavy ones first
+    with ProcessPoolExecutor(max_workers=7) as pool:
+        res = list(pool.map(_solve_shipped, jobs, chunksize=4))
+    exp = dict(res)
+    with open(os.path.join(OUT, "shipped_32x32_expected.json"), "w") as f:
+        json.dump(exp, f, separators=(",", ":"), sort_keys=True)
+    return exp
+
+
+def _solve_shipped(job):
+    import oracle
+    name, inst = job
+    r = oracle.mapf_solve(oracle.ECBS, inst, w=1.3, cap_total=3_000_000, path_cap=1024)
+    return name, summarize(r)
+
+
+def _solve_cbs_1e6(job):
+    import oracle
+    name, inst = job
+    return name, summarize(oracle.mapf_solve(oracle.CBS, inst, cap_total=1_000_000, path_cap=1024))
+
+
+def cbs_8x8_cap1e6():
+    from concurrent.futures import ProcessPoolExecutor
+    jobs = []
+    for n in (10, 12, 16, 20):
+        for k in range(4):
+            name = "map_8by8_obst12_agents%d_ex%d" % (n, k)
+            jobs.append((name, load_mapf_yaml(os.path.join(REF, "benchmark", "8x8_obst12", name + ".yaml"))))
+    with ProcessPoolExecutor(max_workers=7) as pool:
+        exp = dict(pool.map(_solve_cbs_1e6, jobs))
+    with open(os.path.join(OUT, "cbs_8x8_cap1e6.json"), "w") as f:
+        json.dump(exp, f, separators=(",", ":"), sort_keys=True)
+    return exp
+
+
+def ll_jobs(instances):
+    """~200 low-level calls with their oracle results: 32x32 ECBS w=1.3 (agents 10..50), 8x8 CBS and ECBS w=1."""
+    import oracle
+    picks = [("map_32by32_obst204_agents10_ex%d" % k, oracle.ECBS, 1.3, 8) for k in range(0, 60, 4)]
+    picks += [("map_32by32_obst204_agents20_ex%d" % k, oracle.ECBS, 1.3, 6) for k in range(4)]
+    picks += [("map_32by32_obst204_agents30_ex%d" % k, oracle.ECBS, 1.3, 4) for k in range(3)]
+    picks += [("map_32by32_obst204_agents50_ex%d" % k, oracle.ECBS, 1.3, 4) for k in range(3)]
+    picks += [("map_8by8_obst12_agents%d_ex%d" % (n, k), oracle.CBS, 1.0, 4) for n in (4, 6, 8) for k in range(2)]
+    picks += [("map_8by8_obst12_agents%d_ex%d" % (n, k), oracle.ECBS, 1.0, 3) for n in (5, 8) for k in range(2)]
+    out = []
+    for name, algo, w, take in picks:
+        inst = instances[name]
+        _, calls = oracle.mapf_record(algo, inst, w=w, cap_total=300_000)
+        # the last calls of a tree carry the most constraints; keep a spread
+        idx = sorted(set([0, len(calls) - 1] + [int(i * (len(calls) - 1) / max(take - 1, 1)) for i in range(take)]))[:take]
+        for i in idx:
+            c = calls[i]
+            out.append(dict(instance=name, algo="ecbs" if algo == oracle.ECBS else "cbs", w=w, agent=c["agent"],
+                            vertex_constraints=c["vertex_constraints"], edge_constraints=c["edge_constraints"],
+                            ctx_paths=c["ctx_paths"] if algo == oracle.ECBS else [], success=c["success"], cost=c["cost"],
+                            fmin=c["fmin"], expanded=c["expanded"], states=c["states"]))
+    with open(os.path.join(OUT, "ll_jobs.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    return out
+
+
 if __name__ == "__main__":
+    if "--shipped" in sys.argv:  # only the round-3 additions (the other files are unchanged)
+        with open(os.path.join(OUT, "bench_instances.json")) as f:
+            inst = json.load(f)
+        print("ll jobs", len(ll_jobs(inst)))
+        print("cbs 8x8 cap 1e6", cbs_8x8_cap1e6())
+        exp = shipped_corpus()
+        print("shipped: %d instances, %d capped" % (len(exp), sum(1 for v in exp.values() if v["rc"] != 1)))
+        sys.exit(0)
     with open(os.path.join(OUT, "ref_tests.json"), "w") as f:
         json.dump(ref_tests(), f, separators=(",", ":"))
     inst = bench_instances()

@@ -165,3 +165,21 @@ def test_tight_limits_hand_over_cleanly(emu, oracle_mod, bench_instances):
     d2, o2 = _replay(emu, oracle_mod, inst, oracle_mod.ECBS, 1.3, max_t=12)
     d3, o3 = _replay(emu, oracle_mod, inst, oracle_mod.ECBS, 1.3, open_cap=4)
     assert o1 > 0 and o2 > 0 and d1 > 0 and d3 == 0, (d1, o1, d2, o2, d3, o3)
+
+
+def test_golden_low_level_jobs_through_the_emulated_tier(emu, bench_instances, ll_jobs_golden):
+    """tests/golden/ll_jobs.json (committed inputs and oracle outputs) through the emulated tier: no oracle involved."""
+    n = 0
+    for j in ll_jobs_golden:
+        inst = bench_instances[j["instance"]]
+        a = j["agent"]
+        eps = j["algo"] == "ecbs"
+        r = emu_search(emu, eps, inst, a, inst["starts"][a], inst["goals"][a], j["vertex_constraints"], j["edge_constraints"],
+                       j["ctx_paths"] if eps else [], j["w"], lds_path_bytes=8192)
+        if r["status"] == -1:
+            continue
+        n += 1
+        assert (r["status"] == 0, r["expanded"]) == (j["success"], j["expanded"]), (j["instance"], a)
+        if j["success"]:
+            assert (r["cost"], r["fmin"], r["states"]) == (j["cost"], j["fmin"], j["states"]), (j["instance"], a)
+    assert n >= 190

@@ -232,3 +232,46 @@ def test_caller_stepped_conflict_tree_on_the_gpu(bench_instances, oracle_expecte
                     hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"], e["digest"]), (n, k)
         finally:
             run.close()
+
+
+def test_all_1000_shipped_32x32_inputs(solver, shipped_corpus):
+    """The corpus BASELINE.json's north_star names, whole: every shipped benchmark/32x32_obst204 input (agents10..100 x
+    ex0..99) as one batch against tests/golden/shipped_32x32_expected.json (our oracle, cap 3 000 000: agents100_ex36 runs
+    into it on both sides)."""
+    from libmultirobotplanning_amd import hl
+    corpus, exp = shipped_corpus
+    assert len(corpus) == 1000
+    res, stats = solver.solve([i for _, i in corpus], algo=hl.ECBS, w=1.3, max_ll_expansions=3_000_000, path_cap=1024)
+    capped = 0
+    for (n, _), r in zip(corpus, res):
+        e = exp[n]
+        if e["rc"] == 1:
+            assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
+                hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"]), n
+            assert _digest(r["paths"]) == e["digest"], n
+        else:
+            capped += 1
+            assert r["status"] == hl.CAP, n
+    assert capped == 1 and exp["map_32by32_obst204_agents100_ex36"]["rc"] != 1
+
+
+def test_cbs_8x8_at_the_surveys_cap(solver, bench_instances):
+    """CBS on shipped 8x8_obst12 inputs with a cap of 1 000 000 low-level expansions per instance —
+    agents10 / 12 inputs that need hundreds of thousands of expansions get real parity, agents16 / 20 cap on both sides."""
+    import json
+    import os
+    from libmultirobotplanning_amd import hl
+    with open(os.path.join(os.path.dirname(__file__), "golden", "cbs_8x8_cap1e6.json")) as f:
+        exp = json.load(f)
+    names = sorted(exp)
+    res, _ = solver.solve([bench_instances[n] for n in names], algo=hl.CBS, max_ll_expansions=1_000_000)
+    solved = 0
+    for n, r in zip(names, res):
+        e = exp[n]
+        if e["rc"] == 1:
+            solved += 1
+            assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"], _digest(r["paths"])) == (
+                hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"], e["digest"]), n
+        else:
+            assert r["status"] == hl.CAP, n
+    assert solved >= 6

@@ -831,3 +831,48 @@ def test_sipp_commit_paths_into_tables(oracle_mod):
     for it in insts:
         eng.sipp_table_destroy(it.h)
     eng.close()
+
+
+def test_golden_low_level_jobs(engine, bench_instances, ll_jobs_golden):
+    """~200 committed low-level calls (inputs and the oracle's outputs, tests/golden/ll_jobs.json): low-level parity that
+    does not need the oracle to be rebuilt on the GPU box."""
+    from libmultirobotplanning_amd import ll
+    assert len(ll_jobs_golden) >= 200
+    for algo_name, algo_ll in (("ecbs", ll.ASTAR_EPS), ("cbs", ll.ASTAR)):
+        for w in sorted({j["w"] for j in ll_jobs_golden if j["algo"] == algo_name}):
+            cases = [(j["instance"], bench_instances[j["instance"]], j) for j in ll_jobs_golden
+                     if j["algo"] == algo_name and j["w"] == w]
+            _run_and_compare(engine, cases, algo_ll, w)
+
+
+def test_zero_initialised_job_struct(oracle_mod, bench_instances):
+    """A job that was memset to zero (the adapter of INTEGRATION.md: `mrp_ll_job job{}`) is a plain search: it stores its
+    path nowhere — with and without a reserved path store."""
+    import ctypes
+    import numpy as np
+    from libmultirobotplanning_amd import ll
+    inst = bench_instances["map_32by32_obst204_agents10_ex1"]
+    want = oracle_mod.ll_search(oracle_mod.ASTAR_EPS, dict(dimx=32, dimy=32, obstacles=inst["obstacles"]), 0,
+                                inst["starts"][0], inst["goals"][0], w=1.3)
+    lib = ll.load_library()
+    for reserve in (0, 64):
+        eng = ll.LowLevelEngine(device=0, n_tickets=1, slots=8)
+        try:
+            mid = eng.upload_map(32, 32, inst["obstacles"])
+            if reserve:
+                assert lib.mrp_ll_path_store_reserve(eng._h, reserve) == 0
+            job = ll.mrp_ll_job()
+            ctypes.memset(ctypes.byref(job), 0, ctypes.sizeof(job))
+            job.map_id, job.algo, job.w = mid, ll.ASTAR_EPS, 1.3
+            job.start_x, job.start_y = inst["starts"][0]
+            job.goal_x, job.goal_y = inst["goals"][0]
+            job.max_expansions = -1
+            res = ll.mrp_ll_result()
+            ctypes.memset(ctypes.byref(res), 0, ctypes.sizeof(res))
+            states = np.zeros((256, 3), dtype=np.int32)
+            res.states_txy = states.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+            res.states_cap = 256
+            assert lib.mrp_ll_search_batch(eng._h, 1, ctypes.byref(job), ctypes.byref(res)) == 0
+            assert (res.status, res.cost, res.expanded) == (ll.OK, want["cost"], want["expanded"])
+        finally:
+            eng.close()
