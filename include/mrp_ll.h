@@ -50,6 +50,13 @@ extern "C" {
                            /* a batch (or a session, mrp_ll_session_begin_sipp) holds either SIPP jobs or A-star     */
                            /* jobs, not both                                                                         */
 
+#define MRP_LL_ASTAR_TA 3  /* a_star.hpp AStar::search over the Environment of example/cbs_ta.cpp:283-372 — the low level of */
+                           /* the task-assignment callers (cbs_ta.hpp:106-109,155-158,196-199; ecbs_ta's Environment is the */
+                           /* same): optional goal (MRP_LL_JOB_NO_GOAL), h = an uploaded shortest-path table               */
+                           /* (mrp_ll_upload_heuristic), Wait costs 0 at the goal, so g != time and decrease-key is live.  */
+                           /* Maps up to 32 x 32, at most 64 vertex and 64 edge constraints, time steps <= 61, f <= 254,   */
+                           /* 1023 open nodes; beyond that a job ends with MRP_LL_CAP_NODES / MRP_LL_CAP_HORIZON.          */
+
 /* ---- per-job status (mrp_ll_result.status) ----------------------------------------------------------------- */
 #define MRP_LL_OK 0             /* search() returned true                                                    */
 #define MRP_LL_NO_SOLUTION 1    /* search() returned false: open list exhausted (a_star.hpp:160)              */
@@ -131,9 +138,15 @@ typedef struct mrp_ll_job {
   const int32_t* path_ids;
   int32_t result_path_id;  /* with MRP_LL_JOB_STORE_RESULT: the slot (0 .. n_slots-1) that also receives the result path */
   int32_t flags;           /* MRP_LL_JOB_* bits; 0 = none */
+  /* MRP_LL_ASTAR_TA only: the shortest-path table of this job's goal cell (mrp_ll_upload_heuristic); ignored with
+   * MRP_LL_JOB_NO_GOAL.  (Zero-initialised jobs of the other algorithms never look at it.) */
+  int32_t heuristic_id;
+  int32_t reserved3;
 } mrp_ll_job;
 
 #define MRP_LL_JOB_STORE_RESULT 1 /* mrp_ll_job.flags: also leave the result path in path-store slot result_path_id */
+#define MRP_LL_JOB_NO_GOAL 2      /* mrp_ll_job.flags, MRP_LL_ASTAR_TA: the agent has no task (cbs_ta.cpp:283-319: h = 0, every
+                                   * cell ends the search once time > the agent's last vertex constraint, every Wait is free) */
 
 typedef struct mrp_ll_result {
   int32_t status;   /* MRP_LL_OK ... */
@@ -145,8 +158,9 @@ typedef struct mrp_ll_result {
   int32_t* actions;    /* caller buffer [states_cap]    = MRP_LL_ACT_* ; may be NULL                          */
   int32_t states_cap;
   int32_t tier;     /* 0 = finished in the LDS tier, 1 = run by the arena tier (diagnostic)                    */
-  int32_t* action_costs; /* caller buffer [states_cap] or NULL: PlanResult::actions[k].second (always 1 for the
-                          * A-star algorithms; Wait durations for MRP_LL_SIPP, sipp.hpp:105-128)                 */
+  int32_t* action_costs; /* caller buffer [states_cap] or NULL: PlanResult::actions[k].second (always 1 for
+                          * MRP_LL_ASTAR / _EPS; 0 for a Wait at the goal with MRP_LL_ASTAR_TA; Wait durations for
+                          * MRP_LL_SIPP, sipp.hpp:105-128)                                                     */
 } mrp_ll_result;
 
 typedef struct mrp_ll_stats {
@@ -173,6 +187,12 @@ const char* mrp_ll_last_error(const mrp_ll_ctx* ctx);
 /* Static map (Environment ctor, ecbs.cpp:249-259): obstacles as [n][2] = x, y.  Uploaded once, used by any job. */
 int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t n_obstacles, const int32_t* obstacles_xy,
                       int32_t* map_id);
+
+/* MRP_LL_ASTAR_TA: the heuristic of one goal cell of map `map_id` — dist[dimy][dimx] (row-major, dist[y * dimx + x]) =
+ * ShortestPathHeuristic::getValue(cell, goal) (example/shortest_path_heuristic.hpp:56-60: all-pairs shortest paths on the
+ * free cells; INT32_MAX = unreachable).  Computing it is the caller's business (the reference does it once per
+ * Environment, cbs_ta.cpp:267); the engine keeps it next to the maps.  MRP_LL_E_BUSY during a session. */
+int mrp_ll_upload_heuristic(mrp_ll_ctx* ctx, int32_t map_id, const int32_t* dist, int32_t* heuristic_id);
 
 /* Copies every map uploaded so far to the device now (otherwise done lazily by the next submit / session_begin). */
 int mrp_ll_sync_maps(mrp_ll_ctx* ctx);

@@ -85,10 +85,12 @@ struct CJob {              // at oJob of the window; pointers as two words
   uint32_t nAgentsPad, tPad;  // focal context: table [tPad][nAgentsPad] of x | y << 8 halfwords (0xFFFF = nobody); <= 128 agents
   uint32_t maxExp;         // 0xFFFFFFFF = unlimited
   uint32_t openCap, maxT;  // limits of this job inside the tier: <= kCap open entries, expanded nodes at t <= maxT <= kMaxT
+  uint32_t taNoGoal;       // compactSearchTA: the agent has no task (cbs_ta.cpp:283-319)
   uint64_t vc;             // const uint32_t*: t << 16 | y << 8 | x
   uint64_t ec;             // const uint32_t*: t << 19 | (y * dimx + x) << 3 | k   (k = index in Wait, Left, Right, Up, Down)
   uint64_t obst;           // const uint32_t*: the map's obstacle bitmap, bit y * dimx + x
-  uint64_t pathsG;         // const uint16_t*: the path table when it is not in the window (PLDS = false)
+  uint64_t pathsG;         // const uint16_t*: the path table when it is not in the window (PLDS = false);
+                           // compactSearchTA: the shortest-path table of the task's cell, [y * 32 + x] halfwords
   uint64_t parentTab;      // uint8_t*: kParentBytes of device memory, action byte per (t, cell)
   uint64_t outPath;        // uint16_t*: x | y << 8 per time step
 };
@@ -682,6 +684,223 @@ WV_ENTRY int32_t compactSearch(Lds window) {
   ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, expanded), expansions);
   ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, nodes), nodes);
   MRP_CT_PROF_STORE(lds);
+  sync();
+  return status;
+}
+
+// ---- the low level of the task-assignment callers ----------------------------------------------
+// AStar::search (a_star.hpp:63-161) over the Environment of example/cbs_ta.cpp:283-372,483-496 (cbs_ta.hpp:106-109,
+// 155-158,196-199; ecbs_ta's low level shares the Environment):
+//   * the task (goal) is optional: without one h = 0, every cell is a goal cell, and the search may end as soon as
+//     time > the time of the agent's LAST vertex constraint of any cell (setLowLevelContext :283-303, isSolution :313-319);
+//   * h = shortest-path distance to the task's cell from an uploaded table (shortest_path_heuristic.hpp:56-60);
+//   * Wait costs 0 at the goal cell (everywhere without a task), every other action 1 (getNeighbors :321-367).
+// So g != time: a state (time, cell) can be discovered again with a smaller g, and the decrease-key branch
+// a_star.hpp:139-145 is live.  Entry:  [30:23] 255 - f   [22:16] g   [15:10] time   [9:0] cell = y * 32 + x  (open order
+// a_star.hpp:168-179: f asc, g desc).  The (time, cell) bitmap holds "discovered" only (obstacles: the obstacle row;
+// vertex constraints: one key per lane, like the edge constraints), and a discovered successor is looked up in the open
+// array by the same scan that openSet.erase uses in compactSearch: found = still open, with its g in the entry (then
+// `openSet.increase(handle)` = a sift-up from that position); not found = closed.  cameFrom is the same byte table,
+// overwritten when a state is re-parented.  No arena tier behind this one: a search that outgrows the window, or an f above
+// 254, ends with a capacity status.
+constexpr uint32_t kTaKm = 0x7FFF0000u;
+enum : int32_t { C_CAP_NODES = 3, C_CAP_HORIZON = 4 };
+WV_ENTRY int32_t compactSearchTA(Lds window) {
+  const Lds lds = windowBase(window);
+  const Sides S = makeSides();
+  const V lane = S.lane;
+  const V hbO = splat(oOpen + 4u), kmO = splat(kTaKm);  // one heap: both sides of the wave do the same work on it
+  const uint32_t dimx = MRP_CT_JOB_U32(lds, dimx), dimy = MRP_CT_JOB_U32(lds, dimy);
+  const uint32_t gx = MRP_CT_JOB_U32(lds, gx), gy = MRP_CT_JOB_U32(lds, gy);
+  const uint32_t nEc = MRP_CT_JOB_U32(lds, nEc), nVc = MRP_CT_JOB_U32(lds, nVc);
+  const bool noGoal = MRP_CT_JOB_U32(lds, taNoGoal) != 0u;
+  int32_t status = C_NO_SOLUTION, cost = 0, fmin = 0, nStates = 0;
+  uint32_t nOpen = 1, nodes = 1, expansions = 0;
+  sync();
+  {  // obstacle row (stride 32) as in compactSearch
+    const uint32_t* obst = MRP_CT_JOB_PTR(const uint32_t, lds, obst);
+    const uint32_t obstWords = MRP_CT_JOB_U32(lds, obstWords);
+    const V y = S.l5;
+    const V bitOff = y * dimx;
+    const V wi = bitOff >> 5, sh = bitOff & 31u;
+    const B rowIn = (y < dimy) & !S.isB;
+    const V lo = gLoad32m(obst, wi, rowIn & (wi < obstWords));
+    const V hi = gLoad32m(obst, wi + 1u, rowIn & ((wi + 1u) < obstWords));
+    V w = sel(sh == 0u, lo, (lo >> sh) | (hi << (splat(32u) - sh)));
+    const uint32_t colMask = dimx >= 32u ? 0xFFFFFFFFu : ((1u << dimx) - 1u);
+    w = (w & colMask) | ~colMask;
+    w = sel(rowIn, w, splat(0xFFFFFFFFu));
+    ldsStore32m(lds, splat(oObst) + y * 4u, w, !S.isB);
+  }
+  {  // open list: every slot "no element"; (time, cell) bitmap: nothing discovered; heuristic table into the window
+    const V4 none{splat(kEmpty), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
+    const V4 head{sel(lane == 0u, splat(kFront), splat(kEmpty)), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
+    const V4 zero{splat(0u), splat(0u), splat(0u), splat(0u)};
+    ldsStore128(lds, splat(oOpen) + lane * 16u, head);
+    for (uint32_t g = 1; g < kGroups; ++g) ldsStore128(lds, splat(oOpen + g * 1024u) + lane * 16u, none);
+    ldsStore128m(lds, splat(oOpen + kGroups * 1024u), none, lane == 0u);
+    for (uint32_t i = 0; i < kRows / 8u; ++i) ldsStore128(lds, splat(oBits + i * 1024u) + lane * 16u, zero);
+    if (!noGoal) {
+      const uint32_t* heur = (const uint32_t*)MRP_CT_JOB_PTR(const uint16_t, lds, pathsG);
+      for (uint32_t q = 0; q < 8u; ++q) ldsStore32(lds, splat(oPaths + q * 256u) + lane * 4u, gLoad32m(heur, splat(q * 64u) + lane, bsplat(true)));
+    }
+  }
+  sync();
+  // constraint keys, one per lane each: vertex t << 16 | y << 8 | x, edge t << 19 | (y * dimx + x) << 3 | k; they pass
+  // through the window so that the loop holds no register a vector-memory load is still writing
+  V vcReg = splat(0xFFFFFFFFu), ecReg = splat(0xFFFFFFFFu);
+  {
+    const uint32_t* vc = MRP_CT_JOB_PTR(const uint32_t, lds, vc);
+    const uint32_t* ec = MRP_CT_JOB_PTR(const uint32_t, lds, ec);
+    ldsStore32(lds, splat(oAux) + lane * 4u, sel(lane < nVc, gLoad32m(vc, lane, lane < nVc), splat(0xFFFFFFFFu)));
+    ldsStore32(lds, splat(oAux + 256u) + lane * 4u, sel(lane < nEc, gLoad32m(ec, lane, lane < nEc), splat(0xFFFFFFFFu)));
+    sync();
+    vcReg = ldsLoad32(lds, splat(oAux) + lane * 4u);
+    ecReg = ldsLoad32(lds, splat(oAux + 256u) + lane * 4u);
+    sync();
+  }
+  const V dx = sel(lane == 1u, splat(0xFFFFFFFFu), sel(lane == 2u, splat(1u), sel(lane < 5u, splat(0u), splat(0x4000u))));
+  const V dy = sel(lane == 3u, splat(1u), sel(lane == 4u, splat(0xFFFFFFFFu), splat(0u)));
+  const int32_t lastGoal = (int32_t)MRP_CT_JOB_U32(lds, lastGoal);
+  const uint32_t maxExp = MRP_CT_JOB_U32(lds, maxExp), openCap = MRP_CT_JOB_U32(lds, openCap), maxT = MRP_CT_JOB_U32(lds, maxT);
+  uint8_t* parentTab = MRP_CT_JOB_PTR(uint8_t, lds, parentTab);
+  const uint32_t goalCell = gx | (gy << 5);
+  {
+    const uint32_t sx = MRP_CT_JOB_U32(lds, sx), sy = MRP_CT_JOB_U32(lds, sy);
+    const uint32_t sc = sx | (sy << 5);
+    const uint32_t h0 = noGoal ? 0u : first(ldsLoadU16(lds, splat(oPaths + sc * 2u)));
+    if (h0 > 254u) status = C_CAP_HORIZON;  // (the start cannot reach its task at all, or not within this tier's f)
+    ldsStoreS(lds, oOpen + 4u, ((255u - (h0 & 255u)) << 23) | (0u << 16) | (0u << 10) | sc);
+  }
+  sync();
+
+  while (status == C_NO_SOLUTION) {
+    if (nOpen == 0u) break;  // open list exhausted: search() returns false (a_star.hpp:160)
+    const uint32_t curE = ldsLoadS(lds, oOpen + 4u);
+    const uint32_t cell = curE & 1023u, t = (curE >> 10) & 63u, g = (curE >> 16) & 127u, fCur = 255u - (curE >> 23);
+    const uint32_t x = cell & 31u, y = cell >> 5;
+    const bool atGoal = noGoal || cell == goalCell;
+    expansions += 1u;  // onExpandNode (a_star.hpp:87)
+    if (expansions > maxExp) {
+      status = C_CAP_EXP;
+      break;
+    }
+    if (atGoal && (int32_t)t > lastGoal) {  // isSolution (cbs_ta.cpp:313-319) -> a_star.hpp:89-106
+      status = C_OK;
+      cost = (int32_t)g;
+      fmin = (int32_t)fCur;
+      nStates = (int32_t)t + 1;
+      uint16_t* outPath = MRP_CT_JOB_PTR(uint16_t, lds, outPath);
+      sync();
+      uint32_t c = cell;
+      const uint32_t* tab32 = (const uint32_t*)parentTab;
+      for (int32_t k0 = (int32_t)t; k0 >= 1; k0 -= 8) {
+        V rowW[8][4];
+        for (int32_t r = 0; r < 8; ++r)
+          for (uint32_t q = 0; q < 4; ++q)
+            rowW[r][q] = (k0 - r >= 1) ? gLoad32Coherent(tab32, splat((uint32_t)(k0 - r) * 256u + q * 64u) + lane) : splat(0u);
+        for (int32_t r = 0; r < 8; ++r)
+          for (uint32_t q = 0; q < 4; ++q) ldsStore32(lds, splat(oBits + (uint32_t)r * 1024u + q * 256u) + lane * 4u, rowW[r][q]);
+        sync();
+        for (int32_t r = 0; r < 8 && k0 - r >= 1; ++r) {
+          gStoreU16m(outPath, splat((uint32_t)(k0 - r)), splat((c & 31u) | ((c >> 5) << 8)), lane == 0u);
+          const uint32_t a = first(ldsLoadU8(lds, splat(oBits + (uint32_t)r * 1024u + c)));
+          c = a == 1u ? c + 1u : a == 2u ? c - 1u : a == 3u ? c - 32u : a == 4u ? c + 32u : c;
+        }
+        sync();
+      }
+      gStoreU16m(outPath, splat(0u), splat((c & 31u) | ((c >> 5) << 8)), lane == 0u);
+      break;
+    }
+    if (nOpen + 5u > openCap) {
+      status = C_CAP_NODES;
+      break;
+    }
+    if (t > maxT) {
+      status = C_CAP_HORIZON;
+      break;
+    }
+    // openSet.pop() (a_star.hpp:109): the last element goes to the root and sifts down
+    {
+      nOpen -= 1u;
+      const uint32_t last = ldsLoadS(lds, oOpen + 4u + 4u * nOpen);
+      ldsStoreS(lds, oOpen + 4u + 4u * nOpen, kEmpty);
+      const V hole = dualDescend<false>(lds, S, hbO, kmO, splat(kHeapClamp), splat(last & kTaKm));
+      if (nOpen) ldsStoreS(lds, oOpen + 4u + 4u * first(hole), last);
+    }
+    // getNeighbors (cbs_ta.cpp:321-367): the five probes on lanes 0..4 — bounds, obstacle, vertex constraint (stateValid),
+    // edge constraint (transitionValid) — then, in order, the new / rediscovered / closed cases of a_star.hpp:116-153
+    const uint32_t t1 = t + 1u;
+    const V nx = splat(x) + dx, ny = splat(y) + dy;
+    const B inb = (nx < dimx) & (ny < dimy);
+    const V ncell = (nx & 31u) | ((ny & 31u) << 5);
+    const V obstW = ldsLoad32(lds, splat(oObst) + ((ny & 31u) << 2));
+    const V wordAddr = splat(oBits + t1 * kRowBytes) + ((ny & 31u) << 2);
+    const V seenW = ldsLoad32(lds, wordAddr);
+    const V hN = noGoal ? splat(0u) : ldsLoadU16(lds, splat(oPaths) + ncell * 2u);
+    uint32_t mask = lo32(ballot(inb & (((obstW >> (nx & 31u)) & 1u) == 0u))) & 0x1Fu;
+    if (nVc) {
+      const V nkey = (t1 << 16) | ((ny & 0xFFu) << 8) | (nx & 0xFFu);
+      for (uint32_t mm = mask; mm; mm &= mm - 1u) {
+        const uint32_t k = ctz32(mm);
+        if (ballot(vcReg == readlane(nkey, k))) mask &= ~(1u << k);
+      }
+    }
+    if (nEc) {
+      const uint32_t base = (t << 19) | ((y * dimx + x) << 3);
+      const V d = ecReg - base;
+      if (ballot(d < 5u))
+        for (uint32_t k = 0; k < 5u; ++k)
+          if (ballot(d == k)) mask &= ~(1u << k);
+    }
+    const uint32_t seenMask = lo32(ballot(((seenW >> (nx & 31u)) & 1u) != 0u));
+    for (uint32_t mm = mask; mm && status == C_NO_SOLUTION; mm &= mm - 1u) {
+      const uint32_t k = ctz32(mm);
+      const uint32_t nc = readlane(ncell, k), h = readlane(hN, k);
+      const uint32_t g2 = g + ((k == 0u && atGoal) ? 0u : 1u);  // tentative_gScore (a_star.hpp:118)
+      const uint32_t id = (t1 << 10) | nc;
+      if (!((seenMask >> k) & 1u)) {  // not in the open list, not closed: a new node (a_star.hpp:120-129)
+        const uint32_t f2 = g2 + h;
+        if (h > 254u || f2 > 254u || g2 > 127u) {
+          status = C_CAP_HORIZON;
+          break;
+        }
+        ldsOr32m(lds, wordAddr, splat(1u) << (nx & 31u), lane == k);
+        gStore8m(parentTab, splat(id), splat(k), lane == 0u);
+        dualSiftUp(lds, S, hbO, kmO, splat(nOpen + 1u), ((255u - f2) << 23) | (g2 << 16) | id, false, false);
+        nOpen += 1u;
+        nodes += 1u;
+        continue;
+      }
+      // discovered before: still in the open list (then its entry says with which g), or closed (a_star.hpp:117)
+      uint32_t p = 0xFFFFFFFFu, eOld = 0;
+      for (uint32_t grp = 0; grp < kGroups && grp * 256u <= nOpen; ++grp) {  // (element 256 grp - 1 belongs to group grp)
+        const V4 q = ldsLoad128(lds, splat(oOpen + grp * 1024u) + lane * 16u);
+        const B m0 = (q.x & 0xFFFFu) == id, m1 = (q.y & 0xFFFFu) == id, m2 = (q.z & 0xFFFFu) == id, m3 = (q.w & 0xFFFFu) == id;
+        const uint64_t any = ballot(m0 | m1 | m2 | m3);
+        if (any) {
+          const uint32_t l = ctz64(any);
+          const V pos = lane * 4u + sel(m0, splat(0xFFFFFFFFu), sel(m1, splat(0u), sel(m2, splat(1u), splat(2u))));
+          const V ent = sel(m0, q.x, sel(m1, q.y, sel(m2, q.z, q.w)));
+          p = grp * 256u + readlane(pos, l);
+          eOld = readlane(ent, l);
+          break;
+        }
+      }
+      if (p == 0xFFFFFFFFu) continue;  // closed
+      const uint32_t gOld = (eOld >> 16) & 127u;
+      if (g2 >= gOld) continue;        // not an improvement (a_star.hpp:135-137)
+      const uint32_t fNew = (255u - (eOld >> 23)) - (gOld - g2);  // fScore -= delta (a_star.hpp:141-142)
+      gStore8m(parentTab, splat(id), splat(k), lane == 0u);       // cameFrom is replaced (a_star.hpp:150-152)
+      dualSiftUp(lds, S, hbO, kmO, splat(p + 1u), ((255u - fNew) << 23) | (g2 << 16) | id, false, false);  // increase(handle)
+    }
+  }
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, status), (uint32_t)status);
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, cost), (uint32_t)cost);
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, fmin), (uint32_t)fmin);
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, nStates), (uint32_t)nStates);
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, expanded), expansions);
+  ldsStoreS(lds, oRes + (uint32_t)offsetof(CRes, nodes), nodes);
   sync();
   return status;
 }

@@ -65,6 +65,9 @@ constexpr uint32_t kCtxById = 1u;
 // (n_vc = room per record of this job: the longest list among its records, as a power of two >= 2).
 // n_ctx = the job's epoch (1..255).  One job per table in flight.  The workgroup finds the start interval itself
 // (findSafeInterval, sipp.hpp:286-296) — the host's copy of the table may be behind the device's (kSippCommit).
+constexpr uint32_t kTaNoGoal = 16u;                                // MRP_LL_ASTAR_TA: ctx_flags bit 4: the agent has no task; path_off =
+                                                                   // word offset of the goal's heuristic table in the maps buffer
+constexpr uint32_t kHeurWords = 512;                               // a heuristic table: [32][32] halfwords (0xFFFF: unreachable)
 constexpr uint32_t kSippResident = 2u;
 constexpr uint32_t kSippCommit = 8u;                               // ctx_flags bit 3: on success the workgroup adds the path's stays to the table
 constexpr uint32_t kSippTierCommitFailed = 0x100u;                 // DevResult.tier flag: a stay did not fit (more than kSippCap intervals,

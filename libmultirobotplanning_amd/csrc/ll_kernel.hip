@@ -1270,6 +1270,51 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
 }
 
 
+// MRP_LL_ASTAR_TA: the low level of the task-assignment callers, served by the compact tier alone
+// (ll_compact.h compactSearchTA).  The job's constraint words are read where the host put them; the goal's shortest-path
+// table sits in the maps buffer (mrp_ll_upload_heuristic).
+DEVI void runJobTA(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t* arenaSlot, DevResult& res, uint16_t* outPath) {
+  res.tier = 0;
+  if (P.lds_nodes == 0 || P.lds_paths_bytes < 2048u || J.dimx > 32u || J.dimy > 32u || J.n_vc > 64u || J.n_ec > 64u ||
+      (uint64_t)P.arena_nodes * 16u < ct::kParentBytes) {
+    res.status = ST_BAD;  // (the host packer refuses such a job; a context without the compact tier cannot run it)
+    return;
+  }
+  ct::CJob cj;
+  cj.dimx = J.dimx; cj.dimy = J.dimy; cj.sx = J.sx; cj.sy = J.sy; cj.gx = J.gx; cj.gy = J.gy;
+  cj.lastGoal = J.last_goal_constraint;
+  cj.w = 1.0f;
+  cj.nVc = J.n_vc; cj.nEc = J.n_ec;
+  cj.obstWords = J.words_per_row;
+  cj.nAgentsPad = 0; cj.tPad = 0;
+  cj.maxExp = J.max_expansions < 0 ? 0xFFFFFFFFu : (J.max_expansions > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)J.max_expansions);
+  cj.openCap = P.lds_nodes / 2u < ct::kCap ? P.lds_nodes / 2u : ct::kCap;
+  cj.maxT = P.lds_rows >= 3u && P.lds_rows - 2u < ct::kMaxT ? P.lds_rows - 2u : ct::kMaxT;
+  cj.taNoGoal = (J.ctx_flags & kTaNoGoal) ? 1u : 0u;
+  cj.vc = (uint64_t)(P.cons + J.vc_off); cj.ec = (uint64_t)(P.cons + J.ec_off);
+  cj.obst = (uint64_t)(P.maps + J.map_word_off);
+  cj.pathsG = (uint64_t)(P.maps + J.path_off);
+  cj.parentTab = (uint64_t)arenaSlot;
+  cj.outPath = (uint64_t)outPath;
+  {
+    auto w32 = (__attribute__((address_space(3))) uint32_t*)((wv::Lds)smem + ct::oJob);
+    const uint32_t* src = (const uint32_t*)&cj;
+#pragma unroll
+    for (uint32_t q = 0; q < sizeof(ct::CJob) / 4; ++q) w32[q] = src[q];
+  }
+  const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
+  const int32_t crc = ct::compactSearchTA((wv::Lds)smem);
+  auto r32 = (__attribute__((address_space(3))) const uint32_t*)((wv::Lds)smem + ct::oRes);
+  res.status = crc;  // C_OK / C_NO_SOLUTION / C_CAP_EXP / C_CAP_NODES / C_CAP_HORIZON == the ST_ codes
+  res.cost = (int32_t)rfl(r32[1]);
+  res.fmin = (int32_t)rfl(r32[2]);
+  res.n_states = (int32_t)rfl(r32[3]);
+  res.expanded = rfl(r32[4]);
+  res.nodes_created = rfl(r32[5]);
+  res.prof[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);
+  res.prof[1] = (uint32_t)res.expanded;
+}
+
 // ---- SIPP (config 5): A* over (cell, safe interval) states ---------------------------------------------------
 // Reference: SIPP::search sipp.hpp:91-134 -> AStar::search a_star.hpp:63-161 over SIPPState with
 // SIPPEnvironment::getNeighbors sipp.hpp:191-223 (motions Up, Down, Left, Right of mapf_prioritized_sipp.cpp:99-121;
@@ -2142,12 +2187,15 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
   if (KIND == 0) {
     if (algo == 1)
       runJob<true>(P, J, smem, arenaSlot, res, outPath);
+    else if (algo == 3)
+      runJobTA(P, J, smem, arenaSlot, res, outPath);
     else
       runJob<false>(P, J, smem, arenaSlot, res, outPath);
   } else if (KIND == 1) {
     if (algo == 1) runJob<true>(P, J, smem, arenaSlot, res, outPath);
   } else {
     if (algo == 0) runJob<false>(P, J, smem, arenaSlot, res, outPath);
+    if (algo == 3) runJobTA(P, J, smem, arenaSlot, res, outPath);
   }
   PROF_ADD(res, 5);
 #if !defined(MRP_LL_TRACE) && !defined(MRP_CT_PROF)

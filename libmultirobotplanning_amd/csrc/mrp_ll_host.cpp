@@ -46,6 +46,10 @@ struct MapRec {
   int32_t dimx, dimy;
   uint32_t wpr, wordOff;
 };
+struct HeurRec {  // MRP_LL_ASTAR_TA: shortest-path table of one goal cell, kHeurWords words inside the maps buffer
+  int32_t mapId;
+  uint32_t wordOff;
+};
 
 // Growable pinned host buffer that the device accesses in place (zero-copy staging, see ll_device.h).
 template <typename T>
@@ -191,7 +195,8 @@ struct mrp_ll_ctx {
   int device = 0;
   std::string err;
   std::vector<MapRec> maps;
-  std::vector<uint32_t> mapWords;  // host copy of all obstacle bitmaps
+  std::vector<uint32_t> mapWords;  // host copy of all obstacle bitmaps (and of the heuristic tables of MRP_LL_ASTAR_TA)
+  std::vector<HeurRec> heurs;
   uint32_t* mapsDev = nullptr;
   size_t mapsDevCap = 0;
   bool mapsDirty = false;
@@ -682,7 +687,7 @@ template <class ConsSink, class PathSink>
 bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, DevJob& d) {
   if (j.map_id < 0 || j.map_id >= static_cast<int32_t>(ctx->maps.size())) return false;
   const MapRec& mp = ctx->maps[j.map_id];
-  if (j.algo != MRP_LL_ASTAR && j.algo != MRP_LL_ASTAR_EPS && j.algo != MRP_LL_SIPP) return false;
+  if (j.algo != MRP_LL_ASTAR && j.algo != MRP_LL_ASTAR_EPS && j.algo != MRP_LL_SIPP && j.algo != MRP_LL_ASTAR_TA) return false;
   if (j.algo == MRP_LL_ASTAR_EPS && j.initial_cost != 0) return false;  // AStarEpsilon::search has no initialCost
   if (j.initial_cost < 0) return false;
   auto inGrid = [&](int x, int y) { return x >= 0 && x < mp.dimx && y >= 0 && y < mp.dimy; };
@@ -698,21 +703,35 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   d.words_per_row = mp.wpr;
   d.sx = j.start_x;
   d.sy = j.start_y;
+  const bool taNoGoal = j.algo == MRP_LL_ASTAR_TA && (j.flags & MRP_LL_JOB_NO_GOAL) != 0;
   // a goal outside the grid can never be reached; keep the reference behaviour (search until open is exhausted /
   // capped) by parking it on an unreachable coordinate that still fits the 8-bit fields only if in range
-  if (!inGrid(j.goal_x, j.goal_y)) return false;
-  d.gx = j.goal_x;
-  d.gy = j.goal_y;
+  if (!taNoGoal && !inGrid(j.goal_x, j.goal_y)) return false;
+  d.gx = taNoGoal ? 0 : j.goal_x;
+  d.gy = taNoGoal ? 0 : j.goal_y;
   d.algo = j.algo;
   d.w = j.w;
   d.max_expansions = j.max_expansions;
   if (j.algo == MRP_LL_SIPP) return packSipp(ctx, j, mp, cs, d);
-  // setLowLevelContext (ecbs.cpp:264-274): last vertex constraint on the goal cell
+  if (j.algo == MRP_LL_ASTAR_TA) {
+    // the compact tier serves these jobs, and only it (ll_compact.h compactSearchTA)
+    if (mp.dimx > 32 || mp.dimy > 32 || j.initial_cost != 0) return false;
+    if (!taNoGoal) {
+      if (j.heuristic_id < 0 || j.heuristic_id >= static_cast<int32_t>(ctx->heurs.size()) ||
+          ctx->heurs[j.heuristic_id].mapId != j.map_id)
+        return false;
+      d.path_off = ctx->heurs[j.heuristic_id].wordOff;
+    } else {
+      d.ctx_flags |= mrp::kTaNoGoal;
+    }
+  }
+  // setLowLevelContext (ecbs.cpp:264-274): last vertex constraint on the goal cell (cbs_ta.cpp:283-303: of ANY cell when
+  // the agent has no task)
   int lastGoal = -1;
   d.vc_off = static_cast<uint32_t>(cs.size());
   for (int i = 0; i < j.n_vertex_constraints; ++i) {
     const int32_t* v = j.vertex_constraints + 3 * i;
-    if (v[1] == j.goal_x && v[2] == j.goal_y) lastGoal = std::max(lastGoal, v[0]);
+    if (taNoGoal || (v[1] == j.goal_x && v[2] == j.goal_y)) lastGoal = std::max(lastGoal, v[0]);
     if (v[0] < 0 || v[0] >= horizon || !inGrid(v[1], v[2])) continue;  // can never match a generated state
     cs.push((static_cast<uint32_t>(v[0]) << 16) | (static_cast<uint32_t>(v[2]) << 8) | static_cast<uint32_t>(v[1]));  // t, y, x
   }
@@ -728,6 +747,15 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   }
   d.n_ec = static_cast<uint32_t>(cs.size()) - d.ec_off;
   if (cs.failed) return false;
+  if (j.algo == MRP_LL_ASTAR_TA) {  // one constraint key per lane of the wave (mrp_ll.h)
+    const uint32_t heurOff = d.path_off;
+    if (d.n_vc > 64 || d.n_ec > 64) return false;
+    d.n_agents_pad = 0;
+    d.t_pad = 0;
+    d.path_off = heurOff;
+    d.store_out_id = mrp::kNoStoreSlot;
+    return true;
+  }
   // focal context: time-major table of the other agents' cells, each path extended by its last cell
   d.n_agents_pad = 0;
   d.t_pad = 0;
@@ -861,7 +889,9 @@ void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool r
   r.status = d.status;
   r.cost = d.cost;
   r.fmin = d.fmin;
-  if (d.status == mrp::ST_OK && init != 0) {
+  if (init & 0x40000000) {
+    // not an initial cost: the goal of an MRP_LL_ASTAR_TA job (used for the action costs below)
+  } else if (d.status == mrp::ST_OK && init != 0) {
     if (sipp) {
       r.cost = d.cost - init;  // sipp.hpp:103; fmin stays the A* f value (absolute)
     } else {                   // a_star.hpp:64,78: every node but the start carries initialCost in g and f
@@ -927,10 +957,27 @@ void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool r
     if (r.actions)
       for (int k = 0; k + 1 < n && k < r.states_cap; ++k)
         r.actions[k] = actionFromDelta((p[k + 1] & 0xFF) - (p[k] & 0xFF), (p[k + 1] >> 8) - (p[k] >> 8));
-    if (r.action_costs)
-      for (int k = 0; k + 1 < n && k < r.states_cap; ++k) r.action_costs[k] = 1;
+    if (r.action_costs) {
+      // MRP_LL_ASTAR_TA (init carries goal and flags, see taInfoOf): a Wait at the goal is free (cbs_ta.cpp:333-338)
+      const bool ta = (init & 0x40000000) != 0, noGoal = (init & 0x10000) != 0;
+      const int tgx = init & 0xFF, tgy = (init >> 8) & 0xFF;
+      for (int k = 0; k + 1 < n && k < r.states_cap; ++k) {
+        const bool wait = p[k] == p[k + 1];
+        const bool atGoal = noGoal || ((p[k] & 0xFF) == tgx && (p[k] >> 8) == tgy);
+        r.action_costs[k] = (ta && wait && atGoal) ? 0 : 1;
+      }
+    }
     if ((r.states_txy || r.actions) && r.states_cap < n) r.status = MRP_LL_PATH_TRUNCATED;
   }
+}
+
+// What unpackResult needs to know about a job besides its device result: initial_cost (A*) / start_time (SIPP), or — for
+// MRP_LL_ASTAR_TA, whose initial cost is always 0 — bit 30 + the goal cell and the no-task flag.
+int32_t jobInitOf(const mrp_ll_job& j, bool ok) {
+  if (!ok) return 0;
+  if (j.algo == MRP_LL_ASTAR_TA)
+    return 0x40000000 | ((j.flags & MRP_LL_JOB_NO_GOAL) ? 0x10000 : ((j.goal_y & 0xFF) << 8 | (j.goal_x & 0xFF)));
+  return j.initial_cost;
 }
 
 void trivialRejectedJob(mrp_ll_ctx* ctx, DevJob& d) {
@@ -1091,6 +1138,32 @@ int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t nObst
   return MRP_LL_SUCCESS;
 }
 
+
+int mrp_ll_upload_heuristic(mrp_ll_ctx* ctx, int32_t mapId, const int32_t* dist, int32_t* heurId) {
+  if (!ctx || !dist || !heurId || mapId < 0 || mapId >= static_cast<int32_t>(ctx->maps.size())) return MRP_LL_E_INVALID;
+  if (ctx->ring.active) return MRP_LL_E_BUSY;  // (the maps buffer may have to grow)
+  const MapRec& mp = ctx->maps[mapId];
+  if (mp.dimx > 32 || mp.dimy > 32) {
+    ctx->err = "mrp_ll_upload_heuristic: MRP_LL_ASTAR_TA serves maps up to 32 x 32";
+    return MRP_LL_E_INVALID;
+  }
+  while (ctx->mapWords.size() & 3u) ctx->mapWords.push_back(0);
+  HeurRec h;
+  h.mapId = mapId;
+  h.wordOff = static_cast<uint32_t>(ctx->mapWords.size());
+  ctx->mapWords.resize(ctx->mapWords.size() + mrp::kHeurWords, 0xFFFFFFFFu);
+  // [y * 32 + x] halfwords, 0xFFFF = unreachable (the reference's table holds INT_MAX there)
+  uint16_t* t16 = reinterpret_cast<uint16_t*>(ctx->mapWords.data() + h.wordOff);
+  for (int y = 0; y < mp.dimy; ++y)
+    for (int x = 0; x < mp.dimx; ++x) {
+      const int32_t v = dist[y * mp.dimx + x];
+      t16[y * 32 + x] = (v < 0 || v > 0xFFFE) ? 0xFFFFu : static_cast<uint16_t>(v);
+    }
+  ctx->heurs.push_back(h);
+  ctx->mapsDirty = true;
+  *heurId = static_cast<int32_t>(ctx->heurs.size()) - 1;
+  return MRP_LL_SUCCESS;
+}
 
 int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t ldsNodes, int32_t ldsRows, int32_t ldsPathBytes, int32_t* occOut) {
   if (!ctx) return MRP_LL_E_INVALID;
@@ -1390,7 +1463,9 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
         g.slotSippFlags[slot] = static_cast<uint8_t>(fl);
       }
     } else {
-      ok = jobs[i].algo != MRP_LL_SIPP && (g.kind == 0 || jobs[i].algo == (g.kind == 1 ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR)) &&
+      ok = jobs[i].algo != MRP_LL_SIPP &&
+           (g.kind == 0 || (g.kind == 1 ? jobs[i].algo == MRP_LL_ASTAR_EPS
+                                        : (jobs[i].algo == MRP_LL_ASTAR || jobs[i].algo == MRP_LL_ASTAR_TA))) &&
            packJob(ctx, jobs[i], cs, ps, d);
     }
     if (!ok) {  // wrong kind of job for this session, or constraint list / table larger than a ring slot
@@ -1400,7 +1475,7 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
     g.jobs[slot] = d;
     ctx->stats.staged_bytes += static_cast<int64_t>(sizeof(DevJob)) + 4 * static_cast<int64_t>(g.sipp ? sippWords : cs.used) +
                                (g.sipp || (d.ctx_flags & mrp::kCtxById) ? 0 : 2 * static_cast<int64_t>(d.t_pad) * d.n_agents_pad);
-    g.slotInit[slot] = ok ? jobs[i].initial_cost : 0;
+    g.slotInit[slot] = jobInitOf(jobs[i], ok);
     g.busy[slot] = 1;
     g.slotTicket[slot] = ti;
     g.slotJob[slot] = i;
@@ -1575,7 +1650,7 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
       t.jobDimx[i] = ok ? static_cast<int32_t>(t.jobs.host[i].dimx) : 1;
     }
     if (static_cast<int>(t.jobInit.size()) < nJobs) t.jobInit.resize(nJobs);
-    t.jobInit[i] = ok ? jobs[i].initial_cost : 0;
+    t.jobInit[i] = jobInitOf(jobs[i], ok);
     if (t.sipp) {
       if (static_cast<int>(t.commitTab.size()) < nJobs) t.commitTab.resize(nJobs);
       t.commitTab[i] = ok && jobs[i].sipp_table && jobs[i].sipp_commit ? const_cast<mrp_ll_sipp_table*>(jobs[i].sipp_table)
@@ -1843,6 +1918,7 @@ int mrp_ll_release_maps(mrp_ll_ctx* ctx) {
   for (const Ticket& t : ctx->tickets)
     if (t.inFlight) return MRP_LL_E_BUSY;
   ctx->maps.clear();
+  ctx->heurs.clear();
   ctx->mapWords.clear();
   ctx->mapsDirty = false;  // nothing to copy; the device buffer (and its capacity) is kept for the next uploads
   return MRP_LL_SUCCESS;

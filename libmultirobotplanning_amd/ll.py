@@ -15,8 +15,8 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MRP_LL_LIB") or os.path.join(_PKG, "lib", "libmrp_ll.so")
 
-ASTAR, ASTAR_EPS, SIPP = 0, 1, 2
-JOB_STORE_RESULT = 1  # mrp_ll_job.flags (include/mrp_ll.h)
+ASTAR, ASTAR_EPS, SIPP, ASTAR_TA = 0, 1, 2, 3
+JOB_STORE_RESULT, JOB_NO_GOAL = 1, 2  # mrp_ll_job.flags (include/mrp_ll.h)
 OK, NO_SOLUTION, CAP_EXPANSIONS, CAP_NODES, CAP_HORIZON, BAD_JOB, PATH_TRUNCATED, CAP_FOCAL = range(8)
 ACTION_NAMES = ["Up", "Down", "Left", "Right", "Wait"]  # example/ecbs.cpp:49-55
 
@@ -40,7 +40,7 @@ class mrp_ll_job(ctypes.Structure):
                 ("n_collision_locations", ctypes.c_int32), ("collision_xy", I32P), ("collision_count", I32P),
                 ("collision_intervals", I32P), ("initial_cost", ctypes.c_int32), ("sipp_commit", ctypes.c_int32),
                 ("sipp_table", ctypes.c_void_p), ("path_ids", I32P), ("result_path_id", ctypes.c_int32),
-                ("flags", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("heuristic_id", ctypes.c_int32), ("reserved3", ctypes.c_int32)]
 
 
 class mrp_ll_result(ctypes.Structure):
@@ -66,7 +66,8 @@ EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_uploa
            "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version",
            "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any", "mrp_ll_submit_lane", "mrp_ll_sync_maps",
            "mrp_ll_configure_tiers", "mrp_ll_session_begin_sipp", "mrp_ll_release_maps", "mrp_ll_session_begin_algo", "mrp_ll_conflict_scan",
-           "mrp_ll_sipp_table_create", "mrp_ll_sipp_table_add", "mrp_ll_sipp_table_destroy", "mrp_ll_path_store_reserve"]
+           "mrp_ll_sipp_table_create", "mrp_ll_sipp_table_add", "mrp_ll_sipp_table_destroy", "mrp_ll_path_store_reserve",
+           "mrp_ll_upload_heuristic"]
 
 _lib = None
 
@@ -121,6 +122,8 @@ def load_library(path: Optional[str] = None):
     lib.mrp_ll_conflict_scan.restype = ctypes.c_int
     lib.mrp_ll_conflict_scan.argtypes = [ctypes.c_void_p, ctypes.c_int32, I32P, I32P, I32P, ctypes.POINTER(mrp_ll_conflict)]
     lib.mrp_ll_path_store_reserve.restype = ctypes.c_int
+    lib.mrp_ll_upload_heuristic.restype = ctypes.c_int
+    lib.mrp_ll_upload_heuristic.argtypes = [ctypes.c_void_p, ctypes.c_int32, I32P, ctypes.POINTER(ctypes.c_int32)]
     lib.mrp_ll_path_store_reserve.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.mrp_ll_sipp_table_create.restype = ctypes.c_int
     lib.mrp_ll_sipp_table_create.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
@@ -141,7 +144,7 @@ class LLJob:
     map_id: int
     algo: int
     start: Sequence[int]
-    goal: Sequence[int]
+    goal: Optional[Sequence[int]]  # None: ASTAR_TA for an agent without a task (MRP_LL_JOB_NO_GOAL)
     agent_idx: int = 0
     w: float = 1.0
     vertex_constraints: Sequence[Sequence[int]] = ()   # (time, x, y)
@@ -154,6 +157,7 @@ class LLJob:
     sipp_commit: bool = False         # SIPP with sipp_table: on success the path's stays join the table (mrp_ll.h)
     path_ids: Optional[Sequence[int]] = None  # f2: path-store slots of ctx_paths (-1 = none); lengths come from ctx_paths
     result_path_id: int = -1                  # f2: path-store slot that also receives the result path
+    heuristic_id: int = -1                    # ASTAR_TA: LowLevelEngine.upload_heuristic of the goal cell
 
 
 @dataclass
@@ -215,7 +219,8 @@ class LowLevelEngine:
         for i, j in enumerate(jobs):
             cj = cjobs[i]
             cj.map_id, cj.algo, cj.w, cj.agent_idx = j.map_id, j.algo, j.w, j.agent_idx
-            cj.start_x, cj.start_y, cj.goal_x, cj.goal_y = j.start[0], j.start[1], j.goal[0], j.goal[1]
+            cj.start_x, cj.start_y = j.start[0], j.start[1]
+            cj.goal_x, cj.goal_y = (j.goal[0], j.goal[1]) if j.goal is not None else (0, 0)
             vc = np.ascontiguousarray(np.asarray(j.vertex_constraints, dtype=np.int32).reshape(-1, 3))
             ec = np.ascontiguousarray(np.asarray(j.edge_constraints, dtype=np.int32).reshape(-1, 5))
             cj.n_vertex_constraints, cj.vertex_constraints = len(vc), vc.ctypes.data_as(I32P)
@@ -233,7 +238,8 @@ class LowLevelEngine:
                 cj.sipp_table = j.sipp_table
                 cj.sipp_commit = 1 if j.sipp_commit else 0
             cj.result_path_id = j.result_path_id
-            cj.flags = JOB_STORE_RESULT if j.result_path_id >= 0 else 0
+            cj.flags = (JOB_STORE_RESULT if j.result_path_id >= 0 else 0) | (JOB_NO_GOAL if j.goal is None else 0)
+            cj.heuristic_id = j.heuristic_id
             if j.path_ids is not None:
                 ids = np.ascontiguousarray(np.asarray(j.path_ids, dtype=np.int32))
                 cj.path_ids = ids.ctypes.data_as(I32P)
@@ -295,6 +301,14 @@ class LowLevelEngine:
                                                    path_first.ctypes.data_as(I32P), xy.ctypes.data_as(I32P), out),
                     "mrp_ll_conflict_scan")
         return [{k: getattr(out[i], k) for k, _ in mrp_ll_conflict._fields_} for i in range(n)]
+
+    def upload_heuristic(self, map_id: int, dist) -> int:
+        """MRP_LL_ASTAR_TA: the shortest-path table of one goal cell, dist[dimy][dimx] (INT32_MAX = unreachable)."""
+        d = np.ascontiguousarray(np.asarray(dist, dtype=np.int64).clip(-1, 2 ** 31 - 1).astype(np.int32).reshape(-1))
+        hid = ctypes.c_int32(-1)
+        self._check(self._lib.mrp_ll_upload_heuristic(self._h, map_id, d.ctypes.data_as(I32P), ctypes.byref(hid)),
+                    "mrp_ll_upload_heuristic")
+        return hid.value
 
     def path_store_reserve(self, n_slots: int) -> None:
         """Allocate the device-resident path store (f2): slots 0..n_slots-1 are the caller's to hand out."""

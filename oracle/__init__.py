@@ -79,6 +79,13 @@ def lib():
         _LIB.oracle_prioritized_sipp.restype = ctypes.c_int
         _LIB.oracle_prioritized_sipp.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, I32P,
                                                  I32P, I64P, I32P, I32P, I32P, ctypes.c_int]
+        _LIB.oracle_ta_ll_search.restype = ctypes.c_int
+        _LIB.oracle_ta_ll_search.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, I32P,
+                                             ctypes.c_int64, I32P, I64P, I32P, I32P, I32P, ctypes.c_int]
+        _LIB.oracle_ta_cbs_fixed.restype = ctypes.c_int64
+        _LIB.oracle_ta_cbs_fixed.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, I32P, I32P, I64P,
+                                             I32P, I32P, ctypes.c_int64, I32P]
         _LIB.oracle_sipp_single.restype = ctypes.c_int
         _LIB.oracle_sipp_single.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, I32P, ctypes.c_int, I64P]
@@ -268,3 +275,58 @@ def prioritized_sipp_batch(dimx, dimy, obstacles, starts, goals, n_threads=1):
                                                st.ctypes.data_as(I32P), go.ctypes.data_as(I32P), n_threads,
                                                out.ctypes.data_as(I64P))
     return out, wall / 1e9
+
+
+def ta_ll_search(inst_map, start, goal, vertex_constraints=(), edge_constraints=(), cap_expansions=-1, cap=1024):
+    """One low-level search of the task-assignment callers (example/cbs_ta.cpp's Environment under AStar): goal = None for an
+    agent without a task.  Returns success, cost, fmin, expanded, states [t, x, y], actions, action_costs."""
+    obst, obst_p = _i32(np.asarray(inst_map["obstacles"], dtype=np.int32).reshape(-1, 2))
+    vc, vc_p = _i32(np.asarray(vertex_constraints, dtype=np.int32).reshape(-1, 3))
+    ec, ec_p = _i32(np.asarray(edge_constraints, dtype=np.int32).reshape(-1, 5))
+    out = np.zeros(4, dtype=np.int32)
+    expanded = np.zeros(1, dtype=np.int64)
+    states = np.zeros((cap, 3), dtype=np.int32)
+    actions = np.zeros(cap, dtype=np.int32)
+    costs = np.zeros(cap, dtype=np.int32)
+    g = goal if goal is not None else (0, 0)
+    rc = lib().oracle_ta_ll_search(inst_map["dimx"], inst_map["dimy"], len(obst), obst_p, start[0], start[1],
+                                   0 if goal is None else 1, g[0], g[1], len(vc), vc_p, len(ec), ec_p, cap_expansions,
+                                   out.ctypes.data_as(I32P), expanded.ctypes.data_as(I64P), states.ctypes.data_as(I32P),
+                                   actions.ctypes.data_as(I32P), costs.ctypes.data_as(I32P), cap)
+    n = int(out[3])
+    assert n <= cap
+    return dict(rc=rc, success=bool(out[0]), cost=int(out[1]), fmin=int(out[2]), expanded=int(expanded[0]),
+                states=states[:n].tolist(), actions=actions[:max(n - 1, 0)].tolist(),
+                action_costs=costs[:max(n - 1, 0)].tolist())
+
+
+def ta_cbs_fixed(inst_map, starts, tasks):
+    """cbs_ta.hpp's conflict tree for ONE fixed assignment (tasks[i] = [x, y] or None).  Returns (summary, low-level calls)."""
+    obst, obst_p = _i32(np.asarray(inst_map["obstacles"], dtype=np.int32).reshape(-1, 2))
+    st, st_p = _i32(starts)
+    tk, tk_p = _i32([t if t is not None else [-1, -1] for t in tasks])
+    n = len(starts)
+    stats = np.zeros(3, dtype=np.int64)
+    end = np.zeros((n, 3), dtype=np.int32)
+    ncalls = np.zeros(1, dtype=np.int32)
+    words = 1 << 16
+    while True:
+        buf = np.zeros(words, dtype=np.int32)
+        need = lib().oracle_ta_cbs_fixed(inst_map["dimx"], inst_map["dimy"], len(obst), obst_p, n, st_p, tk_p,
+                                         stats.ctypes.data_as(I64P), end.ctypes.data_as(I32P), buf.ctypes.data_as(I32P), words,
+                                         ncalls.ctypes.data_as(I32P))
+        if need <= words:
+            break
+        words = int(need)
+    calls = []
+    p = 0
+    for _ in range(int(ncalls[0])):
+        agent, has, tx, ty, ok, cost, fmin, expanded, nvc, nec, nst = (int(v) for v in buf[p:p + 11])
+        p += 11
+        vc = buf[p:p + 3 * nvc].reshape(-1, 3).tolist(); p += 3 * nvc
+        ec = buf[p:p + 5 * nec].reshape(-1, 5).tolist(); p += 5 * nec
+        states = buf[p:p + 3 * nst].reshape(-1, 3).tolist(); p += 3 * nst
+        costs = buf[p:p + max(nst - 1, 0)].tolist(); p += max(nst - 1, 0)
+        calls.append(dict(agent=agent, goal=[tx, ty] if has else None, success=bool(ok), cost=cost, fmin=fmin, expanded=expanded,
+                          vertex_constraints=vc, edge_constraints=ec, states=states, action_costs=costs))
+    return dict(solved=bool(stats[0]), cost=int(stats[1]), end=end.tolist()), calls

@@ -11,6 +11,7 @@
 #include "grid2d_restated.hpp"
 #include "mapf_restated.hpp"
 #include "sipp_restated.hpp"
+#include "ta_restated.hpp"
 
 using namespace oracle;
 using namespace oracle::mapf;
@@ -424,6 +425,102 @@ int oracle_sipp_single_at(int dimx, int dimy, int nObst, const int32_t* obstXY, 
     statesXYT[3 * k + 2] = sol.states[k].second;
   }
   return n;
+}
+
+// ---- task-assignment callers' low level (ta_restated.hpp) ------------------------------------------
+// One AStar::search over example/cbs_ta.cpp's Environment.  hasGoal = 0: the agent has no task (cbs_ta.cpp:283-319).
+// out[0..3] = success, cost, fmin, n_states; statesTXY [cap][3], actions [cap], actionCosts [cap] (Wait at the goal: 0).
+// Returns 0, or -1 when the expansion cap was exceeded.
+int oracle_ta_ll_search(int dimx, int dimy, int nObst, const int32_t* obstXY, int startX, int startY, int hasGoal, int goalX,
+                        int goalY, int nVC, const int32_t* vc, int nEC, const int32_t* ec, int64_t capExpansions,
+                        int32_t* out, int64_t* expanded, int32_t* statesTXY, int32_t* actions, int32_t* actionCosts, int cap) {
+  std::unordered_set<Cell, CellHash> obst;
+  for (int i = 0; i < nObst; ++i) obst.insert(Cell{obstXY[2 * i], obstXY[2 * i + 1]});
+  Constraints cons;
+  for (int i = 0; i < nVC; ++i) cons.vertex.insert(VertexConstraint{vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]});
+  for (int i = 0; i < nEC; ++i)
+    cons.edge.insert(EdgeConstraint{ec[5 * i], ec[5 * i + 1], ec[5 * i + 2], ec[5 * i + 3], ec[5 * i + 4]});
+  ta::Environment env(dimx, dimy, obst);
+  const Cell goal{goalX, goalY};
+  Plan plan;
+  bool ok = false;
+  int rc = 0;
+  try {
+    ok = ta::lowLevelSearch(env, 0, cons, hasGoal ? &goal : nullptr, obst, dimx, dimy, State(0, startX, startY), plan,
+                            capExpansions);
+  } catch (const CapExceeded&) {
+    rc = -1;
+  }
+  *expanded = env.m_llExpandedThisSearch;
+  out[0] = ok ? 1 : 0;
+  out[1] = ok ? plan.cost : 0;
+  out[2] = ok ? plan.fmin : 0;
+  const int n = ok ? static_cast<int>(plan.states.size()) : 0;
+  out[3] = n;
+  for (int k = 0; k < n && k < cap; ++k) {
+    statesTXY[3 * k + 0] = plan.states[k].first.time;
+    statesTXY[3 * k + 1] = plan.states[k].first.x;
+    statesTXY[3 * k + 2] = plan.states[k].first.y;
+    if (k + 1 < n) {
+      actions[k] = actionCode(plan.actions[k].first);
+      actionCosts[k] = plan.actions[k].second;
+    }
+  }
+  return rc;
+}
+
+// cbs_ta.hpp:85-215 for ONE fixed assignment (ta::cbsFixedTasks): tasksXY[i] = (-1, -1): agent i has no task.
+// stats[0..2] = solved, cost, highLevelExpanded; endTXY [nAgents][3] = last state of every path.
+// Every low-level call is serialised into buf (int32 words) as
+//   agent, hasTask, taskX, taskY, success, cost, fmin, expanded, nVC, nEC, nStates, vc[nVC][3], ec[nEC][5],
+//   statesTXY[nStates][3], actionCosts[nStates - 1 (0 if nStates == 0)]
+// Returns the words needed (call again with a bigger buffer if > bufWords); *nCalls = number of calls.
+int64_t oracle_ta_cbs_fixed(int dimx, int dimy, int nObst, const int32_t* obstXY, int nAgents, const int32_t* startsXY,
+                            const int32_t* tasksXY, int64_t* stats, int32_t* endTXY, int32_t* buf, int64_t bufWords,
+                            int32_t* nCalls) {
+  std::unordered_set<Cell, CellHash> obst;
+  for (int i = 0; i < nObst; ++i) obst.insert(Cell{obstXY[2 * i], obstXY[2 * i + 1]});
+  std::vector<State> starts;
+  std::vector<Cell> taskCells(nAgents);
+  std::vector<const Cell*> tasks(nAgents, nullptr);
+  for (int i = 0; i < nAgents; ++i) {
+    starts.push_back(State(0, startsXY[2 * i], startsXY[2 * i + 1]));
+    if (tasksXY[2 * i] >= 0) {
+      taskCells[i] = Cell{tasksXY[2 * i], tasksXY[2 * i + 1]};
+      tasks[i] = &taskCells[i];
+    }
+  }
+  std::vector<Plan> sol;
+  int cost = 0;
+  std::vector<ta::LowLevelCall> rec;
+  const bool ok = ta::cbsFixedTasks(dimx, dimy, obst, starts, tasks, sol, cost, &rec);
+  stats[0] = ok ? 1 : 0;
+  stats[1] = ok ? cost : 0;
+  stats[2] = 0;
+  if (ok)
+    for (int i = 0; i < nAgents; ++i) {
+      const State& s = sol[i].states.back().first;
+      endTXY[3 * i] = s.time;
+      endTXY[3 * i + 1] = s.x;
+      endTXY[3 * i + 2] = s.y;
+    }
+  int64_t w = 0;
+  auto put = [&](int32_t v) {
+    if (w < bufWords) buf[w] = v;
+    ++w;
+  };
+  for (const auto& c : rec) {
+    const int nst = c.ok ? static_cast<int>(c.plan.states.size()) : 0;
+    put(static_cast<int32_t>(c.agent)); put(c.hasTask ? 1 : 0); put(c.task.x); put(c.task.y); put(c.ok ? 1 : 0);
+    put(c.ok ? c.plan.cost : 0); put(c.ok ? c.plan.fmin : 0); put(static_cast<int32_t>(c.expanded));
+    put(static_cast<int32_t>(c.constraints.vertex.size())); put(static_cast<int32_t>(c.constraints.edge.size())); put(nst);
+    for (const auto& v : c.constraints.vertex) { put(v.time); put(v.x); put(v.y); }
+    for (const auto& e : c.constraints.edge) { put(e.time); put(e.x1); put(e.y1); put(e.x2); put(e.y2); }
+    for (int k = 0; k < nst; ++k) { put(c.plan.states[k].first.time); put(c.plan.states[k].first.x); put(c.plan.states[k].first.y); }
+    for (int k = 0; k + 1 < nst; ++k) put(c.plan.actions[k].second);
+  }
+  *nCalls = static_cast<int32_t>(rec.size());
+  return w;
 }
 
 }  // extern "C"

@@ -95,6 +95,7 @@ def ref_tests():
                        obstacles=[[int(o[0]), int(o[1])] for o in (s["environment"]["obstacles"] or [])],
                        start=[int(v) for v in s["start"]], goal=[int(v) for v in s["goal"]],
                        collision_intervals=ci, n_states=6, last=[2, 3, 9], src="test/test_sipp.py:16-21")
+    t["cbs_ta"] = ta_tests()
     return t
 
 
@@ -223,7 +224,30 @@ def ll_jobs(instances):
     return out
 
 
+def ta_tests():
+    """test/mapfta_simple1_a{1,2,3}.yaml (data) + what test/test_cbs_ta.py:24-38 asserts about them."""
+    out = {}
+    for k in (1, 2, 3):
+        with open(os.path.join(REF, "test", "mapfta_simple1_a%d.yaml" % k)) as f:
+            cfg = yaml.safe_load(f)
+        dim = cfg["map"]["dimensions"]
+        out["mapfta_simple1_a%d" % k] = dict(
+            dimx=int(dim[0]), dimy=int(dim[1]), obstacles=[[int(o[0]), int(o[1])] for o in (cfg["map"]["obstacles"] or [])],
+            starts=[[int(a["start"][0]), int(a["start"][1])] for a in cfg["agents"]],
+            potential_goals=[[[int(g[0]), int(g[1])] for g in (a["potentialGoals"] or [])] for a in cfg["agents"]])
+    return dict(inputs=out, cost=dict(mapfta_simple1_a1=6, mapfta_simple1_a2=6, mapfta_simple1_a3=5),
+                ends=dict(mapfta_simple1_a2=dict(agent0=[4, 0, 4], agent1_xy=[2, 1]), mapfta_simple1_a3=dict(agent0=[3, 0, 3])),
+                src="test/test_cbs_ta.py:24-38 (agent end states as x, y, t)")
+
+
 if __name__ == "__main__":
+    if "--ta" in sys.argv:  # round-3 addition: the task-assignment fixtures go into ref_tests.json
+        with open(os.path.join(OUT, "ref_tests.json")) as f:
+            t = json.load(f)
+        t["cbs_ta"] = ta_tests()
+        with open(os.path.join(OUT, "ref_tests.json"), "w") as f:
+            json.dump(t, f, separators=(",", ":"))
+        sys.exit(0)
     if "--shipped" in sys.argv:  # only the round-3 additions (the other files are unchanged)
         with open(os.path.join(OUT, "bench_instances.json")) as f:
             inst = json.load(f)

@@ -132,4 +132,79 @@ int emu_compact_search(int eps, int dimx, int dimy, int n_obst, const int32_t* o
   return 0;
 }
 
+// One low-level search of the task-assignment callers (compactSearchTA).  has_goal = 0: no task.  heur: the shortest-path
+// table of the goal cell, [dimy][dimx] int32 (INT32_MAX: unreachable), as the caller of mrp_ll_upload_heuristic passes it.
+// out as in emu_compact_search (status 3 / 4: capacity of the tier).
+int emu_compact_search_ta(int dimx, int dimy, int n_obst, const int32_t* obst_xy, int sx, int sy, int has_goal, int gx, int gy,
+                          const int32_t* heur, int n_vc, const int32_t* vc, int n_ec, const int32_t* ec, int64_t max_exp,
+                          int open_cap, int max_t, int64_t* out, int32_t* states_xy, int states_cap) {
+  using namespace mrp::ct;
+  if (dimx < 1 || dimy < 1 || dimx > 32 || dimy > 32) return -2;
+  const uint32_t cells = (uint32_t)dimx * dimy;
+  std::vector<uint32_t> obst((cells + 31) / 32, 0u);
+  for (int i = 0; i < n_obst; ++i) {
+    const int x = obst_xy[2 * i], y = obst_xy[2 * i + 1];
+    if (x < 0 || x >= dimx || y < 0 || y >= dimy) continue;
+    const uint32_t c = (uint32_t)(y * dimx + x);
+    obst[c >> 5] |= 1u << (c & 31);
+  }
+  std::vector<uint32_t> vcw, ecw;
+  int lastGoal = -1;
+  for (int i = 0; i < n_vc; ++i) {
+    const int32_t* v = vc + 3 * i;
+    if (!has_goal || (v[1] == gx && v[2] == gy)) lastGoal = std::max(lastGoal, v[0]);  // cbs_ta.cpp:290-301
+    if (v[0] < 0 || v[0] >= 1024 || v[1] < 0 || v[1] >= dimx || v[2] < 0 || v[2] >= dimy) continue;
+    vcw.push_back(((uint32_t)v[0] << 16) | ((uint32_t)v[2] << 8) | (uint32_t)v[1]);
+  }
+  for (int i = 0; i < n_ec; ++i) {
+    const int32_t* e = ec + 5 * i;
+    const int k = neighborIndexFromDelta(e[3] - e[1], e[4] - e[2]);
+    if (k < 0 || e[0] < 0 || e[0] >= 1024 || e[1] < 0 || e[1] >= dimx || e[2] < 0 || e[2] >= dimy) continue;
+    ecw.push_back(((uint32_t)e[0] << 19) | ((uint32_t)(e[2] * dimx + e[1]) << 3) | (uint32_t)k);
+  }
+  if (vcw.size() > 64 || ecw.size() > 64) return -2;
+  vcw.push_back(0);
+  ecw.push_back(0);
+  std::vector<uint16_t> table(1024, 0xFFFFu);  // [y * 32 + x], 0xFFFF = unreachable (what mrp_ll_upload_heuristic stores)
+  if (has_goal)
+    for (int y = 0; y < dimy; ++y)
+      for (int x = 0; x < dimx; ++x) {
+        const int32_t d = heur[y * dimx + x];
+        table[y * 32 + x] = (d < 0 || d > 0xFFFE) ? 0xFFFFu : (uint16_t)d;
+      }
+  std::vector<uint8_t> ldsMem(kLdsBytes + 2048u, 0xA5);
+  wv::LdsWindow win{ldsMem.data(), (uint32_t)ldsMem.size(), 0, 0};
+  std::vector<uint8_t> parentTab(kParentBytes, 0xEE);
+  std::vector<uint16_t> outPath(1024, 0);
+  CJob J;
+  std::memset(&J, 0, sizeof(J));
+  J.dimx = dimx; J.dimy = dimy; J.sx = sx; J.sy = sy; J.gx = has_goal ? gx : 0; J.gy = has_goal ? gy : 0;
+  J.lastGoal = lastGoal;
+  J.nVc = (uint32_t)vcw.size() - 1; J.nEc = (uint32_t)ecw.size() - 1;
+  J.vc = (uint64_t)(uintptr_t)vcw.data(); J.ec = (uint64_t)(uintptr_t)ecw.data();
+  J.obst = (uint64_t)(uintptr_t)obst.data(); J.obstWords = (uint32_t)obst.size();
+  J.pathsG = (uint64_t)(uintptr_t)table.data();
+  J.taNoGoal = has_goal ? 0u : 1u;
+  J.maxExp = max_exp < 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(max_exp, 0xFFFFFFFEll);
+  J.openCap = open_cap > 0 ? std::min<uint32_t>((uint32_t)open_cap, kCap) : kCap;
+  J.maxT = max_t > 0 ? std::min<uint32_t>((uint32_t)max_t, kMaxT) : kMaxT;
+  J.parentTab = (uint64_t)(uintptr_t)parentTab.data();
+  J.outPath = (uint64_t)(uintptr_t)outPath.data();
+  std::memcpy(ldsMem.data() + oJob, &J, sizeof(J));
+  const int32_t rc = compactSearchTA(&win);
+  CRes R;
+  std::memcpy(&R, ldsMem.data() + oRes, sizeof(R));
+  if (rc != R.status) return -3;
+  out[0] = rc;
+  out[1] = R.cost; out[2] = R.fmin; out[3] = R.nStates; out[4] = R.expanded; out[5] = R.nodes;
+  out[6] = (int64_t)win.oobReads;
+  out[7] = (int64_t)win.oobWrites;
+  if (rc == C_OK)
+    for (int k = 0; k < R.nStates && k < states_cap; ++k) {
+      states_xy[2 * k] = outPath[k] & 0xFF;
+      states_xy[2 * k + 1] = outPath[k] >> 8;
+    }
+  return 0;
+}
+
 }  // extern "C"

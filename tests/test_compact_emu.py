@@ -183,3 +183,98 @@ def test_golden_low_level_jobs_through_the_emulated_tier(emu, bench_instances, l
         if j["success"]:
             assert (r["cost"], r["fmin"], r["states"]) == (j["cost"], j["fmin"], j["states"]), (j["instance"], a)
     assert n >= 190
+
+
+def _bfs_table(dimx, dimy, obstacles, goal):
+    """shortest_path_heuristic.hpp's row for `goal` (what a caller uploads with mrp_ll_upload_heuristic)."""
+    from collections import deque
+    obst = {(o[0], o[1]) for o in obstacles}
+    dist = [[2 ** 31 - 1] * dimx for _ in range(dimy)]
+    if tuple(goal) in obst:
+        return dist
+    dist[goal[1]][goal[0]] = 0
+    q = deque([tuple(goal)])
+    while q:
+        x, y = q.popleft()
+        for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+            nx, ny = x + dx, y + dy
+            if 0 <= nx < dimx and 0 <= ny < dimy and (nx, ny) not in obst and dist[ny][nx] == 2 ** 31 - 1:
+                dist[ny][nx] = dist[y][x] + 1
+                q.append((nx, ny))
+    return dist
+
+
+def emu_search_ta(L, inst_map, start, goal, vc, ec, max_exp=-1, open_cap=0, max_t=0):
+    if not hasattr(L, "_ta_ready"):
+        L.emu_compact_search_ta.restype = ctypes.c_int
+        L.emu_compact_search_ta.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, I32P, ctypes.c_int, I32P, ctypes.c_int64,
+                                            ctypes.c_int, ctypes.c_int, I64P, I32P, ctypes.c_int]
+        L._ta_ready = True
+    obst, obst_p = _arr(inst_map["obstacles"], (-1, 2))
+    vca, vc_p = _arr(vc, (-1, 3))
+    eca, ec_p = _arr(ec, (-1, 5))
+    g = goal if goal is not None else (0, 0)
+    heur, heur_p = _arr(_bfs_table(inst_map["dimx"], inst_map["dimy"], inst_map["obstacles"], g) if goal is not None else [0], (-1,))
+    out = np.zeros(8, dtype=np.int64)
+    states = np.zeros((1024, 2), dtype=np.int32)
+    rc = L.emu_compact_search_ta(inst_map["dimx"], inst_map["dimy"], len(obst), obst_p, start[0], start[1], 0 if goal is None else 1,
+                                 g[0], g[1], heur_p, len(vca), vc_p, len(eca), ec_p, max_exp, open_cap, max_t,
+                                 out.ctypes.data_as(I64P), states.ctypes.data_as(I32P), 1024)
+    assert rc == 0, rc
+    return dict(status=int(out[0]), cost=int(out[1]), fmin=int(out[2]), n_states=int(out[3]), expanded=int(out[4]),
+                oob_reads=int(out[6]), oob_writes=int(out[7]), states=states[:int(out[3])].tolist())
+
+
+def _compare_ta(r, o):
+    assert r["oob_reads"] == 0 and r["oob_writes"] == 0
+    if r["status"] in (3, 4):
+        return False  # a capacity limit of the tier
+    if o["rc"] == -1:
+        assert r["status"] == 2
+        return True
+    assert (r["status"] == 0, r["expanded"]) == (o["success"], o["expanded"]), (r, o["expanded"])
+    if o["success"]:
+        assert (r["cost"], r["fmin"]) == (o["cost"], o["fmin"]), (r, o["cost"], o["fmin"])
+        assert r["states"] == [s[1:] for s in o["states"]]
+    return True
+
+
+def test_task_assignment_low_level(emu, oracle_mod, ref_tests, bench_instances):
+    """SURVEY.md §8 f4: the compact tier's search for the task-assignment callers (optional goal, shortest-path heuristic,
+    free Wait at the goal, decrease-key live) against the oracle's restatement of example/cbs_ta.cpp + a_star.hpp: every
+    low-level call of the conflict trees over the reference's three fixtures (all assignments), then random constraint
+    sets on shipped 8x8 and 32x32 maps, with and without a task."""
+    from test_oracle_known_answers import _ta_assignments
+    n = 0
+    for name, inst in ref_tests["cbs_ta"]["inputs"].items():
+        m = dict(dimx=inst["dimx"], dimy=inst["dimy"], obstacles=inst["obstacles"])
+        for tasks in _ta_assignments(inst["potential_goals"]):
+            _, calls = oracle_mod.ta_cbs_fixed(m, inst["starts"], tasks)
+            for c in calls:
+                o = dict(rc=0, success=c["success"], cost=c["cost"], fmin=c["fmin"], expanded=c["expanded"], states=c["states"])
+                r = emu_search_ta(emu, m, inst["starts"][c["agent"]], c["goal"], c["vertex_constraints"], c["edge_constraints"])
+                n += _compare_ta(r, o)
+    assert n >= 12
+    rng = np.random.default_rng(11)
+    for trial in range(120):
+        inst = bench_instances["map_8by8_obst12_agents8_ex%d" % (trial % 5)] if trial % 2 else \
+            bench_instances["map_32by32_obst204_agents10_ex%d" % (trial % 7)]
+        m = dict(dimx=inst["dimx"], dimy=inst["dimy"], obstacles=inst["obstacles"])
+        d = inst["dimx"]
+        a = int(rng.integers(0, len(inst["starts"])))
+        s = inst["starts"][a]
+        goal = None if trial % 3 == 0 else inst["goals"][a]
+        vc = [[int(rng.integers(0, 14)), int(rng.integers(0, d)), int(rng.integers(0, d))] for _ in range(int(rng.integers(0, 30)))]
+        if goal is not None and trial % 4 == 1:
+            vc.append([int(rng.integers(3, 20)), goal[0], goal[1]])
+        ec = []
+        for _ in range(int(rng.integers(0, 30))):
+            x, y = int(rng.integers(0, d)), int(rng.integers(0, d))
+            dx, dy = [(0, 0), (1, 0), (-1, 0), (0, 1), (0, -1)][int(rng.integers(0, 5))]
+            ec.append([int(rng.integers(0, 14)), x, y, x + dx, y + dy])
+        cap = int(rng.choice([-1, -1, -1, 30]))
+        o = oracle_mod.ta_ll_search(m, s, goal, vc, ec, cap_expansions=cap)
+        r = emu_search_ta(emu, m, s, goal, vc, ec, max_exp=cap)
+        n += _compare_ta(r, o)
+    assert n >= 100
