@@ -93,7 +93,12 @@ def cpu_leg(oracle, ia, gpu_results, cap, n_sample, hl):
                 mism += 1
         elif r["status"] != hl.CAP:  # capped on the CPU => must be capped on the GPU too
             mism += 1
+    # SURVEY.md §7 hard part 2: where Boost.Heap is installed the same sample also runs through the oracle built on the real
+    # boost::heap::d_ary_heap ("identical" closes the w > 1 tie-break gap); this image has no Boost: "absent"
+    boost = oracle.boost_crosscheck(oracle.ECBS, ia.dimx, ia.dimy, ia.obstacles[:n], ia.starts[:n], ia.goals[:n], per, w=1.3,
+                                    cap_total=cap, n_threads=1)
     return {"value": float(per[:, 4].sum()) / max(search_s, 1e-12), "unit": "expansions/s", "cores": 1, "kind": "port",
+            "boost_crosscheck": boost,
             "sample": "first %d instances of the leg's batch, oracle ECBS w=1.3 (g++ -O3), search() time only" % n,
             "instances_per_s": n / max(search_s, 1e-12), "seconds": search_s,
             "capped": int((per[:, 0] == -1).sum()), "parity_mismatches_vs_gpu": mism}

@@ -92,6 +92,48 @@ def lib():
     return _LIB
 
 
+_BOOST = None
+
+
+def boost_lib():
+    """The same oracle built on the REAL boost::heap::d_ary_heap (oracle/boost_heap_adapter.hpp, `make liboracle_boost.so`), or
+    None where Boost.Heap is not installed (this image) or the build fails."""
+    global _BOOST
+    if _BOOST is None:
+        so = os.path.join(_HERE, "liboracle_boost.so")
+        try:
+            subprocess.check_call(["make", "-C", _HERE, "liboracle_boost.so"], stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL)
+            L = ctypes.CDLL(so)
+            L.oracle_heap_kind.restype = ctypes.c_int
+            if L.oracle_heap_kind() != 1:
+                raise OSError("not a Boost build")
+            L.oracle_mapf_solve_batch.restype = ctypes.c_int64
+            L.oracle_mapf_solve_batch.argtypes = lib().oracle_mapf_solve_batch.argtypes
+            _BOOST = L
+        except (OSError, subprocess.CalledProcessError):
+            _BOOST = False
+    return _BOOST or None
+
+
+def boost_crosscheck(algo, dimx, dimy, obstacles, starts, goals, per_restated, w=1.0, cap_total=-1, n_threads=1):
+    """Runs the instances through the Boost-backed oracle and compares (rc, cost, makespan, highLevelExpanded,
+    lowLevelExpanded) with `per_restated` (the [n][6] array mapf_solve_batch returned for the same instances).
+    "absent" | "identical" | {"mismatches": k, "of": n}."""
+    L = boost_lib()
+    if L is None:
+        return "absent"
+    ob = np.ascontiguousarray(obstacles, dtype=np.int32)
+    st = np.ascontiguousarray(starts, dtype=np.int32)
+    go = np.ascontiguousarray(goals, dtype=np.int32)
+    n = len(st)
+    out = np.zeros((n, 6), dtype=np.int64)
+    L.oracle_mapf_solve_batch(algo, w, n, dimx, dimy, ob.shape[1], ob.ctypes.data_as(I32P), st.shape[1], st.ctypes.data_as(I32P),
+                              go.ctypes.data_as(I32P), cap_total, n_threads, out.ctypes.data_as(I64P))
+    bad = int((out[:, :5] != np.asarray(per_restated)[:n, :5]).any(axis=1).sum())
+    return "identical" if bad == 0 else {"mismatches": bad, "of": n}
+
+
 def _i32(a):
     a = np.ascontiguousarray(np.asarray(a, dtype=np.int32))
     return a, a.ctypes.data_as(I32P)

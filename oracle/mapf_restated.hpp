@@ -321,7 +321,7 @@ class CBS {  // cbs.hpp:79-249
       if (!lowLevel(i, root.constraints[i], starts[i], root.solution[i])) return false;
       root.cost += root.solution[i].cost;
     }
-    MutableBinaryHeap<HLNode, HLLess> open;
+    ORACLE_HEAP<HLNode, HLLess> open;
     open.push(root);
     solution.clear();
     int id = 1;
@@ -379,7 +379,7 @@ class ECBS {  // ecbs.hpp:103-423
   struct HLLess {  // ecbs.hpp:321-325
     bool operator()(const HLNode& a, const HLNode& b) const { return a.cost > b.cost; }
   };
-  typedef MutableBinaryHeap<HLNode, HLLess> Open;
+  typedef ORACLE_HEAP<HLNode, HLLess> Open;
   typedef Open::handle_type OpenHandle;
   struct FocalLess {  // ecbs.hpp:344-352
     const Open* open;
@@ -437,7 +437,7 @@ class ECBS {  // ecbs.hpp:103-423
     root.focalHeuristic = m_env.focalHeuristic(root.solution);
 
     Open open;
-    MutableBinaryHeap<OpenHandle, FocalLess> focal(FocalLess{&open});
+    ORACLE_HEAP<OpenHandle, FocalLess> focal(FocalLess{&open});
     OpenHandle h0 = open.push(root);
     focal.push(h0);
     int bestCost = open[h0].cost;

@@ -8,6 +8,13 @@
 #include <thread>
 #include <vector>
 
+#ifdef ORACLE_USE_BOOST_HEAP  // cross-check build (Makefile: liboracle_boost.so)
+#include "boost_heap_adapter.hpp"
+#ifndef ORACLE_HAVE_BOOST_HEAP
+#error "liboracle_boost.so needs <boost/heap/d_ary_heap.hpp>"
+#endif
+#define ORACLE_HEAP BoostHeap
+#endif
 #include "grid2d_restated.hpp"
 #include "mapf_restated.hpp"
 #include "sipp_restated.hpp"
@@ -31,6 +38,15 @@ int actionCode(Action a) { return static_cast<int>(a); }
 }  // namespace
 
 extern "C" {
+
+// 0: the heaps are the restated MutableBinaryHeap; 1: this library was built on the real boost::heap::d_ary_heap
+int oracle_heap_kind(void) {
+#ifdef ORACLE_USE_BOOST_HEAP
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 // algo: 0 = CBS (cbs.hpp), 1 = ECBS (ecbs.hpp, bound w as float32).
 // stats[0..5] = cost, makespan, highLevelExpanded, lowLevelExpanded, elapsed_ns (search() only), n_ll_searches

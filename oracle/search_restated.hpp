@@ -17,6 +17,12 @@
 
 #include "heap_restated.hpp"
 
+// The heap type of every search and conflict-tree loop of the oracle: the restated one, unless a cross-check build
+// (boost_heap_adapter.hpp, `make liboracle_boost.so`) names the real Boost.Heap adapter.
+#ifndef ORACLE_HEAP
+#define ORACLE_HEAP MutableBinaryHeap
+#endif
+
 namespace oracle {
 
 template <typename State, typename Action, typename Cost>
@@ -49,7 +55,7 @@ class AStar {
       return a.g < b.g;
     }
   };
-  typedef MutableBinaryHeap<OpenRec, OpenLess> Open;
+  typedef ORACLE_HEAP<OpenRec, OpenLess> Open;
 
  public:
   explicit AStar(Environment& env) : m_env(env) {}
@@ -144,7 +150,7 @@ class AStarEpsilon {
       return a.g < b.g;
     }
   };
-  typedef MutableBinaryHeap<OpenRec, OpenLess> Open;
+  typedef ORACLE_HEAP<OpenRec, OpenLess> Open;
   typedef typename Open::handle_type OpenHandle;
   struct FocalLess {  // a_star_epsilon.hpp:346-366 — compares the open records behind two handles
     const Open* open;
@@ -156,7 +162,7 @@ class AStarEpsilon {
       return a.g < b.g;
     }
   };
-  typedef MutableBinaryHeap<OpenHandle, FocalLess> Focal;
+  typedef ORACLE_HEAP<OpenHandle, FocalLess> Focal;
 
  public:
   AStarEpsilon(Environment& env, float w) : m_env(env), m_w(w) {}

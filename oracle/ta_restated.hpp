@@ -243,7 +243,7 @@ inline bool cbsFixedTasks(int dimx, int dimy, const std::unordered_set<Cell, Cel
     if (!search(i, start.constraints[i], start.solution[i])) return false;
     start.cost += start.solution[i].cost;
   }
-  MutableBinaryHeap<Node, Worse> open;
+  ORACLE_HEAP<Node, Worse> open;
   open.push(start);
   int id = 1;
   while (!open.empty()) {

@@ -37,3 +37,14 @@ def test_heap_random_ops_and_ordered_walks(oracle_mod):
         layout, w1, w2 = oracle_mod.heap_replay(ops)
         assert w1 == w2, trial
         assert sorted(w1) == sorted(layout)
+
+
+def test_boost_crosscheck_hook_reports_absent_here(oracle_mod):
+    """The oracle's heaps come from ORACLE_HEAP; `make liboracle_boost.so` rebuilds it on the real boost::heap::d_ary_heap
+    where that header exists.  This image has no Boost: the hook must say so (and never pretend otherwise)."""
+    import numpy as np
+    assert oracle_mod.lib().oracle_heap_kind() == 0
+    if oracle_mod.boost_lib() is None:
+        per = np.zeros((1, 6), dtype=np.int64)
+        assert oracle_mod.boost_crosscheck(oracle_mod.ECBS, 4, 4, np.zeros((1, 0, 2)), np.zeros((1, 1, 2)),
+                                           np.zeros((1, 1, 2)), per) == "absent"
