@@ -467,8 +467,38 @@ def main():
         if sharded_ct is not None:
             by["sharded_conflict_tree"] = sharded_ct
         out["by_workload"] = by
+        # How much of the GPU a given number of host threads can feed (an 8-GPU job on this pool's 16-CPU quota has two
+        # per GPU): one short step of the headline shape per thread count, each with its own solver (one engine, one
+        # resident launch per thread; the chip's resident wavefronts are divided among the engines)
+        if world == 1 and args.legs != "none" and first_batch is not None:
+            sweep = {}
+            solver.close()
+            solver = None
+            nb = min(B, 65536)
+            sub = first_batch[:nb]
+            for t in (16, 8, 4, 2):
+                if t > max(hc, 2):
+                    continue
+                sv = hl.BatchSolver(device=local_rank, n_threads=t, slots=min(2048, max(512, 2048 // t)))
+                try:
+                    prep = sv.prepare(sub, want_paths=False)
+                    sv.solve_prepared(prep, algo=hl.ECBS, w=1.3, max_ll_expansions=args.max_ll_expansions, raw=True)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    _, st = sv.solve_prepared(prep, algo=hl.ECBS, w=1.3, max_ll_expansions=args.max_ll_expansions, raw=True)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t1
+                    sv.release(prep)
+                    sweep[str(t)] = {"value": st["ll_expansions"] / dt, "seconds": dt, "instances": nb}
+                finally:
+                    sv.close()
+            if "16" in sweep:
+                for t in sweep:
+                    sweep[t]["vs_16_threads"] = sweep[t]["value"] / sweep["16"]["value"]
+            out["host_threads_sweep"] = sweep
         print(json.dumps(out), flush=True)
-    solver.close()
+    if solver is not None:
+        solver.close()
     if dist is not None:
         dist.destroy_process_group()
 

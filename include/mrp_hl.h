@@ -139,6 +139,22 @@ int mrp_hl_ct_deliver(mrp_hl_ct* ct, int32_t group, int32_t n, const mrp_ll_resu
 int32_t mrp_hl_ct_done(const mrp_hl_ct* ct);
 int mrp_hl_ct_solution(const mrp_hl_ct* ct, mrp_hl_solution* out);
 
+/* One round of a conflict tree whose searches are sharded over `world` ranks (ct_sharded.py): every rank
+ * holds the same tree, group j of the pending requests belongs to rank j % world.
+ *   mrp_hl_ct_round_mine   runs THIS rank's requests on `ll` (mrp_ll_search_batch) and packs their results into `rows`, one
+ *                          row of 8 + max_states int32 words per search:
+ *                            group, slot, status, cost, fmin, expanded (low 31 bits), expanded >> 31, n_states,
+ *                            then one word x | y << 16 per state.
+ *                          rows_per_rank[world] receives how many rows every rank produces this round (the same on all
+ *                          ranks: the shape of the all-gather); returns the number of rows written (<= cap_rows), or
+ *                          a negative MRP_LL_E_* — in which case the rank still writes ONE row with group = INT32_MIN, so that
+ *                          the collective can take place and every rank sees the failure.
+ *   mrp_hl_ct_deliver_rows takes the gathered rows of all ranks ([world][rows_stride][8 + max_states]) and delivers the
+ *                          groups in their pending order.  MRP_LL_E_DEVICE if any rank reported a failure. */
+int32_t mrp_hl_ct_round_mine(mrp_hl_ct* ct, mrp_ll_ctx* ll, int32_t rank, int32_t world, int32_t max_states, int32_t* rows,
+                             int32_t cap_rows, int32_t* rows_per_rank);
+int mrp_hl_ct_deliver_rows(mrp_hl_ct* ct, const int32_t* gathered, int32_t world, int32_t rows_stride, int32_t max_states);
+
 /* BASELINE.json configs[0] — `./a_star` on a text map (example/a_star.cpp:72-125,190-191) — is host plumbing: a single
  * 2-D A* (AStar::search a_star.hpp:63-161, neighbours Up, Down, Left, Right, unit costs, Manhattan heuristic), run on
  * the CPU with the reference's heap tie-breaks.  obstacle_mask[y * dimx + x] != 0 = '#'.  Returns the number of states

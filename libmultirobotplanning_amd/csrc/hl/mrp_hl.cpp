@@ -1361,6 +1361,126 @@ int mrp_hl_ct_deliver(mrp_hl_ct* c, int32_t group, int32_t n, const mrp_ll_resul
 
 int32_t mrp_hl_ct_done(const mrp_hl_ct* c) { return c && c->inst->done() ? 1 : 0; }
 
+namespace {
+constexpr int32_t kRowHdr = 8;
+constexpr int32_t kFailedRound = INT32_MIN;  // group word of a failure row (group ids are >= -1: -1 is the root step)
+// the pending groups in order, and which rank searches which (group j -> rank j % world)
+void roundOwners(const mrp_hl_ct& c, int32_t world, std::vector<int32_t>& groups, std::vector<int32_t>& ownerOfReq) {
+  groups.clear();
+  ownerOfReq.assign(c.req.size(), 0);
+  for (size_t k = 0; k < c.req.size(); ++k) {
+    if (groups.empty() || groups.back() != c.req[k].group) groups.push_back(c.req[k].group);
+    ownerOfReq[k] = static_cast<int32_t>((groups.size() - 1) % static_cast<size_t>(world));
+  }
+}
+}  // namespace
+
+int32_t mrp_hl_ct_round_mine(mrp_hl_ct* c, mrp_ll_ctx* ll, int32_t rank, int32_t world, int32_t maxStates, int32_t* rows,
+                             int32_t capRows, int32_t* rowsPerRank) {
+  if (!c || !ll || !rows || !rowsPerRank || world < 1 || rank < 0 || rank >= world || maxStates < 1 || capRows < 1)
+    return MRP_LL_E_INVALID;
+  const size_t rowWords = static_cast<size_t>(kRowHdr) + static_cast<size_t>(maxStates);
+  std::vector<int32_t> groups, owner;
+  roundOwners(*c, world, groups, owner);
+  for (int32_t r = 0; r < world; ++r) rowsPerRank[r] = 0;
+  std::vector<size_t> mine;
+  for (size_t k = 0; k < c->req.size(); ++k) {
+    rowsPerRank[owner[k]] += 1;
+    if (owner[k] == rank) mine.push_back(k);
+  }
+  auto fail = [&](int rc) {
+    std::memset(rows, 0, rowWords * sizeof(int32_t));
+    rows[0] = kFailedRound;
+    rows[2] = rc;
+    return rc;
+  };
+  if (static_cast<int32_t>(mine.size()) > capRows) return fail(MRP_LL_E_INVALID);
+  std::vector<mrp_ll_job> jobs(mine.size());
+  std::vector<mrp_ll_result> res(mine.size());
+  std::vector<int32_t> states(mine.size() * static_cast<size_t>(maxStates) * 3);
+  for (size_t q = 0; q < mine.size(); ++q) {
+    jobs[q] = c->jobs[mine[q]];
+    std::memset(&res[q], 0, sizeof(mrp_ll_result));
+    res[q].states_txy = states.data() + q * static_cast<size_t>(maxStates) * 3;
+    res[q].states_cap = maxStates;
+  }
+  if (!mine.empty()) {
+    const int rc = mrp_ll_search_batch(ll, static_cast<int32_t>(jobs.size()), jobs.data(), res.data());
+    if (rc != MRP_LL_SUCCESS) return fail(rc);
+  }
+  for (size_t q = 0; q < mine.size(); ++q) {
+    int32_t* row = rows + q * rowWords;
+    const mrp_ll_result& r = res[q];
+    if (r.status == MRP_LL_PATH_TRUNCATED || r.n_states > maxStates) return fail(MRP_LL_E_INVALID);  // max_states too small
+    row[0] = c->req[mine[q]].group;
+    row[1] = c->req[mine[q]].slot;
+    row[2] = r.status;
+    row[3] = r.cost;
+    row[4] = r.fmin;
+    row[5] = static_cast<int32_t>(r.expanded & 0x7FFFFFFF);
+    row[6] = static_cast<int32_t>(r.expanded >> 31);
+    row[7] = r.n_states;
+    for (int32_t k = 0; k < r.n_states; ++k) row[kRowHdr + k] = r.states_txy[3 * k + 1] | (r.states_txy[3 * k + 2] << 16);
+  }
+  return static_cast<int32_t>(mine.size());
+}
+
+int mrp_hl_ct_deliver_rows(mrp_hl_ct* c, const int32_t* gathered, int32_t world, int32_t rowsStride, int32_t maxStates) {
+  if (!c || !gathered || world < 1 || rowsStride < 1 || maxStates < 1) return MRP_LL_E_INVALID;
+  const size_t rowWords = static_cast<size_t>(kRowHdr) + static_cast<size_t>(maxStates);
+  std::vector<int32_t> groups, owner;
+  roundOwners(*c, world, groups, owner);
+  std::vector<int32_t> perRank(world, 0);
+  for (size_t k = 0; k < c->req.size(); ++k) perRank[owner[k]] += 1;
+  // a rank that failed sent one row marked kFailedRound: every rank stops here, together
+  for (int32_t r = 0; r < world; ++r)
+    if (gathered[static_cast<size_t>(r) * rowsStride * rowWords] == kFailedRound) return MRP_LL_E_DEVICE;
+  struct Row {
+    int32_t slot;
+    const int32_t* w;
+  };
+  std::map<int32_t, std::vector<Row>> byGroup;
+  for (int32_t r = 0; r < world; ++r) {
+    if (perRank[r] > rowsStride) return MRP_LL_E_INVALID;
+    for (int32_t q = 0; q < perRank[r]; ++q) {
+      const int32_t* w = gathered + (static_cast<size_t>(r) * rowsStride + q) * rowWords;
+      byGroup[w[0]].push_back(Row{w[1], w});
+    }
+  }
+  std::vector<int32_t> states;
+  std::vector<mrp_ll_result> res;
+  for (int32_t g : groups) {  // the same order on every rank
+    auto it = byGroup.find(g);
+    if (it == byGroup.end()) return MRP_LL_E_INVALID;
+    std::vector<Row>& rws = it->second;
+    std::sort(rws.begin(), rws.end(), [](const Row& a, const Row& b) { return a.slot < b.slot; });
+    res.assign(rws.size(), mrp_ll_result());
+    states.assign(rws.size() * static_cast<size_t>(maxStates) * 3, 0);
+    for (size_t q = 0; q < rws.size(); ++q) {
+      const int32_t* w = rws[q].w;
+      mrp_ll_result& r = res[q];
+      std::memset(&r, 0, sizeof(r));
+      r.status = w[2];
+      r.cost = w[3];
+      r.fmin = w[4];
+      r.expanded = static_cast<int64_t>(w[5]) | (static_cast<int64_t>(w[6]) << 31);
+      r.n_states = w[7];
+      if (r.n_states < 0 || r.n_states > maxStates) return MRP_LL_E_INVALID;
+      r.states_txy = states.data() + q * static_cast<size_t>(maxStates) * 3;
+      r.states_cap = maxStates;
+      for (int32_t k = 0; k < r.n_states; ++k) {
+        r.states_txy[3 * k] = k;
+        r.states_txy[3 * k + 1] = w[kRowHdr + k] & 0xFFFF;
+        r.states_txy[3 * k + 2] = w[kRowHdr + k] >> 16;
+      }
+    }
+    const int rc = mrp_hl_ct_deliver(c, g, static_cast<int32_t>(res.size()), res.data());
+    if (rc != MRP_LL_SUCCESS) return rc;
+    if (c->inst->done()) break;
+  }
+  return MRP_LL_SUCCESS;
+}
+
 int mrp_hl_ct_solution(const mrp_hl_ct* c, mrp_hl_solution* out) {
   if (!c || !out || !c->inst->done()) return MRP_LL_E_INVALID;
   writeSolution(*c->inst, *out);

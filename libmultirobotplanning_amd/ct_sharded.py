@@ -13,6 +13,11 @@ all of them deliver the groups in the same order.  Children are committed strict
 Collectives (RCCL when the backend is "nccl", gloo on CPU): one broadcast of the instance (the static map, starts,
 goals) from rank 0, then one fixed-shape int32 all-gather per round — per result: group, slot, status, cost (the
 incumbent's contribution), fmin, expansions and the path.  Messages are a few KB: latency-bound, as SURVEY §8e expects.
+
+A round is native: `mrp_hl_ct_round_mine` (libmrp_hl) runs this rank's searches straight from the tree's own job structs
+on the rank's engine and packs the rows, `mrp_hl_ct_deliver_rows` unpacks all ranks' rows and steps the tree; Python only
+moves one int32 buffer through the collective.  A failing rank contributes a failure row, so all ranks raise together
+instead of leaving the others blocked in the all-gather.  (`executor` callables — Python per request — remain for tests.)
 """
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -45,8 +50,49 @@ def broadcast_instance(inst: Optional[Dict], dist, device: str = "cpu", src: int
                 goals=v[n_ob + n_ag:].tolist())
 
 
-def gpu_executor(inst: Dict, device: int = 0, max_horizon: int = 512) -> Callable[[Sequence[Dict]], List[Dict]]:
-    """The product executor: this rank's MI355X through the C-ABI (ll.LowLevelEngine); no CPU fallback."""
+class NativeEngine:
+    """The product executor: this rank's engine as a mrp_ll_ctx handle for the native rounds (mrp_hl_ct_round_mine).
+    `lib` = the ctypes library that exports the mrp_ll_* C-ABI: libmrp_ll.so on a GPU (no CPU fallback); tests pass the
+    oracle-backed CPU build (tests/support/mock_ll.cpp inside tests/_build/libmrp_hl_cpu.so)."""
+
+    def __init__(self, inst: Dict, device: int = 0, max_horizon: int = 512, lib=None):
+        from . import ll
+        import ctypes
+        self._lib = lib if lib is not None else ll.load_library()
+        opt = ll.mrp_ll_options(device, 1, 64, 0, max_horizon, 0, 0, 0)
+        h = ctypes.c_void_p()
+        self._lib.mrp_ll_create.restype = ctypes.c_int
+        self._lib.mrp_ll_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        if self._lib.mrp_ll_create(ctypes.byref(opt), ctypes.byref(h)) != 0:
+            raise RuntimeError("mrp_ll_create failed (no HIP device?)")
+        self.handle = h
+        ob = np.ascontiguousarray(np.asarray(inst["obstacles"], dtype=np.int32).reshape(-1, 2))
+        mid = ctypes.c_int32(-1)
+        self._lib.mrp_ll_upload_map.restype = ctypes.c_int
+        self._lib.mrp_ll_upload_map.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+        rc = self._lib.mrp_ll_upload_map(h, inst["dimx"], inst["dimy"], len(ob), ob.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                         ctypes.byref(mid))
+        if rc != 0 or mid.value != 0:
+            raise RuntimeError("mrp_ll_upload_map failed rc=%d" % rc)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            import ctypes
+            self._lib.mrp_ll_destroy.restype = None
+            self._lib.mrp_ll_destroy.argtypes = [ctypes.c_void_p]
+            self._lib.mrp_ll_destroy(self.handle)
+            self.handle = None
+
+
+
+def gpu_executor(inst: Dict, device: int = 0, max_horizon: int = 512):
+    """This rank's MI355X for solve_sharded (native rounds)."""
+    return NativeEngine(inst, device=device, max_horizon=max_horizon)
+
+
+def python_executor(inst: Dict, device: int = 0, max_horizon: int = 512) -> Callable[[Sequence[Dict]], List[Dict]]:
+    """The same engine behind a per-request Python callable (round 2's path; kept for comparison)."""
     from . import ll
     eng = ll.LowLevelEngine(device=device, n_tickets=1, slots=64, max_horizon=max_horizon)
     mid = eng.upload_map(inst["dimx"], inst["dimy"], inst["obstacles"])
@@ -78,8 +124,30 @@ def solve_sharded(inst: Dict, executor: Callable[[Sequence[Dict]], List[Dict]], 
     ct = hl.ConflictTree(inst, algo=algo, w=w, map_id=0, spec_width=spec_width, max_ll_expansions=max_ll_expansions,
                          max_hl_expansions=max_hl_expansions, _lib_path=_lib_path)
     rounds = ran = 0
+    native = isinstance(executor, NativeEngine)
     try:
         while not ct.done():
+            if native:
+                # one native round: this rank's searches + rows; ONE all-gather; all ranks step the tree with the same rows
+                n_req = ct.n_requests()
+                if n_req == 0:
+                    raise RuntimeError("conflict tree is neither done nor asking for searches")
+                rows = np.zeros((n_req, 8 + max_states), dtype=np.int32)
+                per_rank = np.zeros(world, dtype=np.int32)
+                n_mine = ct.round_mine(executor.handle, me, world, rows, per_rank)
+                stride = max(int(per_rank.max()), 1)
+                ran += max(n_mine, 0)
+                rounds += 1
+                mine_rows = np.ascontiguousarray(rows[:stride])
+                if world == 1:
+                    gathered = mine_rows[None]
+                else:
+                    buf = torch.from_numpy(mine_rows).to(device)
+                    parts = [torch.empty_like(buf) for _ in range(world)]
+                    dist.all_gather(parts, buf)
+                    gathered = torch.stack(parts).cpu().numpy()
+                ct.deliver_rows(gathered)  # raises on EVERY rank if any rank sent a failure row
+                continue
             reqs = ct.requests()
             if not reqs:
                 raise RuntimeError("conflict tree is neither done nor asking for searches")
@@ -104,7 +172,7 @@ def solve_sharded(inst: Dict, executor: Callable[[Sequence[Dict]], List[Dict]], 
                     buf[i, :_HDR] = torch.tensor([r["group"], r["slot"], x["status"], x["cost"], x["fmin"],
                                                   x["expanded"] & 0x7FFFFFFF, x["expanded"] >> 31, n], dtype=torch.int32)
                     if n:
-                        buf[i, _HDR:_HDR + n] = torch.tensor([p[0] | (p[1] << 8) for p in x["states"]], dtype=torch.int32)
+                        buf[i, _HDR:_HDR + n] = torch.tensor([p[0] | (p[1] << 16) for p in x["states"]], dtype=torch.int32)
                 buf = buf.to(device)
                 gathered = [torch.zeros_like(buf) for _ in range(world)]
                 dist.all_gather(gathered, buf)
@@ -119,7 +187,7 @@ def solve_sharded(inst: Dict, executor: Callable[[Sequence[Dict]], List[Dict]], 
                         rows.append((int(h[0]), int(h[1]),
                                      dict(status=int(h[2]), cost=int(h[3]), fmin=int(h[4]),
                                           expanded=int(h[5]) | (int(h[6]) << 31),
-                                          states=[[int(c) & 0xFF, int(c) >> 8] for c in cells])))
+                                          states=[[int(c) & 0xFFFF, int(c) >> 16] for c in cells])))
             by_group: Dict[int, List] = {}
             for g, slot, x in rows:
                 by_group.setdefault(g, []).append((slot, x))

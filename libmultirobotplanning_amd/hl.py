@@ -440,6 +440,31 @@ class ConflictTree:
         if rc != 0:
             raise RuntimeError("mrp_hl_ct_deliver(group=%d, n=%d) failed rc=%d" % (group, n, rc))
 
+    def n_requests(self) -> int:
+        return int(self._lib.mrp_hl_ct_n_requests(self._h))
+
+    def round_mine(self, ll_handle, rank: int, world: int, rows: np.ndarray, rows_per_rank: np.ndarray) -> int:
+        """mrp_hl_ct_round_mine: run this rank's share of the pending searches on the engine `ll_handle` (a mrp_ll_ctx of
+        the same library) and pack the results into `rows` ([cap][8 + max_states] int32).  Returns the rows written, or a
+        negative MRP_LL_E_* (then rows[0] is the failure row that still has to take part in the all-gather)."""
+        fn = self._lib.mrp_hl_ct_round_mine
+        fn.restype = ctypes.c_int32
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, I32P, ctypes.c_int32, I32P]
+        return int(fn(self._h, ll_handle, rank, world, rows.shape[1] - 8, rows.ctypes.data_as(I32P), rows.shape[0],
+                      rows_per_rank.ctypes.data_as(I32P)))
+
+    def deliver_rows(self, gathered: np.ndarray) -> None:
+        """mrp_hl_ct_deliver_rows: gathered = [world][rows][8 + max_states] int32, what the all-gather of every rank's
+        round_mine rows returned."""
+        fn = self._lib.mrp_hl_ct_deliver_rows
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, I32P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        g = np.ascontiguousarray(gathered, dtype=np.int32)
+        rc = fn(self._h, g.ctypes.data_as(I32P), g.shape[0], g.shape[1], g.shape[2] - 8)
+        if rc != 0:
+            raise RuntimeError("mrp_hl_ct_deliver_rows failed rc=%d (a rank reported a failed round, or the rows do not "
+                               "match the pending requests)" % rc)
+
     def solution(self, path_cap: int = 1024) -> Dict:
         sol = mrp_hl_solution()
         plen = np.zeros(max(self.n_agents, 1), dtype=np.int32)

@@ -101,6 +101,15 @@ for case in cases:
         return res
     r = ct_sharded.solve_sharded(inst, run, dist, algo=case["algo"], w=1.3, spec_width=case["spec"], device="cpu",
                                  max_ll_expansions=case.get("cap", -1), _lib_path={lib!r})
+    # ... and the product's round: native pack / deliver (mrp_hl_ct_round_mine / _deliver_rows) on an engine handle — here
+    # the oracle-backed C-ABI inside the CPU build of the drivers (tests/support/mock_ll.cpp)
+    import ctypes
+    eng = ct_sharded.NativeEngine(inst, lib=ctypes.CDLL({lib!r}))
+    rn = ct_sharded.solve_sharded(inst, eng, dist, algo=case["algo"], w=1.3, spec_width=case["spec"], device="cpu",
+                                  max_ll_expansions=case.get("cap", -1), _lib_path={lib!r})
+    eng.close()
+    r["native_same"] = all(r[k] == rn[k] for k in ("status", "cost", "makespan", "hl_expanded", "ll_expanded")) and \
+        r.get("paths") == rn.get("paths") and rn["searches_run_here"] > 0
     out.append(r)
 with open({outdir!r} + "/rank%d.json" % rank, "w") as f:  # (two ranks printing to one pipe can interleave)
     json.dump(out, f)
@@ -140,9 +149,11 @@ def test_one_conflict_tree_sharded_over_two_ranks(oracle_mod, bench_instances, o
             assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
                 hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"]), (n, rank)
             assert r["searches_run_here"] > 0
+            assert r["native_same"], (n, rank)
         assert per_rank[0][i]["paths"] == per_rank[1][i]["paths"]
         assert per_rank[0][i]["rounds"] == per_rank[1][i]["rounds"]
         # the two ranks split the work: together they ran every consumed search (plus any look-ahead that was not)
         assert per_rank[0][i]["searches_run_here"] + per_rank[1][i]["searches_run_here"] >= per_rank[0][i]["ll_searches"]
         assert per_rank[0][i]["rounds"] < per_rank[0][i]["ll_searches"]
     assert per_rank[0][-1]["status"] == hl.CAP and per_rank[1][-1]["status"] == hl.CAP
+    assert per_rank[0][-1]["native_same"] and per_rank[1][-1]["native_same"]
