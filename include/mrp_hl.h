@@ -110,7 +110,9 @@ typedef struct mrp_hl_sipp_solution {
   int64_t cost;
   int64_t low_level_expanded;
   int32_t n_planned;
-  int32_t reserved;
+  int32_t status;       /* 0: every agent got the reference's answer (planned or "not found"); otherwise the MRP_LL_*
+                         * capacity status (expansion cap, node arena, horizon) of the search that stopped THIS
+                         * instance — its later agents are not planned; other instances of the batch are unaffected */
   int32_t* planned;     /* caller buffer [n_agents] */
   int32_t* n_states;    /* caller buffer [n_agents] */
   int32_t* states_xyt;  /* caller buffer [n_agents][state_cap][3] or NULL */

@@ -353,8 +353,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     P.outSlot.assign(jobs.size(), -1);
     if (pathSlots > 0)
       for (size_t q = 0; q < jobs.size(); ++q) {
-        jobs[q].result_path_id = P.outSlot[q] = slotPool.take();
-        jobs[q].flags |= MRP_LL_JOB_STORE_RESULT;
+        jobs[q].result_path_id = P.outSlot[q] = slotPool.take();  // -1: store full, later jobs ship this path as a table
+        if (P.outSlot[q] >= 0) jobs[q].flags |= MRP_LL_JOB_STORE_RESULT;
       }
     P.res.assign(jobs.size(), mrp_ll_result());
     P.states.resize(jobs.size() * static_cast<size_t>(cap) * 3);
@@ -815,7 +815,9 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   int32_t storeMaxAgents = 128;
   if (const char* e = std::getenv("MRP_HL_STORE_MAX_AGENTS")) storeMaxAgents = std::atoi(e);
   if (opt.algo == MRP_HL_ECBS && opt.mode != 1 && maxAgents <= storeMaxAgents) {
-    pathSlots = 1 << 18;
+    // every live conflict-tree node of every active instance holds one slot per replaced path: a worker with 16384
+    // active instances (few threads, big batch) needs millions of them, and a slot is max_horizon halfwords
+    pathSlots = std::max(1 << 18, std::min(1 << 22, (1 << 22) / std::max(nThreads, 1)));
     if (const char* e = std::getenv("MRP_HL_PATH_SLOTS")) pathSlots = std::max(0, std::atoi(e));  // 0 = ship tables (round 1)
     if (pathSlots != s->pathSlots) {
       for (int32_t t = 0; t < static_cast<int32_t>(s->engines.size()); ++t)
@@ -874,6 +876,13 @@ namespace {
 // The loop of mapf_prioritized_sipp.cpp:214-270 for instances idx[...] on one engine: round r plans agent r of every
 // instance that still has one (agents of one instance are a chain — each plans against the intervals the earlier ones
 // occupy — instances are independent).
+// Test knob (MRP_HL_SIPP_MAX_EXPANSIONS): the expansion cap of every search of the prioritized-SIPP drivers, read per
+// call; the reference has none (-1), and a capped search ends its instance with that status.
+int64_t sippMaxExpansions() {
+  const char* e = std::getenv("MRP_HL_SIPP_MAX_EXPANSIONS");
+  return e && std::atoll(e) > 0 ? std::atoll(e) : -1;
+}
+
 void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, int32_t nTickets, const mrp_hl_instance* instances,
                   mrp_hl_sipp_solution* sols, const std::vector<int32_t>& idx, GroupResult& out) {
   struct Iv { int32_t s, e; };
@@ -903,6 +912,7 @@ void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, int32_t nTickets, const mrp_
     sols[idx[q]].cost = 0;
     sols[idx[q]].low_level_expanded = 0;
     sols[idx[q]].n_planned = 0;
+    sols[idx[q]].status = 0;
     st[q].dimx = in.dimx;
     st[q].perCell.assign(static_cast<size_t>(std::max(in.dimx, 0)) * std::max(in.dimy, 0), std::vector<Iv>());
   }
@@ -951,7 +961,7 @@ void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, int32_t nTickets, const mrp_
       j.start_y = in.starts_xy[2 * p.agent + 1];
       j.goal_x = in.goals_xy[2 * p.agent];
       j.goal_y = in.goals_xy[2 * p.agent + 1];
-      j.max_expansions = -1;
+      j.max_expansions = sippMaxExpansions();
       j.n_collision_locations = static_cast<int32_t>(p.cnt.size());
       j.collision_xy = p.xy.data();
       j.collision_count = p.cnt.data();
@@ -991,8 +1001,14 @@ void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, int32_t nTickets, const mrp_
       so.low_level_expanded += r.expanded;
       out.expansions += r.expanded;
       if (r.status != MRP_LL_OK && r.status != MRP_LL_NO_SOLUTION) {
-        out.err = "prioritized SIPP: low-level capacity status " + std::to_string(r.status);
-        return false;
+        // a capacity status (expansion cap, node arena, horizon) is not the reference's answer for this agent, and every
+        // later agent of the instance would plan against the wrong intervals: THIS instance stops here and says so in
+        // its status; the other instances of the batch are not affected
+        so.status = r.status;
+        if (so.planned) so.planned[a] = 0;
+        if (so.n_states) so.n_states[a] = 0;
+        p.agent = instances[idx[H.owner[jq]]].n_agents;
+        continue;
       }
       const bool ok = r.status == MRP_LL_OK;
       if (so.planned) so.planned[a] = ok ? 1 : 0;
@@ -1071,6 +1087,7 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
     sols[idx[q]].cost = 0;
     sols[idx[q]].low_level_expanded = 0;
     sols[idx[q]].n_planned = 0;
+    sols[idx[q]].status = 0;
     if (mrp_ll_sipp_table_create(ctx, st[q].mapId, &st[q].tab) != MRP_LL_SUCCESS) {
       out.err = "mrp_ll_sipp_table_create failed";
       return;
@@ -1105,7 +1122,7 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
     j.start_y = in.starts_xy[2 * p.agent + 1];
     j.goal_x = in.goals_xy[2 * p.agent];
     j.goal_y = in.goals_xy[2 * p.agent + 1];
-    j.max_expansions = -1;
+    j.max_expansions = sippMaxExpansions();
     j.sipp_table = p.tab;  // sipp.setCollisionIntervals(location, intervals) for every location (:224-226), kept up to date
     j.sipp_commit = 1;     // ... by the engine: the stays of the path it finds become collision intervals (:237-246)
     std::memset(&p.res, 0, sizeof(p.res));
@@ -1181,9 +1198,12 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
       so.low_level_expanded += r.expanded;
       out.expansions += r.expanded;
       if (r.status != MRP_LL_OK && r.status != MRP_LL_NO_SOLUTION) {
-        out.err = "prioritized SIPP: low-level capacity status " + std::to_string(r.status);
-        failed = true;
-        break;
+        // capacity status: this instance stops here (see runSippGroup), the rest of the batch goes on
+        so.status = r.status;
+        if (so.planned) so.planned[a] = 0;
+        if (so.n_states) so.n_states[a] = 0;
+        p.agent = in.n_agents;
+        continue;
       }
       const bool ok = r.status == MRP_LL_OK;
       if (so.planned) so.planned[a] = ok ? 1 : 0;

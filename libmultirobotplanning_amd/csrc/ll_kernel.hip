@@ -2348,6 +2348,7 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
   uint32_t* const ring0 = P.ring_state;
   uint32_t* const tickets0 = P.queue_head;        // device counters, 64 bytes apart
   uint32_t* const head0 = P.ring_head;            // host words, 64 bytes apart
+  uint32_t* const mirror = P.queue_head + 32;     // device: [0] copy of *head0, [16] copy of *ring_stop (zeroed with the tickets)
   const uint32_t compSize = P.n_slots;
   bool haveBulk = false;                          // a bulk ticket is held and not yet served
   uint32_t bulkT = 0;
@@ -2362,10 +2363,17 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
         bulkT = rfl(atomicAdd(tickets0, lane == 0 ? 1u : 0u));
         haveBulk = true;
       }
-      // Waiting workgroups poll the published-ticket counts and back off in proportion to how far ahead of the bulk
-      // count their ticket is: the next in line looks every ~2 us, the k-th every ~2k us (<= ~100 us), so a thousand
-      // idle wavefronts do not saturate PCIe with reads.
-      // The spin itself uses RELAXED system-scope loads (they go to the host word, not to a cached copy); the ONE acquire
+      // Waiting workgroups do NOT poll the host.  The published-ticket count lives in pinned host memory (head0); its
+      // device-side MIRROR (tickets0[32], in HBM) is what every waiting workgroup looks at, with agent-scope loads that
+      // cost an L2 access.  Exactly one waiting workgroup — the one whose ticket equals the mirror, i.e. the next in line;
+      // tickets are consecutive, so while anybody waits there is one — reads the host's word (every ~2 us), copies it
+      // into the mirror when it has moved, and copies the host's stop flag likewise.  PCIe reads per engine: one poller
+      // instead of one per idle workgroup.  (Round 2 let every idle workgroup poll the host with a back-off; with two
+      // engines of 896 workgroups and a host that cannot keep them busy that is ~4e7 uncached reads/s through a handful
+      // of L2 channels: measured, the HBM tier ran 14x slower and a 65536-instance step took 6.8 s instead of 1 s.)
+      // The others back off in proportion to how far ahead of the mirror their ticket is (next every ~2 us, the k-th
+      // every ~2k us, <= ~100 us).
+      // The host loads are RELAXED system-scope loads (they go to the host word, not to a cached copy); the ONE acquire
       // sits behind the generation match.  An acquire load per poll is a buffer_inv on this CU's L1 — the cache the
       // ten other searches of the CU are working in — for every look of every idle wavefront (MI355X_MICROARCH.md:
       // "polling with ACQUIRE loads -> correct, 2-3x slower per hop").  -DMRP_LL_RING_POLL_ACQUIRE: the old form (A/B).
@@ -2374,7 +2382,23 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
 #else
       constexpr int kPollOrder = __ATOMIC_RELAXED;
 #endif
-      const uint32_t hd = rfl(__hip_atomic_load(head0, kPollOrder, __HIP_MEMORY_SCOPE_SYSTEM));
+      uint32_t hd = rfl(__hip_atomic_load(mirror, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      uint32_t sp = 0;
+#ifndef MRP_LL_RING_POLL_ALL
+      if (hd == bulkT) {  // next in line: look at the host for everybody
+#else
+      {                   // A/B: every waiting workgroup polls the host (round 2)
+#endif
+        const uint32_t hh = rfl(__hip_atomic_load(head0, kPollOrder, __HIP_MEMORY_SCOPE_SYSTEM));
+        if ((int32_t)(hh - hd) > 0) {
+          hd = hh;
+#ifndef MRP_LL_RING_POLL_ALL
+          __hip_atomic_store(mirror, hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // single writer: only T == mirror gets here
+#endif
+        }
+        sp = rfl(__hip_atomic_load(P.ring_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (sp != 0) __hip_atomic_store(mirror + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if ((int32_t)(hd - bulkT) > 0) {
         const uint32_t gen = (bulkT / q0 + 1) & 0x1FFFFFu;
         const uint32_t e = rfl(__hip_atomic_load(ring0 + bulkT % q0, kPollOrder, __HIP_MEMORY_SCOPE_SYSTEM));
@@ -2388,7 +2412,7 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
           break;
         }
       }
-      const uint32_t sp = rfl(__hip_atomic_load(P.ring_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      if (sp == 0) sp = rfl(__hip_atomic_load(mirror + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       if (sp != 0) {
         stop = true;
         break;

@@ -46,7 +46,7 @@ class mrp_hl_batch_stats(ctypes.Structure):
 
 class mrp_hl_sipp_solution(ctypes.Structure):
     _fields_ = [("cost", ctypes.c_int64), ("low_level_expanded", ctypes.c_int64), ("n_planned", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("planned", I32P), ("n_states", I32P), ("states_xyt", I32P),
+                ("status", ctypes.c_int32), ("planned", I32P), ("n_states", I32P), ("states_xyt", I32P),
                 ("state_cap", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
 
 
@@ -354,6 +354,7 @@ class BatchSolver:
         for i in range(n):
             pl, ns, sx = bufs[i]
             out.append(dict(cost=csol[i].cost, expanded=csol[i].low_level_expanded, n_planned=csol[i].n_planned,
+                            status=csol[i].status,
                             planned=pl.tolist(),
                             schedules=[sx[a, :ns[a]].tolist() for a in range(len(pl))] if want_schedules else None))
         stats = dict(wall_seconds=st.wall_seconds, rounds=st.rounds, ll_searches=st.ll_searches,

@@ -27,6 +27,8 @@ for rep in range(int(os.environ.get('MRP_REPS', '3'))):
         st["build_seconds"], st["ll_call_seconds"], ls["pack_ms"] / 1e3, ls["unpack_ms"] / 1e3, ls["kernel_ms"] / 1e3,
         ls["h2d_ms"] / 1e3, ls["d2h_ms"] / 1e3, st["consume_seconds"]), flush=True)
     print("   staged in pinned host memory: %.1f MB = %.0f bytes per search" % (ls["staged_bytes"] / 1e6, ls["staged_bytes"] / max(st["ll_searches"], 1)), flush=True)
+    import collections
+    print("   statuses: " + str(dict(collections.Counter(r["status"] for r in res))), flush=True)
     pf = ls["prof"]
     print("   kernel tiers: LDS %.2f us/expansion over %.4g expansions; arena %.2f us/expansion over %.4g expansions" % (
         pf[0] / 100.0 / max(pf[1], 1), pf[1], pf[2] / 100.0 / max(pf[3], 1), pf[3]), flush=True)

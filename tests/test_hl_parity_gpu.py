@@ -161,6 +161,40 @@ def test_prioritized_sipp_known_answers_and_64x64(solver, oracle_mod, ref_tests)
     assert stats["rounds"] == 100
 
 
+@pytest.mark.parametrize("batch_mode", [False, True])
+def test_prioritized_sipp_capacity_status_is_per_instance(solver, oracle_mod, ref_tests, batch_mode):
+    """A search that ends with a capacity status (here: the expansion cap of the test knob) stops ITS instance — status
+    says which, the agents planned before it keep the reference's schedules — and leaves every other instance of the
+    batch alone (round 2 failed the whole call); both schedules of the driver."""
+    import os
+    from libmultirobotplanning_amd import hl, ll
+    names = list(ref_tests["prioritized_sipp"]["cost"].keys())
+    insts = [ref_tests["mapf"][n] for n in names] + [hl.generate_instance(32000 + k, 32, 32, 204, 30) for k in range(6)]
+    knobs = {"MRP_HL_SIPP_MAX_EXPANSIONS": "60"}
+    if batch_mode:
+        knobs["MRP_HL_SIPP_BATCH"] = "1"
+    os.environ.update(knobs)
+    try:
+        res, _ = solver.prioritized_sipp(insts)
+    finally:
+        for k in knobs:
+            del os.environ[k]
+    stopped = 0
+    for inst, r in zip(insts, res):
+        o = oracle_mod.prioritized_sipp(inst)
+        if r["status"] == 0:
+            assert (r["cost"], r["planned"], r["schedules"]) == (o["cost"], o["planned"], o["schedules"])
+            continue
+        stopped += 1
+        assert r["status"] == ll.CAP_EXPANSIONS
+        # the prefix planned before the capped search is the reference's; nothing is planned after it
+        k = next((a for a in range(len(r["planned"]))
+                  if r["planned"][a] != o["planned"][a] or r["schedules"][a] != o["schedules"][a]), len(r["planned"]))
+        assert r["planned"][k:] == [0] * (len(r["planned"]) - k)
+        assert r["schedules"][:k] == o["schedules"][:k] and r["n_planned"] == sum(o["planned"][:k])
+    assert 0 < stopped < len(insts)
+
+
 def test_bench_scale_properties_and_determinism(solver):
     """At the bench workload's size the oracle is too slow to check everything, so size-independent properties are
     checked on 4096 synthetic agents10 instances (and the oracle on a sample):
