@@ -1,6 +1,10 @@
 # PMC passes over the RESIDENT kernels as they are timed (run on the GPU box through gpurun):
-#   mrp_ll_ecbs_persistent_kernel under `bench.py --steps 1 --warmup 0 --legs none` at the default batch, and
-#   mrp_ll_sipp_persistent_kernel under `scripts/sipp_bench.py 100 8192 16 0`.
+#   mrp_ll_ecbs_persistent_kernel under `bench.py --steps 1 --warmup 0 --legs none --threads 1 --instances 16384`
+#     (ONE engine = one resident launch of 1792 workgroups: rocprofv3 serialises dispatches while it collects counters,
+#     so the sixteen launches of a sixteen-thread step would run one after the other, each waiting for the previous
+#     thread's whole share of the batch), and
+#   mrp_ll_sipp_persistent_kernel under `scripts/sipp_bench.py 100 8192 16 0` (static split: the sixteen launches do run
+#     one after the other here, each over its own instances).
 # usage: bash scripts/r3_pmc_resident.sh <tag> [ecbs|sipp|both] ["1 2 5" = passes to run, default all]
 #        -> gpurun_out/pmcres_<tag>/<kernel>_p<pass>/ + logs
 # Counters are collected in their own runs (--kernel-trace + --pmc only), the program directly after `--`.
@@ -33,7 +37,7 @@ run_pass() {  # kernel-tag pass-name "counters" program args...
 if [ "$W" = ecbs ] || [ "$W" = both ]; then
   for i in $SEL; do
     eval c=\$P$i
-    run_pass ecbs p$i "$c" python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --legs none
+    run_pass ecbs p$i "$c" python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --legs none --threads 1 --instances 16384
   done
 fi
 if [ "$W" = sipp ] || [ "$W" = both ]; then
