@@ -261,6 +261,12 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
 // `shared` != nullptr: the workers draw instances 0..nTotal-1 from one counter as their own active set drains, so a
 // worker whose instances turn out easy takes more of them (map id of instance k on this engine = mapBase + k);
 // otherwise the worker owns exactly idx[...].
+// MRP_HL_TIMING only: the moment the current batch call started (set by the solve entry points)
+std::chrono::steady_clock::time_point& batchEpoch() {
+  static std::chrono::steady_clock::time_point t;
+  return t;
+}
+
 void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance* instIn, mrp_hl_solution* sols,
                      const std::vector<int32_t>& idx, const std::vector<int32_t>& mapIds, int32_t horizon,
                      int32_t workgroups, int32_t pathSlots, GroupResult& out, std::atomic<int32_t>* shared = nullptr,
@@ -274,6 +280,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     bool queued = false;          // in `backlog`
     bool counted = false;         // its completion has been taken off nActive
     double tAdmit = 0, tDone = 0;  // MRP_HL_TIMING only: seconds since the loop started
+    int64_t hl = 0, ll = 0, spec = 0;  // ... and what the instance had consumed when it was retired
+    int32_t searches = 0;
   };
   struct Pending {                // one ticket in flight
     size_t live = 0;
@@ -468,13 +476,26 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   };
   // look ahead only while the engine has idle wavefronts: speculative searches must not queue in front of real ones
   auto specNow = [&]() -> int32_t { return jobsOut < static_cast<int64_t>(workgroups) ? specK : 1; };
-  auto retire = [&](Live& L) {
+  // A finished instance is written out and FREED here, inside the loop, where the host has slack and the device is busy:
+  // the paths, constraint sets and heaps of 16 384 instances are ~1e6 heap blocks per worker, and freeing them after
+  // the loop was 70-130 ms of a 930 ms step with the GPU idle (measured, MRP_HL_TIMING).  Searches of the instance that
+  // are still in flight (look-ahead) find `inst` empty when they return and are dropped.
+  auto retire = [&](size_t k) {
+    Live& L = live[k];
     if (!L.counted && L.inst->done()) {
       L.counted = true;
       nActive -= 1;
       L.req.clear();  // requests of a finished instance point into freed CT nodes
       L.reqHead = 0;
       if (timing) L.tDone = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
+      writeSolution(*L.inst, sols[gidx[k]]);
+      L.hl = L.inst->hlExpanded();
+      L.ll = L.inst->llExpanded();
+      L.spec = L.inst->specSearches();
+      L.searches = L.inst->llSearches();
+      out.expansions += L.ll;
+      out.specSearches += L.spec;
+      L.inst.reset();
     }
   };
   bool failed = false;
@@ -513,7 +534,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       nActive += 1;
       L.inst->setSpecWidth(specNow());
       L.inst->start(L.req);
-      retire(L);
+      retire(k);
       if (!submitAll(k)) failed = true;
       progress = true;
       if (failed) break;
@@ -555,9 +576,12 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       const int32_t group = P.group;
       pendFree.push_back(donePend[d]);
       auto tu1 = nowS();
-      L.inst->setSpecWidth(specNow());
-      L.inst->deliver(group, ans, L.req);
-      retire(L);
+      if (L.inst) {  // (else: a pre-computed expansion that came back after its instance had finished)
+        L.inst->setSpecWidth(specNow());
+        L.inst->deliver(group, ans, L.req);
+        retire(k);
+      }
+      ans.clear();   // the paths nobody took go back to the slot pool now
       auto tu2 = nowS();
       tmUnpack += secsS(tu0, tu1);
       tmAdvance += secsS(tu1, tu2);
@@ -610,17 +634,28 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     for (size_t q = 0; q < std::min<size_t>(3, order.size()); ++q) {
       const Live& L = live[order[q]];
       std::fprintf(stderr, "[mrp_hl]     last #%zu: instance %d admitted %.1f ms done %.1f ms, HL %lld, LL %lld, searches %d (+%lld ahead)\n", q,
-                   gidx[order[q]], L.tAdmit * 1e3, L.tDone * 1e3, (long long)L.inst->hlExpanded(),
-                   (long long)L.inst->llExpanded(), L.inst->llSearches(), (long long)L.inst->specSearches());
+                   gidx[order[q]], L.tAdmit * 1e3, L.tDone * 1e3, (long long)L.hl, (long long)L.ll, L.searches,
+                   (long long)L.spec);
     }
   }
   if (failed) return;
-  for (size_t k = 0; k < live.size(); ++k) {
-    writeSolution(*live[k].inst, sols[gidx[k]]);
-    out.expansions += live[k].inst->llExpanded();
-    out.specSearches += live[k].inst->specSearches();
-  }
+  for (size_t k = 0; k < live.size(); ++k)
+    if (live[k].inst) {  // (none: the loop ends when every instance has been retired)
+      writeSolution(*live[k].inst, sols[gidx[k]]);
+      out.expansions += live[k].inst->llExpanded();
+      out.specSearches += live[k].inst->specSearches();
+    }
   out.specWasted += ranExpansions - out.expansions;
+  if (timing) {
+    auto tg5 = std::chrono::steady_clock::now();
+    live.clear();
+    auto tg6 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[mrp_hl]   thread began %.1f ms after the batch, loop ended at %.1f ms, solutions written at %.1f ms, "
+                 "instances freed at %.1f ms\n", std::chrono::duration<double, std::milli>(tg0 - batchEpoch()).count(),
+                 std::chrono::duration<double, std::milli>(tg3 - batchEpoch()).count(),
+                 std::chrono::duration<double, std::milli>(tg5 - batchEpoch()).count(),
+                 std::chrono::duration<double, std::milli>(tg6 - batchEpoch()).count());
+  }
 }
 
 }  // namespace
@@ -833,6 +868,7 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   std::atomic<int32_t> nextInstance(0);
   const bool sharedPool = std::getenv("MRP_HL_STATIC_SPLIT") == nullptr;
   auto t0 = std::chrono::steady_clock::now();
+  batchEpoch() = t0;
   {
     std::vector<std::thread> th;
     for (int32_t t = 0; t < nThreads; ++t)

@@ -18,8 +18,16 @@ cpu_n = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 mode = int(os.environ.get('MRP_HL_MODE', '0'))
 for rep in range(int(os.environ.get('MRP_REPS', '3'))):
     s.ll_stats(reset=True)
+    def _thr():
+        try:
+            return {l.split()[0]: int(l.split()[1]) for l in open("/sys/fs/cgroup/cpu.stat") if "throttled" in l}
+        except OSError:
+            return {}
+    th0 = _thr()
     res, st = s.solve(insts, algo=hl.ECBS, w=1.3, want_paths=False, max_ll_expansions=int(os.environ.get("MRP_CAP", "50000")), mode=mode)
     ls = s.ll_stats()
+    th1 = _thr()
+    print("   cgroup throttling during the call: " + str({k: th1[k] - th0.get(k, 0) for k in th1}), flush=True)
     print("rep %d: wall %.3fs  solved %d/%d  LL exp %d  => %.3e exp/s, %.1f inst/s ; rounds %d searches %d ; kernel_ms(sum) %.1f launches %d migrated %d" % (
         rep, st["wall_seconds"], st["solved"], n_inst, st["ll_expansions"], st["ll_expansions"] / st["wall_seconds"],
         n_inst / st["wall_seconds"], st["rounds"], st["ll_searches"], ls["kernel_ms"], ls["launches"], ls["migrated"]), flush=True)
