@@ -18,6 +18,9 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include "../../../include/mrp_hl.h"
 #include "ct_solver.hpp"
 #include "grid2d_astar.hpp"
@@ -265,6 +268,19 @@ void runGroup(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance*
 std::chrono::steady_clock::time_point& batchEpoch() {
   static std::chrono::steady_clock::time_point t;
   return t;
+}
+
+// MRP_HL_PIN="base[,stride]": worker t of a batch call runs on CPU base + t * stride (default: wherever the scheduler
+// puts it).  Tuning knob for hosts whose CPUs are spread over sockets / SMT siblings.
+void pinWorker(int32_t t) {
+  const char* e = std::getenv("MRP_HL_PIN");
+  if (!e) return;
+  int base = 0, stride = 1;
+  if (std::sscanf(e, "%d,%d", &base, &stride) < 1) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  CPU_SET(base + t * stride, &set);
+  (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
 }
 
 void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance* instIn, mrp_hl_solution* sols,
@@ -838,6 +854,11 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
         return MRP_LL_E_DEVICE;
       }
   }
+  if (opt.mode != 1 && !s->engines.empty()) {  // what the runtime grants the kernel family of this batch's sessions
+    int32_t occ = 0;
+    if (mrp_ll_session_occupancy(s->engines[0], opt.algo == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR, &occ) == MRP_LL_SUCCESS && occ > 0)
+      occupancy = occ;
+  }
   // resident wavefronts per engine: the chip holds 256 CUs x `occupancy` workgroups of this kernel at once
   int32_t sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, (256 * occupancy) / nThreads));
   if (const char* e = std::getenv("MRP_HL_SESSION_WGS")) sessionWgs = std::max(1, std::atoi(e));  // tuning knob
@@ -873,6 +894,7 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
     std::vector<std::thread> th;
     for (int32_t t = 0; t < nThreads; ++t)
       th.emplace_back([&, t]() {
+        pinWorker(t);
         if (opt.mode == 1)
           runGroup(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, gr[t]);
         else if (sharedPool)

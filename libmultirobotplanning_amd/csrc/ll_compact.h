@@ -60,6 +60,15 @@ constexpr uint32_t oBits = oAux + kAuxBytes;
 constexpr uint32_t oObst = oBits + kRows * kRowBytes;
 constexpr uint32_t oPaths = oObst + kRowBytes;    // the focal path table follows (size chosen by the launcher)
 constexpr uint32_t kLdsBytes = oPaths;
+// BG ("bitmap in global memory", the A*-epsilon-only kernels): the (time, cell) bitmap lives in the search's arena slot
+// (CJob::bitsG) instead of the window, which then ends right behind the walk queue: obstacle row, path table.  8 KB less
+// LDS per search = 12 instead of 7 searches per CU at ten agents.
+constexpr uint32_t obstOff(bool bg) { return bg ? oBits : oObst; }
+constexpr uint32_t pathsOff(bool bg) { return obstOff(bg) + kRowBytes; }
+constexpr uint32_t windowBytes(bool bg) { return pathsOff(bg); }
+constexpr uint32_t kBitsBytes = kRows * kRowBytes;
+static_assert(oFocal == oOpen + kHeapBytes && 2u * kHeapBytes >= kBitsBytes,
+              "BG builds the bitmap in the (not yet initialised) open + focal areas before it copies it out");
 static_assert(oOpen % 16 == 0 && oFocal % 16 == 0 && oAux % 16 == 0 && oBits % 16 == 0 && oObst % 16 == 0 && oPaths % 16 == 0,
               "LDS areas are 16-byte aligned");
 static_assert((kHeapClamp & 1u) == 1u && 4u * (kHeapClamp + 3u) <= kHeapBytes, "clamped child pair stays inside the heap area");
@@ -93,6 +102,7 @@ struct CJob {              // at oJob of the window; pointers as two words
                            // compactSearchTA: the shortest-path table of the task's cell, [y * 32 + x] halfwords
   uint64_t parentTab;      // uint8_t*: kParentBytes of device memory, action byte per (t, cell)
   uint64_t outPath;        // uint16_t*: x | y << 8 per time step
+  uint64_t bitsG;          // uint32_t*: BG instances: kBitsBytes of device memory for the (time, cell) bitmap
 };
 static_assert(sizeof(CJob) <= oRes - oJob && sizeof(CJob) % 4 == 0, "CJob fits its block of the window");
 struct CRes {              // at oRes
@@ -276,8 +286,12 @@ WV_FN void pushPairs(Lds lds, const Rows& R, uint32_t hbX, uint32_t kmX, uint32_
 // The job is the CJob at oJob of the window, the result the CRes at oRes.  PLDS: the focal path table is in the window at
 // oPaths (else at CJob::pathsG); the search loop of a PLDS instance issues no vector-memory LOAD at all — its only
 // vector-memory instruction is the cameFrom store — so nothing in it ever waits on vmcnt.
-template <bool EPS, bool PLDS>
+// BG: the (time, cell) bitmap is in device memory (CJob::bitsG): one masked load per expansion, requested before the pops,
+// and one merged store per touched word (the Wait / Left / Right successors share theirs).
+template <bool EPS, bool PLDS, bool BG = false>
 WV_ENTRY int32_t compactSearch(Lds window) {
+  constexpr uint32_t oObstX = obstOff(BG), oPathsX = pathsOff(BG);
+  constexpr uint32_t oBuild = BG ? oOpen : oBits;   // where the bitmap is put together / where the goal branch stages rows
   const Lds lds = windowBase(window);
   const Sides S = makeSides();
   const Rows Rw = makeRows();
@@ -295,6 +309,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
   MRP_CT_PROF_DECL;
   // ---- job set-up -------------------------------------------------------------------------------------------
   sync();  // the previous job's LDS reads are done; the CJob block is written
+  uint32_t* bitsG = BG ? MRP_CT_JOB_PTR(uint32_t, lds, bitsG) : nullptr;
   {  // obstacle row with a stride of 32 bits per y (the map's bitmap has a stride of dimx): lane y builds word y
     const uint32_t* obst = MRP_CT_JOB_PTR(const uint32_t, lds, obst);
     const uint32_t obstWords = MRP_CT_JOB_U32(lds, obstWords);
@@ -308,9 +323,9 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     const uint32_t colMask = dimx >= 32u ? 0xFFFFFFFFu : ((1u << dimx) - 1u);
     w = (w & colMask) | ~colMask;                       // columns beyond the map: blocked
     w = sel(rowIn, w, splat(0xFFFFFFFFu));              // rows beyond the map: blocked
-    ldsStore32m(lds, splat(oObst) + y * 4u, w, !S.isB);
+    ldsStore32m(lds, splat(oObstX) + y * 4u, w, !S.isB);
   }
-  {  // heaps and walk queue: every slot "no element", the words in front of element 0 the largest key
+  auto initHeaps = [&]() {  // heaps and walk queue: every slot "no element", the words in front of element 0 the largest key
     const V4 none{splat(kEmpty), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
     const V4 head{sel(lane == 0u, splat(kFront), splat(kEmpty)), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
     ldsStore128(lds, splat(oOpen) + lane * 16u, head);
@@ -323,12 +338,13 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     ldsStore128m(lds, splat(oOpen + kGroups * 1024u), none, lane == 0u);
     ldsStore128m(lds, splat(oFocal + kGroups * 1024u), none, lane == 0u);
     for (uint32_t b = 1024u; b < kAuxBytes; b += 1024u) ldsStore128m(lds, splat(oAux + b) + lane * 16u, none, (lane * 16u + b) < kAuxBytes);
-  }
+  };
+  if (!BG) initHeaps();
   sync();
   {  // bitmap rows: row t = obstacles (| vertex constraints at t, below | states discovered, during the search)
-    const V4 chunk = ldsLoad128(lds, splat(oObst) + (lane & 7u) * 16u);
+    const V4 chunk = ldsLoad128(lds, splat(oObstX) + (lane & 7u) * 16u);
     for (uint32_t i = 0; i < kRows / 8u; ++i)
-      ldsStore128(lds, splat(oBits + i * 8u * kRowBytes) + (lane >> 3) * kRowBytes + (lane & 7u) * 16u, chunk);
+      ldsStore128(lds, splat(oBuild + i * 8u * kRowBytes) + (lane >> 3) * kRowBytes + (lane & 7u) * 16u, chunk);
   }
   sync();
   {  // stateValid's vertex constraints (ecbs.cpp:499-502)
@@ -338,8 +354,15 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       const B in = (lane + j0) < nVc;
       const V v = gLoad32m(vc, lane + j0, in);
       const V tt = v >> 16, yy = (v >> 8) & 0xFFu, xx = v & 0xFFu;
-      ldsOr32m(lds, splat(oBits) + tt * kRowBytes + yy * 4u, splat(1u) << xx, in & (tt < kRows) & (yy < 32u) & (xx < 32u));
+      ldsOr32m(lds, splat(oBuild) + tt * kRowBytes + yy * 4u, splat(1u) << xx, in & (tt < kRows) & (yy < 32u) & (xx < 32u));
     }
+  }
+  if (BG) {  // the finished rows leave for device memory (8 x 1 KB, coalesced); then the heaps take the area over
+    sync();
+    for (uint32_t i = 0; i < kBitsBytes / 1024u; ++i)
+      gStore128(bitsG, splat(i * 64u) + lane, ldsLoad128(lds, splat(oBuild + i * 1024u) + lane * 16u));
+    sync();
+    initHeaps();
   }
   // edge-constraint keys, one per lane.  They pass through the window (the walk queue's area, restored afterwards) so that
   // the loop below holds no register a vector-memory load is still writing.
@@ -514,12 +537,12 @@ WV_ENTRY int32_t compactSearch(Lds window) {
           for (uint32_t q = 0; q < 4; ++q)
             rowW[r][q] = (k0 - r >= 1) ? gLoad32Coherent(tab32, splat((uint32_t)(k0 - r) * 256u + q * 64u) + lane) : splat(0u);
         for (int32_t r = 0; r < 8; ++r)
-          for (uint32_t q = 0; q < 4; ++q) ldsStore32(lds, splat(oBits + (uint32_t)r * 1024u + q * 256u) + lane * 4u, rowW[r][q]);
+          for (uint32_t q = 0; q < 4; ++q) ldsStore32(lds, splat(oBuild + (uint32_t)r * 1024u + q * 256u) + lane * 4u, rowW[r][q]);
         sync();
         for (int32_t r = 0; r < 8 && k0 - r >= 1; ++r) {
           const uint32_t k = (uint32_t)(k0 - r);
           gStoreU16m(outPath, splat(k), splat((c & 31u) | ((c >> 5) << 8)), lane == 0u);
-          const uint32_t a = first(ldsLoadU8(lds, splat(oBits + (uint32_t)r * 1024u + c)));
+          const uint32_t a = first(ldsLoadU8(lds, splat(oBuild + (uint32_t)r * 1024u + c)));
           // the parent's cell: undo Wait, Left, Right, Up, Down
           c = a == 1u ? c + 1u : a == 2u ? c - 1u : a == 3u ? c - 32u : a == 4u ? c + 32u : c;
         }
@@ -537,7 +560,11 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     const B inb = (nx < dimx) & (ny < dimy);
     const V ncell = (nx & 31u) | ((ny & 31u) << 5);
     const V wordAddr = splat(oBits + t1 * kRowBytes) + ((ny & 31u) << 2);
-    const V word = ldsLoad32(lds, wordAddr);
+    const V wordIdx = splat(t1 * (kRowBytes / 4u)) + (ny & 31u);
+    // (a plain, cached load: the bitmap is written by this wave alone — set-up above, the merged stores below — and a
+    // wave's own stores are what its later loads see; an agent-scope load goes past the XCD's L2 to memory and cost
+    // 0.9 us per expansion, measured)
+    const V word = BG ? gLoad32m(bitsG, wordIdx, lane < 5u) : ldsLoad32(lds, wordAddr);
     // other agents' positions at t (a) and t + 1 (b), one agent per lane
     V a0 = splat(0xFFFFu), b0 = splat(0xFFFFu), a1 = splat(0xFFFFu), b1 = splat(0xFFFFu);
     if (EPS && nAgentsPad) {
@@ -545,11 +572,11 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       const uint32_t rb = t1 < tPad ? t1 : tPad - 1u;
       // (lanes beyond a row's end look at the row's last agent instead, and are masked: every read stays inside the table)
       if (PLDS) {
-        a0 = sel(in0, ldsLoadU16(lds, splat(oPaths + ra * nAgentsPad * 2u) + col0 * 2u), splat(0xFFFFu));
-        b0 = sel(in0, ldsLoadU16(lds, splat(oPaths + rb * nAgentsPad * 2u) + col0 * 2u), splat(0xFFFFu));
+        a0 = sel(in0, ldsLoadU16(lds, splat(oPathsX + ra * nAgentsPad * 2u) + col0 * 2u), splat(0xFFFFu));
+        b0 = sel(in0, ldsLoadU16(lds, splat(oPathsX + rb * nAgentsPad * 2u) + col0 * 2u), splat(0xFFFFu));
         if (nAgentsPad > 64u) {
-          a1 = sel(in1, ldsLoadU16(lds, splat(oPaths + ra * nAgentsPad * 2u) + col1 * 2u), splat(0xFFFFu));
-          b1 = sel(in1, ldsLoadU16(lds, splat(oPaths + rb * nAgentsPad * 2u) + col1 * 2u), splat(0xFFFFu));
+          a1 = sel(in1, ldsLoadU16(lds, splat(oPathsX + ra * nAgentsPad * 2u) + col1 * 2u), splat(0xFFFFu));
+          b1 = sel(in1, ldsLoadU16(lds, splat(oPathsX + rb * nAgentsPad * 2u) + col1 * 2u), splat(0xFFFFu));
         }
       } else {
         a0 = sel(in0, gLoadU16m(pathsG, splat(ra * nAgentsPad) + col0, in0), splat(0xFFFFu));
@@ -649,7 +676,13 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       maskF = lo32(ballot(mine & leF32(cvtF32(f), bound)));
     }
     // discovered: stands for stateToHeap / closedSet membership (a_star_epsilon.hpp:224-227)
-    ldsOr32m(lds, wordAddr, splat(1u) << (nx & 31u), mine);
+    if (BG) {  // Wait, Left and Right (lanes 0..2) share the word of row y: each of them stores all of their bits
+      const uint32_t bx = 1u << x;
+      const uint32_t rowBits = ((mask & 1u) ? bx : 0u) | ((mask & 2u) ? bx >> 1 : 0u) | ((mask & 4u) ? bx << 1 : 0u);
+      gStore32m(bitsG, wordIdx, word | sel(lane < 3u, splat(rowBits), splat(1u) << (nx & 31u)), mine);
+    } else {
+      ldsOr32m(lds, wordAddr, splat(1u) << (nx & 31u), mine);
+    }
     // cameFrom (a_star_epsilon.hpp:275-279): the action that led here
     gStore8m(parentTab, splat(t1 << 10) + ncell, lane, mine);
     nodes += (uint32_t)__builtin_popcount(mask);

@@ -984,7 +984,8 @@ DEVI int runSearch(Mem<T>& m, SState& s, const Ctx& c, typename Mem<T>::P32 obst
 // Dynamic LDS of a CBS / ECBS workgroup: the compact tier's window (ll_compact.h: open list, focal list, walk queue,
 // (time, cell) bitmap, obstacle row), then the focal path table.  A search that has left the compact tier keeps the
 // heaps' top entries in the same window (TierHyb).
-__host__ __device__ inline uint32_t ldsBytes(uint32_t pathBytes) { return ct::kLdsBytes + pathBytes; }
+// bg: the window of the A*-epsilon-only kernels (ll_compact.h BG: the (time, cell) bitmap lives in the arena slot)
+__host__ __device__ inline uint32_t ldsBytes(uint32_t pathBytes, bool bg) { return ct::windowBytes(bg) + pathBytes; }
 
 // A read of the device path store.  The slot was written by another workgroup (another CU, possibly another XCD) of the
 // same resident launch before its completion was published; an agent-scope load goes past this CU's L1 to the coherent
@@ -998,7 +999,7 @@ DEVI uint32_t storeLoad(const uint16_t* p) {
 #endif
 }
 
-template <bool EPS>
+template <bool EPS, bool BG>
 DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t* arenaSlot, DevResult& res,
                  uint16_t* outPath) {
   const uint32_t lane = threadIdx.x;
@@ -1030,7 +1031,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     }
     const uint32_t pathBytes = c.tPad * c.nAgentsPad * 2;  // multiple of 32
     const uint32_t* psrc = (const uint32_t*)(P.paths + J.path_off);
-    uint8_t* ldsPaths = smem + ldsBytes(0);
+    uint8_t* ldsPaths = smem + ldsBytes(0, BG);
     c.pathsLds = nullptr;
     if (pathBytes != 0 && (J.ctx_flags & kCtxById)) {
       // f2: the CT node's paths are named by their slots in the device-resident path store (each was written there by
@@ -1153,19 +1154,27 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   // LDS (the compact tier's area, free once a search has left it)
   Mem<TierHyb> gh;
   {
-    const uint32_t area = ct::kLdsBytes - ct::oOpen;  // (the window's control blocks in front of it stay as they are)
-    uint32_t per = (area / 3u) & ~15u;  // bytes per heap, 16-byte aligned starts
-    uint32_t nTop = per >= 32u ? ((per - 8u) / 8u) : 0u;
-    if (nTop > 4095u) nTop = 4095u;
-    nTop = nTop ? ((nTop - 1u) | 1u) : 0u;  // odd (or 0: no LDS tier configured)
-    if (P.lds_nodes == 0) nTop = 0;
+    const uint32_t area = ct::windowBytes(BG) - ct::oOpen;  // (the window's control blocks in front of it stay as they are)
+    // the open list gets half of the area, the focal list five sixteenths, the walk queue the rest (MRP_LL_TOPS_EQUAL:
+    // thirds, as before the A*-epsilon kernels' window shrank)
+#ifdef MRP_LL_TOPS_EQUAL
+    const uint32_t perO = (area / 3u) & ~15u, perF = perO, perA = perO;
+#else
+    const uint32_t perO = (area / 2u) & ~15u, perF = (area * 5u / 16u) & ~15u, perA = (area - perO - perF) & ~15u;
+#endif
+    auto tops = [&](uint32_t per) {
+      uint32_t n = per >= 32u ? ((per - 8u) / 8u) : 0u;
+      if (n > 4095u) n = 4095u;
+      n = n ? ((n - 1u) | 1u) : 0u;  // odd (or 0: no LDS tier configured)
+      return P.lds_nodes == 0 ? 0u : n;
+    };
     auto l8 = (__attribute__((address_space(3))) uint8_t*)smem + ct::oOpen;
     gh.nodes = g.nodes;
     gh.pos = nullptr;
     gh.gOf = nullptr;
-    gh.open = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + 8), (uint64_t*)g.open, nTop};
-    gh.focal = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + per + 8), (uint64_t*)g.focal, nTop};
-    gh.aux = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + 2 * per + 8), (uint64_t*)g.aux, nTop};
+    gh.open = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + 8), (uint64_t*)g.open, tops(perO)};
+    gh.focal = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + perO + 8), (uint64_t*)g.focal, tops(perF)};
+    gh.aux = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + perO + perF + 8), (uint64_t*)g.aux, tops(perA)};
     gh.bits = g.bits;
     gh.capNodes = g.capNodes; gh.capHeap = g.capHeap; gh.capRows = g.capRows; gh.rowWords = g.rowWords;
   }
@@ -1179,7 +1188,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   // up to 128 agents in the focal context; a search that outgrows the tier (open list, time steps, focalH field) comes
   // back as C_OVERFLOW with nothing of it observable, and is run again from the start by the arena tier below.
   const bool compactOk = P.lds_nodes != 0 && c.dimx <= 32u && c.dimy <= 32u && c.nAgentsPad <= 128u && c.nEc <= 64u &&
-                         (uint64_t)P.arena_nodes * 16u >= ct::kParentBytes;
+                         (uint64_t)P.arena_nodes * 16u >= ct::kParentBytes + (BG ? ct::kBitsBytes : 0u);
   bool done = false;
   if (compactOk) {
     // the job goes into its block of the LDS window (every lane stores the same words), the result comes back from there:
@@ -1200,6 +1209,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     cj.pathsG = (uint64_t)c.paths;
     cj.parentTab = (uint64_t)arenaSlot;  // the arena's node area: unused while the search is in this tier
     cj.outPath = (uint64_t)outPath;
+    cj.bitsG = (uint64_t)(arenaSlot + ct::kParentBytes);  // (BG) ... and its (time, cell) bitmap behind it
     {
       auto w32 = (__attribute__((address_space(3))) uint32_t*)((wv::Lds)smem + ct::oJob);
       const uint32_t* src = (const uint32_t*)&cj;
@@ -1210,7 +1220,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
 #ifndef MRP_LL_TRACE  // (the trace build uses prof[] for its phase counters)
     const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int32_t crc = tableInLds ? ct::compactSearch<EPS, true>((wv::Lds)smem) : ct::compactSearch<EPS, false>((wv::Lds)smem);
+    const int32_t crc = tableInLds ? ct::compactSearch<EPS, true, BG>((wv::Lds)smem) : ct::compactSearch<EPS, false, BG>((wv::Lds)smem);
     ct::CRes cr;
     {
       auto r32 = (__attribute__((address_space(3))) const uint32_t*)((wv::Lds)smem + ct::oRes);
@@ -2186,15 +2196,15 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
   const uint32_t algo = rfl(J.algo);
   if (KIND == 0) {
     if (algo == 1)
-      runJob<true>(P, J, smem, arenaSlot, res, outPath);
+      runJob<true, false>(P, J, smem, arenaSlot, res, outPath);
     else if (algo == 3)
       runJobTA(P, J, smem, arenaSlot, res, outPath);
     else
-      runJob<false>(P, J, smem, arenaSlot, res, outPath);
-  } else if (KIND == 1) {
-    if (algo == 1) runJob<true>(P, J, smem, arenaSlot, res, outPath);
+      runJob<false, false>(P, J, smem, arenaSlot, res, outPath);
+  } else if (KIND == 1) {  // the A*-epsilon-only kernels: the small window (mrp_ll_lds_bytes(kind = 1))
+    if (algo == 1) runJob<true, true>(P, J, smem, arenaSlot, res, outPath);
   } else {
-    if (algo == 0) runJob<false>(P, J, smem, arenaSlot, res, outPath);
+    if (algo == 0) runJob<false, false>(P, J, smem, arenaSlot, res, outPath);
     if (algo == 3) runJobTA(P, J, smem, arenaSlot, res, outPath);
   }
   PROF_ADD(res, 5);
@@ -2504,10 +2514,10 @@ static hipError_t allowFullLds(const void* fn, int which) {
 }  // namespace mrp
 
 // ---- host-callable launcher (used by mrp_ll_host.cpp) -----------------------------------------------------------
-extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes) {
+extern "C" uint32_t mrp_ll_lds_bytes(int kind, uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes) {
   (void)rows; (void)rowWords;
   // without the compact tier a workgroup still stages its job descriptor and result through the window's control block
-  return capNodes ? mrp::ldsBytes(pathBytes) : mrp::ct::oJob;
+  return capNodes ? mrp::ldsBytes(pathBytes, kind == 1) : mrp::ct::oJob;
 }
 
 // kind: 0 = mixed, 1 = A*-epsilon jobs only, 2 = A* jobs only (see processJob)

@@ -15,7 +15,8 @@
 #include "../../include/mrp_ll.h"
 #include "ll_device.h"
 
-extern "C" uint32_t mrp_ll_lds_bytes(uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes);
+extern "C" uint32_t mrp_ll_lds_bytes(int kind, uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes);
+extern "C" int mrp_ll_persistent_occupancy(int kind, uint32_t ldsBytes);
 extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, int kind,
                                     hipStream_t stream);
 extern "C" hipError_t mrp_ll_launch_sipp(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream);
@@ -827,7 +828,9 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
 }
 
 // Fills the launch parameters that do not depend on where the jobs live; returns the dynamic LDS size.
-int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t& ldsBytesOut) {
+// kind: the kernel family the launch uses (0 mixed, 1 A*-epsilon only, 2 A* only): the A*-epsilon-only kernels keep the
+// (time, cell) bitmap of the compact tier in the arena slot and take a smaller LDS window.
+int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t& ldsBytesOut, int kind) {
   P.maps = ctx->mapsDev;
   P.queue_head = t.queueHead;
   P.arena = t.arena;
@@ -848,13 +851,13 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
   if (const char* e = std::getenv("MRP_LL_LDS_PATHS")) ldsPaths = static_cast<uint32_t>(std::max(0, std::atoi(e))) & ~31u;  // tuning knob
   if (ldsNodes) {
     rows = 64;
-    ldsBytes = mrp_ll_lds_bytes(ldsNodes, rows, rowWords, ldsPaths);
+    ldsBytes = mrp_ll_lds_bytes(kind, ldsNodes, rows, rowWords, ldsPaths);
     if (ldsBytes > 160u * 1024u - 512u) {
       ldsNodes = 0;
       rows = 0;
     }
   }
-  if (!ldsNodes) ldsBytes = mrp_ll_lds_bytes(0, 0, 0, 0);  // the control block alone
+  if (!ldsNodes) ldsBytes = mrp_ll_lds_bytes(kind, 0, 0, 0, 0);  // the control block alone
   P.path_store = ctx->pathStore;
   P.path_store_stride = ctx->pathStoreStride;
   P.path_store_slots = ctx->pathStore ? ctx->pathStoreSlots : 0;
@@ -1178,10 +1181,24 @@ int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t ldsNodes, int32_t ldsRows, i
   if (occOut) {
     const uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
     const uint32_t bytes = ctx->opt.lds_nodes
-                               ? mrp_ll_lds_bytes(static_cast<uint32_t>(ctx->opt.lds_nodes), ctx->tierRows, rowWords, ctx->tierPathBytes) + 256
+                               ? mrp_ll_lds_bytes(0, static_cast<uint32_t>(ctx->opt.lds_nodes), ctx->tierRows, rowWords, ctx->tierPathBytes) + 256
                                : 0;
     *occOut = bytes ? static_cast<int32_t>(std::max<uint32_t>(1, std::min<uint32_t>(16, (160u * 1024u) / bytes))) : 16;
   }
+  return MRP_LL_SUCCESS;
+}
+
+int mrp_ll_session_occupancy(mrp_ll_ctx* ctx, int32_t algo, int32_t* occOut) {
+  if (!ctx || !occOut) return MRP_LL_E_INVALID;
+  if (algo != MRP_LL_ASTAR && algo != MRP_LL_ASTAR_EPS && algo != MRP_LL_ASTAR_TA) return MRP_LL_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int kind = algo == MRP_LL_ASTAR_EPS ? 1 : 2;
+  const uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
+  const uint32_t bytes = mrp_ll_lds_bytes(kind, static_cast<uint32_t>(ctx->opt.lds_nodes), ctx->tierRows, rowWords,
+                                          ctx->opt.lds_nodes ? ctx->tierPathBytes : 0);
+  int occ = mrp_ll_persistent_occupancy(kind, bytes);  // what the runtime grants this kernel with this much dynamic LDS
+  if (occ <= 0) occ = static_cast<int>(std::max<uint32_t>(1, std::min<uint32_t>(16, (160u * 1024u) / (bytes + 256u))));
+  *occOut = std::min(occ, 16);
   return MRP_LL_SUCCESS;
 }
 
@@ -1301,7 +1318,7 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
   g.inFlightJobs = 0;
   __atomic_store_n(g.headWord + mrp::kHeartbeatWord, 0u, __ATOMIC_RELEASE);
   uint32_t ldsBytes = 0;
-  rc = fillCommonParams(ctx, t, P, ldsBytes);
+  rc = fillCommonParams(ctx, t, P, ldsBytes, sipp ? 0 : kind);
   if (rc != MRP_LL_SUCCESS) return rc;
   ctx->sessionRowWords = P.lds_row_words;
   g.grid = static_cast<uint32_t>(workgroups > 0 ? std::min(workgroups, ctx->opt.slots) : ctx->opt.slots);
@@ -1332,7 +1349,7 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
       P2.arena = t.arena + static_cast<uint64_t>(g.grid) * ctx->arenaStride;  // arena slots behind the first launch's
       // the counters the workgroups take tickets from are zeroed on t.stream: order this launch behind that
       HIPCHK(ctx, hipStreamWaitEvent(g.stream2, g.ev0, 0));
-      HIPCHK(ctx, mrp_ll_launch_persistent(&P2, extra, mrp_ll_lds_bytes(0, 0, 0, 0), kind, g.stream2));
+      HIPCHK(ctx, mrp_ll_launch_persistent(&P2, extra, mrp_ll_lds_bytes(kind, 0, 0, 0, 0), kind, g.stream2));
       HIPCHK(ctx, hipEventRecord(g.ev2, g.stream2));
       g.grid2 = extra;
       ctx->stats.launches += 1;
@@ -1690,7 +1707,7 @@ int mrp_ll_submit(mrp_ll_ctx* ctx, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll
   P.n_jobs = static_cast<uint32_t>(nJobs);
   uint32_t ldsBytes = 0;
   {
-    int rcp = fillCommonParams(ctx, t, P, ldsBytes);
+    int rcp = fillCommonParams(ctx, t, P, ldsBytes, t.kind);
     if (rcp != MRP_LL_SUCCESS) return rcp;
   }
   uint32_t grid = std::min<uint32_t>(static_cast<uint32_t>(nJobs), static_cast<uint32_t>(ctx->opt.slots));

@@ -111,6 +111,17 @@ WV_FN V gLoad32Coherent(const uint32_t* base, V idx) {
 WV_FN void gStoreU16m(uint16_t* base, V idx, V val, B m) {
   if (m) WV_G(uint16_t, base)[idx] = (uint16_t)val;
 }
+WV_FN V gLoad32CoherentM(const uint32_t* base, V idx, B m) {
+  return m ? __hip_atomic_load(WV_G(const uint32_t, base) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
+WV_FN void gStore32m(uint32_t* base, V idx, V val, B m) {
+  if (m) WV_G(uint32_t, base)[idx] = val;
+}
+WV_FN void gStore128(uint32_t* base, V idx16, V4 val) {  // idx16 counts 16-byte units
+  v4u t;
+  t.x = val.x; t.y = val.y; t.z = val.z; t.w = val.w;
+  WV_G(v4u, base)[idx16] = t;
+}
 WV_FN void sync() { __syncthreads(); }
 
 }  // namespace wv

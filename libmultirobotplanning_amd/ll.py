@@ -65,7 +65,7 @@ class mrp_ll_stats(ctypes.Structure):
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
            "mrp_ll_submit", "mrp_ll_wait", "mrp_ll_get_stats", "mrp_ll_reset_stats", "mrp_ll_version",
            "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any", "mrp_ll_submit_lane", "mrp_ll_sync_maps",
-           "mrp_ll_configure_tiers", "mrp_ll_session_begin_sipp", "mrp_ll_release_maps", "mrp_ll_session_begin_algo", "mrp_ll_conflict_scan",
+           "mrp_ll_configure_tiers", "mrp_ll_session_occupancy", "mrp_ll_session_begin_sipp", "mrp_ll_release_maps", "mrp_ll_session_begin_algo", "mrp_ll_conflict_scan",
            "mrp_ll_sipp_table_create", "mrp_ll_sipp_table_add", "mrp_ll_sipp_table_destroy", "mrp_ll_path_store_reserve",
            "mrp_ll_upload_heuristic"]
 
@@ -324,6 +324,12 @@ class LowLevelEngine:
 
     def sipp_table_destroy(self, table: int) -> None:
         self._lib.mrp_ll_sipp_table_destroy(table)
+
+    def session_occupancy(self, algo: int) -> int:
+        """mrp_ll_session_occupancy: resident searches per CU of a session of `algo`."""
+        occ = ctypes.c_int32(0)
+        self._check(self._lib.mrp_ll_session_occupancy(self._h, algo, ctypes.byref(occ)), "mrp_ll_session_occupancy")
+        return occ.value
 
     def configure_tiers(self, lds_nodes: int = 0, lds_rows: int = 0, lds_path_bytes: int = 0) -> int:
         """Geometry of the LDS fast tier for the launches that follow (0 = keep); returns resident searches per CU."""

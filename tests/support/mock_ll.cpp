@@ -142,6 +142,10 @@ int mrp_ll_configure_tiers(mrp_ll_ctx*, int32_t, int32_t, int32_t, int32_t* occ)
   if (occ) *occ = 4;
   return MRP_LL_SUCCESS;
 }
+int mrp_ll_session_occupancy(mrp_ll_ctx*, int32_t, int32_t* occ) {
+  if (occ) *occ = 4;
+  return MRP_LL_SUCCESS;
+}
 int mrp_ll_session_begin(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
 int mrp_ll_session_begin_sipp(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
 int mrp_ll_session_begin_algo(mrp_ll_ctx*, int32_t, int32_t) { return MRP_LL_SUCCESS; }

@@ -290,6 +290,21 @@ WV_FN void gStoreU16m(uint16_t* base, const V& idx, const V& val, const B& m) {
   for (int i = 0; i < kLanes; ++i)
     if ((m.m >> i) & 1) base[idx.l[i]] = (uint16_t)val.l[i];
 }
+WV_FN V gLoad32CoherentM(const uint32_t* base, const V& idx, const B& m) {
+  V r;
+  for (int i = 0; i < kLanes; ++i) r.l[i] = ((m.m >> i) & 1) ? base[idx.l[i]] : 0u;
+  return r;
+}
+WV_FN void gStore32m(uint32_t* base, const V& idx, const V& val, const B& m) {
+  for (int i = 0; i < kLanes; ++i)
+    if ((m.m >> i) & 1) base[idx.l[i]] = val.l[i];
+}
+WV_FN void gStore128(uint32_t* base, const V& idx16, const V4& val) {  // idx16 counts 16-byte units
+  for (int i = 0; i < kLanes; ++i) {
+    uint32_t* d = base + 4u * idx16.l[i];
+    d[0] = val.x.l[i]; d[1] = val.y.l[i]; d[2] = val.z.l[i]; d[3] = val.w.l[i];
+  }
+}
 WV_FN void sync() {}
 
 }  // namespace wv

@@ -49,7 +49,7 @@ def emu_search(L, eps, inst, agent, start, goal, vc, ec, ctx_paths, w, max_exp=-
     pxy, pxy_p = _arr([xy for p in ctx_paths for xy in p], (-1, 2))
     out = np.zeros(8, dtype=np.int64)
     states = np.zeros((1024, 2), dtype=np.int32)
-    rc = L.emu_compact_search(1 if eps else 0, inst["dimx"], inst["dimy"], len(obst), obst_p, start[0], start[1], goal[0],
+    rc = L.emu_compact_search((2 if getattr(L, "_bg", False) else 1) if eps else 0, inst["dimx"], inst["dimy"], len(obst), obst_p, start[0], start[1], goal[0],
                               goal[1], w, len(vca), vc_p, len(eca), ec_p, len(plen), agent, plen_p, pxy_p, max_exp,
                               lds_path_bytes, open_cap, max_t, out.ctypes.data_as(I64P), states.ctypes.data_as(I32P), 1024)
     if rc == -2:  # not a job of the compact tier (more than 64 edge constraints, more than 128 agents)
@@ -81,9 +81,13 @@ def _replay(L, oracle_mod, inst, algo, w, lds_path_bytes=2048, cap_total=-1, ope
     return done, over
 
 
-@pytest.fixture(scope="module")
-def emu():
-    return _emu_lib()
+@pytest.fixture(scope="module", params=[False, True], ids=["bitmap_in_lds", "bitmap_in_memory"])
+def emu(request):
+    """Both forms of the tier: the (time, cell) bitmap in the LDS window (CBS / mixed kernels) and in device memory
+    (ll_compact.h BG: the A*-epsilon-only kernels, whose window is 8 KB smaller)."""
+    L = _emu_lib()
+    L._bg = request.param
+    return L
 
 
 def test_ecbs_agents10_all_searches(emu, oracle_mod, bench_instances):
@@ -241,6 +245,8 @@ def _compare_ta(r, o):
 
 
 def test_task_assignment_low_level(emu, oracle_mod, ref_tests, bench_instances):
+    if emu._bg:
+        pytest.skip("the task-assignment search has one form (bitmap in LDS)")
     """SURVEY.md §8 f4: the compact tier's search for the task-assignment callers (optional goal, shortest-path heuristic,
     free Wait at the goal, decrease-key live) against the oracle's restatement of example/cbs_ta.cpp + a_star.hpp: every
     low-level call of the conflict trees over the reference's three fixtures (all assignments), then random constraint
