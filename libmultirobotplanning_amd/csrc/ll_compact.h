@@ -564,7 +564,8 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     // (a plain, cached load: the bitmap is written by this wave alone — set-up above, the merged stores below — and a
     // wave's own stores are what its later loads see; an agent-scope load goes past the XCD's L2 to memory and cost
     // 0.9 us per expansion, measured)
-    const V word = BG ? gLoad32m(bitsG, wordIdx, lane < 5u) : ldsLoad32(lds, wordAddr);
+    // (unmasked: the lanes that probe nothing look at the word of the Wait successor — the same cache line, no branch)
+    const V word = BG ? gLoad32m(bitsG, wordIdx, bsplat(true)) : ldsLoad32(lds, wordAddr);
     // other agents' positions at t (a) and t + 1 (b), one agent per lane
     V a0 = splat(0xFFFFu), b0 = splat(0xFFFFu), a1 = splat(0xFFFFu), b1 = splat(0xFFFFu);
     if (EPS && nAgentsPad) {
@@ -679,12 +680,13 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     if (BG) {  // Wait, Left and Right (lanes 0..2) share the word of row y: each of them stores all of their bits
       const uint32_t bx = 1u << x;
       const uint32_t rowBits = ((mask & 1u) ? bx : 0u) | ((mask & 2u) ? bx >> 1 : 0u) | ((mask & 4u) ? bx << 1 : 0u);
-      gStore32m(bitsG, wordIdx, word | sel(lane < 3u, splat(rowBits), splat(1u) << (nx & 31u)), mine);
+      // ... together with cameFrom (a_star_epsilon.hpp:275-279): the action that led here — one masked region
+      gStore32and8m(bitsG, wordIdx, word | sel(lane < 3u, splat(rowBits), splat(1u) << (nx & 31u)), parentTab,
+                    splat(t1 << 10) + ncell, lane, mine);
     } else {
       ldsOr32m(lds, wordAddr, splat(1u) << (nx & 31u), mine);
+      gStore8m(parentTab, splat(t1 << 10) + ncell, lane, mine);
     }
-    // cameFrom (a_star_epsilon.hpp:275-279): the action that led here
-    gStore8m(parentTab, splat(t1 << 10) + ncell, lane, mine);
     nodes += (uint32_t)__builtin_popcount(mask);
     MRP_CT_PROF_MARK(4);
     // ---- openSet.push for every successor, focalSet.push for those within the bound, in successor order — two successors

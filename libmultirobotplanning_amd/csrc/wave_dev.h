@@ -117,6 +117,12 @@ WV_FN V gLoad32CoherentM(const uint32_t* base, V idx, B m) {
 WV_FN void gStore32m(uint32_t* base, V idx, V val, B m) {
   if (m) WV_G(uint32_t, base)[idx] = val;
 }
+WV_FN void gStore32and8m(uint32_t* base32, V idx, V val, uint8_t* base8, V off, V val8, B m) {  // two stores, one mask
+  if (m) {
+    WV_G(uint32_t, base32)[idx] = val;
+    WV_G(uint8_t, base8)[off] = (uint8_t)val8;
+  }
+}
 WV_FN void gStore128(uint32_t* base, V idx16, V4 val) {  // idx16 counts 16-byte units
   v4u t;
   t.x = val.x; t.y = val.y; t.z = val.z; t.w = val.w;

@@ -11,7 +11,7 @@ tail -2 $O/tests.log
 ( time timeout -k 10 1000 python bench.py > $O/bench_line.json 2> $O/bench.err ) 2> $O/bench_time.txt || { tail -5 $O/bench.err; exit 1; }
 grep real $O/bench_time.txt
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --legs none > $O/bench_line_under_rocprof.json 2> $O/rocprof.err || { tail -5 $O/rocprof.err; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 3 --warmup 0 --no-cpu-baseline --legs none > $O/bench_line_under_rocprof.json 2> $O/rocprof.err || { tail -5 $O/rocprof.err; exit 1; }
 find $O/prof -name "*kernel_trace.csv" -delete
 echo "rocprof stats done"
 bash $R/scripts/r3_pmc_resident.sh r03 ecbs > $O/pmc_ecbs.log 2>&1 || { tail -5 $O/pmc_ecbs.log; exit 1; }

@@ -299,6 +299,10 @@ WV_FN void gStore32m(uint32_t* base, const V& idx, const V& val, const B& m) {
   for (int i = 0; i < kLanes; ++i)
     if ((m.m >> i) & 1) base[idx.l[i]] = val.l[i];
 }
+WV_FN void gStore32and8m(uint32_t* base32, const V& idx, const V& val, uint8_t* base8, const V& off, const V& val8, const B& m) {
+  gStore32m(base32, idx, val, m);
+  gStore8m(base8, off, val8, m);
+}
 WV_FN void gStore128(uint32_t* base, const V& idx16, const V4& val) {  // idx16 counts 16-byte units
   for (int i = 0; i < kLanes; ++i) {
     uint32_t* d = base + 4u * idx16.l[i];
