@@ -127,8 +127,11 @@ int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t n_instances, const 
  * low-level calls), exposed so that a caller can decide WHERE each low-level search runs — e.g. the searches of one
  * round sharded over several GPUs (libmultirobotplanning_amd/ct_sharded.py).  Pending requests come in
  * groups (the root step, or the two children of one conflict-tree node; with spec_width > 1 also the children of the
- * nodes that will probably be popped next); a group is answered as a whole, groups in any order.  Results do not depend
- * on spec_width or on the order of delivery. */
+ * nodes that will probably be popped next); a group is answered as a whole, groups in any order.  The result of an
+ * instance that is SOLVED (or has no solution) does not depend on spec_width or on the order of delivery.  An instance
+ * that ends in MRP_HL_CAP reports MRP_HL_CAP either way, but its low_level_expanded / n_ll_searches may differ with
+ * spec_width: a pre-computed search is issued with the budget left at that moment, before the searches in front of
+ * it have been accounted. */
 typedef struct mrp_hl_ct mrp_hl_ct;
 int mrp_hl_ct_create(const mrp_hl_instance* instance, const mrp_hl_options* opt, int32_t map_id, int32_t spec_width,
                      mrp_hl_ct** out);

@@ -25,6 +25,7 @@ import numpy as np
 
 from . import hl
 
+_FAILED_ROUND = -(2 ** 31)  # group id of a failure row (mrp_hl.cpp kFailedRound): no conflict-tree group uses it
 _HDR = 8  # int32 words in front of the path: group, slot, status, cost, fmin, expanded lo, expanded hi, n_states
 
 
@@ -157,25 +158,40 @@ def solve_sharded(inst: Dict, executor: Callable[[Sequence[Dict]], List[Dict]], 
                     groups.append(r["group"])
             owner = {g: j % world for j, g in enumerate(groups)}
             mine = [r for r in reqs if owner[r["group"]] == me]
-            res = executor(mine)
-            ran += len(mine)
-            rounds += 1
             if world == 1:
+                res = executor(mine)
+                ran += len(mine)
+                rounds += 1
                 rows = [(r["group"], r["slot"], x) for r, x in zip(mine, res)]
             else:
-                per_rank = max(sum(1 for r in reqs if owner[r["group"]] == k) for k in range(world))
+                # A rank whose share of the round fails (executor error, a path longer than max_states) still takes part
+                # in the round's collective and says so in its first row; every rank then raises together instead of
+                # one rank leaving the others blocked in all_gather.
+                per_rank = max(1, max(sum(1 for r in reqs if owner[r["group"]] == k) for k in range(world)))
                 buf = torch.zeros((per_rank, _HDR + max_states), dtype=torch.int32)
-                for i, (r, x) in enumerate(zip(mine, res)):
-                    n = len(x["states"])
-                    if n > max_states:
-                        raise RuntimeError("path longer than max_states")
-                    buf[i, :_HDR] = torch.tensor([r["group"], r["slot"], x["status"], x["cost"], x["fmin"],
-                                                  x["expanded"] & 0x7FFFFFFF, x["expanded"] >> 31, n], dtype=torch.int32)
-                    if n:
-                        buf[i, _HDR:_HDR + n] = torch.tensor([p[0] | (p[1] << 16) for p in x["states"]], dtype=torch.int32)
+                failure = None
+                try:
+                    res = executor(mine)
+                    for i, (r, x) in enumerate(zip(mine, res)):
+                        n = len(x["states"])
+                        if n > max_states:
+                            raise RuntimeError("path longer than max_states")
+                        buf[i, :_HDR] = torch.tensor([r["group"], r["slot"], x["status"], x["cost"], x["fmin"],
+                                                      x["expanded"] & 0x7FFFFFFF, x["expanded"] >> 31, n], dtype=torch.int32)
+                        if n:
+                            buf[i, _HDR:_HDR + n] = torch.tensor([p[0] | (p[1] << 16) for p in x["states"]], dtype=torch.int32)
+                except Exception as e:  # noqa: BLE001 — reported to every rank below
+                    failure = e
+                    buf.zero_()
+                    buf[0, 0] = _FAILED_ROUND
+                ran += len(mine)
+                rounds += 1
                 buf = buf.to(device)
                 gathered = [torch.zeros_like(buf) for _ in range(world)]
                 dist.all_gather(gathered, buf)
+                bad = [k for k in range(world) if int(gathered[k][0, 0]) == _FAILED_ROUND]
+                if bad:
+                    raise RuntimeError("sharded round failed on rank(s) %s" % bad) from failure
                 rows = []
                 for k in range(world):
                     n_k = sum(1 for r in reqs if owner[r["group"]] == k)

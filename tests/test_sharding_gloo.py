@@ -111,6 +111,21 @@ for case in cases:
     r["native_same"] = all(r[k] == rn[k] for k in ("status", "cost", "makespan", "hl_expanded", "ll_expanded")) and \
         r.get("paths") == rn.get("paths") and rn["searches_run_here"] > 0
     out.append(r)
+# a rank whose share of a round fails must not leave the other rank blocked in the round's all-gather: BOTH raise
+inst = ct_sharded.broadcast_instance(cases[2]["inst"] if rank == 0 else None, dist, "cpu")
+calls = [0]
+def failing(reqs):
+    calls[0] += 1
+    if rank == 1 and calls[0] == 3:
+        raise ValueError("executor broke on rank 1")
+    return run(reqs)
+m = dict(dimx=inst["dimx"], dimy=inst["dimy"], obstacles=inst["obstacles"])
+try:
+    ct_sharded.solve_sharded(inst, failing, dist, algo=cases[2]["algo"], w=1.3, spec_width=2, device="cpu", _lib_path={lib!r})
+    raised = ""
+except RuntimeError as e:
+    raised = str(e)
+out.append(dict(raised=raised))
 with open({outdir!r} + "/rank%d.json" % rank, "w") as f:  # (two ranks printing to one pipe can interleave)
     json.dump(out, f)
 dist.destroy_process_group()
@@ -155,5 +170,7 @@ def test_one_conflict_tree_sharded_over_two_ranks(oracle_mod, bench_instances, o
         # the two ranks split the work: together they ran every consumed search (plus any look-ahead that was not)
         assert per_rank[0][i]["searches_run_here"] + per_rank[1][i]["searches_run_here"] >= per_rank[0][i]["ll_searches"]
         assert per_rank[0][i]["rounds"] < per_rank[0][i]["ll_searches"]
-    assert per_rank[0][-1]["status"] == hl.CAP and per_rank[1][-1]["status"] == hl.CAP
-    assert per_rank[0][-1]["native_same"] and per_rank[1][-1]["native_same"]
+    assert per_rank[0][-2]["status"] == hl.CAP and per_rank[1][-2]["status"] == hl.CAP
+    assert per_rank[0][-2]["native_same"] and per_rank[1][-2]["native_same"]
+    # the failure case: both ranks raised, naming the rank that failed
+    assert "rank(s) [1]" in per_rank[0][-1]["raised"] and "rank(s) [1]" in per_rank[1][-1]["raised"]
