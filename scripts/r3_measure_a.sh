@@ -8,6 +8,8 @@ mkdir -p $O
 cd $R
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
 tail -2 $O/tests.log
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 || { tail -5 $O/smoke.log; exit 1; }
+tail -1 $O/smoke.log
 ( time timeout -k 10 1000 python bench.py > $O/bench_line.json 2> $O/bench.err ) 2> $O/bench_time.txt || { tail -5 $O/bench.err; exit 1; }
 grep real $O/bench_time.txt
 cd /tmp && export TMPDIR=/tmp
