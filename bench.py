@@ -483,13 +483,16 @@ def main():
                 try:
                     prep = sv.prepare(sub, want_paths=False)
                     sv.solve_prepared(prep, algo=hl.ECBS, w=1.3, max_ll_expansions=args.max_ll_expansions, raw=True)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    _, st = sv.solve_prepared(prep, algo=hl.ECBS, w=1.3, max_ll_expansions=args.max_ll_expansions, raw=True)
-                    torch.cuda.synchronize()
-                    dt = time.perf_counter() - t1
+                    times = []
+                    for _ in range(2):  # two timed steps, the faster one counts (both are listed)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        _, st = sv.solve_prepared(prep, algo=hl.ECBS, w=1.3, max_ll_expansions=args.max_ll_expansions, raw=True)
+                        torch.cuda.synchronize()
+                        times.append(time.perf_counter() - t1)
+                    dt = min(times)
                     sv.release(prep)
-                    sweep[str(t)] = {"value": st["ll_expansions"] / dt, "seconds": dt, "instances": nb}
+                    sweep[str(t)] = {"value": st["ll_expansions"] / dt, "seconds": dt, "seconds_each": times, "instances": nb}
                 finally:
                     sv.close()
             if "16" in sweep:

@@ -999,6 +999,13 @@ DEVI uint32_t storeLoad(const uint16_t* p) {
 #endif
 }
 
+// Words the HOST wrote (job descriptors, constraint words, id lists, shipped tables) and words the host READS (result
+// records, paths): system-scope accesses that go past this XCD's L2 in both directions.  The resident loop publishes and
+// consumes jobs without cache-wide fences (residentLoop), so nothing else guarantees that a plain load of a recycled job
+// slot does not find the previous occupant in L2, or that a plain store has left it when the done word is written.
+DEVI uint32_t hostLoad32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+DEVI void hostStore32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 template <bool EPS, bool BG>
 DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t* arenaSlot, DevResult& res,
                  uint16_t* outPath) {
@@ -1022,10 +1029,11 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     const uint32_t* src = P.cons + J.vc_off;          // vertex words, then edge words (contiguous)
     const uint32_t nWords = c.nVc + c.nEc;
     if (nWords <= kConsLocalWords) {
-      for (uint32_t i = lane; i < nWords; i += 64) consLocal[i] = src[i];
+      for (uint32_t i = lane; i < nWords; i += 64) consLocal[i] = hostLoad32(src + i);
       c.vc = consLocal;
       c.ec = consLocal + c.nVc;
-    } else {
+    } else {  // (more than 2048 constraint words: the search reads them where the host put them, with plain loads)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
       c.vc = src;
       c.ec = P.cons + J.ec_off;
     }
@@ -1064,7 +1072,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
       for (uint32_t a0 = 0; a0 < nCtx; a0 += 64) {
         // this chunk's ids and lengths, one agent per lane (one gather for all lengths)
         uint32_t idL = kNoStoreSlot, lenL = 0;
-        if (a0 + lane < nCtx) idL = ids[a0 + lane];
+        if (a0 + lane < nCtx) idL = hostLoad32(ids + a0 + lane);
         if (idL < P.path_store_slots) lenL = storeLoad(P.path_store + (size_t)idL * P.path_store_stride);
         if (lenL > P.path_store_stride - 1) lenL = P.path_store_stride - 1;
         const uint32_t nHere = nCtx - a0 < 64 ? nCtx - a0 : 64;
@@ -1120,14 +1128,15 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
       c.paths = nullptr;
     } else if (P.lds_nodes != 0 && pathBytes <= P.lds_paths_bytes) {
       uint32_t* dst = (uint32_t*)ldsPaths;
-      for (uint32_t i = lane; i < pathBytes / 4; i += 64) dst[i] = psrc[i];
+      for (uint32_t i = lane; i < pathBytes / 4; i += 64) dst[i] = hostLoad32(psrc + i);
       c.paths = (const uint16_t*)ldsPaths;
       c.pathsLds = (__attribute__((address_space(3))) const uint16_t*)ldsPaths;
     } else if (pathBytes <= P.arena_paths_bytes) {
       uint32_t* dst = (uint32_t*)pathsArena;
-      for (uint32_t i = lane; i < pathBytes / 4; i += 64) dst[i] = psrc[i];
+      for (uint32_t i = lane; i < pathBytes / 4; i += 64) dst[i] = hostLoad32(psrc + i);
       c.paths = (const uint16_t*)pathsArena;
     } else {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
       c.paths = P.paths + J.path_off;
     }
   }
@@ -1301,7 +1310,14 @@ DEVI void runJobTA(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_
   cj.openCap = P.lds_nodes / 2u < ct::kCap ? P.lds_nodes / 2u : ct::kCap;
   cj.maxT = P.lds_rows >= 3u && P.lds_rows - 2u < ct::kMaxT ? P.lds_rows - 2u : ct::kMaxT;
   cj.taNoGoal = (J.ctx_flags & kTaNoGoal) ? 1u : 0u;
-  cj.vc = (uint64_t)(P.cons + J.vc_off); cj.ec = (uint64_t)(P.cons + J.ec_off);
+  {  // the constraint words leave host memory in one pass (at most 64 + 64 of them)
+    uint32_t* consLocal = (uint32_t*)(arenaSlot + P.arena_scratch_off + (size_t)P.out_stride * 2);
+    const uint32_t lane = threadIdx.x;
+    if (lane < J.n_vc) consLocal[lane] = hostLoad32(P.cons + J.vc_off + lane);
+    if (lane < J.n_ec) consLocal[64 + lane] = hostLoad32(P.cons + J.ec_off + lane);
+    cj.vc = (uint64_t)consLocal; cj.ec = (uint64_t)(consLocal + 64);
+    __syncthreads();
+  }
   cj.obst = (uint64_t)(P.maps + J.map_word_off);
   cj.pathsG = (uint64_t)(P.maps + J.path_off);
   cj.parentTab = (uint64_t)arenaSlot;
@@ -2180,7 +2196,7 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
   __syncthreads();
   {  // one coalesced read of the 80-byte descriptor from host memory
     const uint32_t* src = (const uint32_t*)jobSrc;
-    if (lane < sizeof(DevJob) / 4) ((uint32_t*)&jobS)[lane] = src[lane];
+    if (lane < sizeof(DevJob) / 4) ((uint32_t*)&jobS)[lane] = hostLoad32(src + lane);
   }
   __syncthreads();
   const DevJob& J = jobS;
@@ -2217,19 +2233,22 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
   __syncthreads();
   resS = res;
   __syncthreads();
-  if (lane < sizeof(DevResult) / 4) ((uint32_t*)resDst)[lane] = ((const uint32_t*)&resS)[lane];
+  if (lane < sizeof(DevResult) / 4) hostStore32((uint32_t*)resDst + lane, ((const uint32_t*)&resS)[lane]);
   if (res.status == ST_OK) {
     const uint32_t words = ((uint32_t)res.n_states + 1) / 2;
     const uint32_t* src = (const uint32_t*)outPath;
     uint32_t* dst = (uint32_t*)pathDst;
-    for (uint32_t i = lane; i < words; i += 64) dst[i] = src[i];
+    for (uint32_t i = lane; i < words; i += 64) hostStore32(dst + i, src[i]);
     // f2: the path also goes into the device path store (as cells), where the jobs of the conflict-tree nodes that
     // contain it will read it; visible to them because they are published after this job's completion was seen
     const uint32_t sid = rfl(J.store_out_id);
     if (sid < P.path_store_slots && (uint32_t)res.n_states < P.path_store_stride) {
+      // (agent-scope stores: through this XCD's L2 to memory, where the readers' agent-scope loads find them — no
+      // write-back of the whole L2 is needed to publish them, residentLoop)
       uint16_t* slot = P.path_store + (size_t)sid * P.path_store_stride;
-      for (uint32_t i = lane; i < (uint32_t)res.n_states; i += 64) slot[1 + i] = outPath[i];  // x | y << 8
-      slot[0] = (uint16_t)res.n_states;
+      for (uint32_t i = lane; i < (uint32_t)res.n_states; i += 64)
+        __hip_atomic_store(slot + 1 + i, outPath[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // x | y << 8
+      __hip_atomic_store(slot, (uint16_t)res.n_states, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -2413,8 +2432,16 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
         const uint32_t gen = (bulkT / q0 + 1) & 0x1FFFFFu;
         const uint32_t e = rfl(__hip_atomic_load(ring0 + bulkT % q0, kPollOrder, __HIP_MEMORY_SCOPE_SYSTEM));
         if ((e >> kRingSlotBits) == gen) {
-#ifndef MRP_LL_RING_POLL_ACQUIRE
+          // NO acquire fence here.  What the host wrote before publishing (descriptor, constraint words, ids, tables) is
+          // read with system-scope loads that go past the caches (hostLoad32: processJob, runJob).  A system-scope
+          // acquire FENCE is a buffer_inv sc0 sc1 — it throws away every clean line of this XCD's L2, i.e. the bitmaps,
+          // nodes and heaps of the 380 other searches that share it — and round 3 measured what 4e6 of them per second
+          // (with the write-backs below) cost: 2.9 instead of 2.5 us per expansion in the compact tier and 11.7
+          // instead of 5.1 us in the arena tier on a full chip.  -DMRP_LL_SESSION_FENCES restores them (A/B).
+#if defined(MRP_LL_SESSION_FENCES) && !defined(MRP_LL_RING_POLL_ACQUIRE)
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the job data the host wrote before publishing
+#elif !defined(MRP_LL_RING_POLL_ACQUIRE)
+          if (SIPP) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // (the SIPP kernels read their tables with plain loads)
 #endif
           slot = e & kRingSlotMask;
           doneVal = ((bulkT + 1u) & 0x3FFFFFFFu) | 0x40000000u;
@@ -2453,6 +2480,7 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
     else
       processJob<KIND>(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, smem, arenaSlot,
                        jobS, resS);
+#ifdef MRP_LL_SESSION_FENCES
     __threadfence_system();
     __hip_atomic_store(P.ring_done + slot, doneVal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring
@@ -2460,6 +2488,23 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
     cidx = rfl(cidx);
     __hip_atomic_store(P.comp_ring + (cidx % compSize), ((cidx / compSize + 1) << kRingSlotBits) | slot, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    // Publication without a cache write-back.  What the host reads (result record, path, done word, completion entry)
+    // was written with system-scope stores (processJob: hostStore32) that go through the L2 to host memory, and they
+    // are complete — in order for the host — once vmcnt says so.  What other workgroups read (the path-store slot) was written with agent-scope stores that go
+    // through to memory (processJob).  A system-scope release would add a buffer_wbl2 sc0 sc1: a write-back of EVERY
+    // dirty line of this XCD's L2 (the bitmaps, cameFrom bytes, arena nodes and heaps of every search on the XCD), per job.
+    if (SIPP) __threadfence_system();  // (the SIPP kernels write results and table commits with plain stores)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(P.ring_done + slot, doneVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring; it looks at the done
+    // word of the slot an entry names, so the done word goes first
+    uint32_t cidx = atomicAdd(P.comp_count, lane == 0 ? 1u : 0u);
+    cidx = rfl(cidx);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(P.comp_ring + (cidx % compSize), ((cidx / compSize + 1) << kRingSlotBits) | slot, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
     busyTicks += __builtin_amdgcn_s_memrealtime() - t1c;
   }
   atomicAdd(P.sess_ticks + 0, lane == 0 ? (unsigned long long)busyTicks : 0ull);

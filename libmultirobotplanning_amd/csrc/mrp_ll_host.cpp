@@ -134,7 +134,16 @@ struct Ring {
   static constexpr uint32_t kTickets = kTickets0 + kTickets1;
   static constexpr uint32_t kSlotConsWords = 1024;        // 4 KB of constraint words per job
   static constexpr uint32_t kSlotPathHalfs = 16 * 1024;   // 32 KB path table per job
-  uint8_t* block = nullptr;        // one coherent allocation holding everything below
+  uint8_t* block = nullptr;        // pinned host memory: what the DEVICE writes and the host reads (done words, completion
+                                   // queue, results, output paths) — and, without a large BAR, everything else too
+  uint8_t* push = nullptr;         // what the HOST writes and the device reads (ticket entries, head / stop / heartbeat words,
+                                   // job descriptors, constraint words, path tables): pinned host memory, or — with a large
+                                   // BAR and MRP_LL_RING_IN_DEVICE=1 — UNCACHED DEVICE memory the host stores into directly
+                                   // (write-combined, posted PCIe writes), so that the resident workgroups never read host
+                                   // memory.  Measured the same within 1 % once the per-job cache fences were gone.
+  bool pushInDevice = false;
+  size_t pushBytes = 0;
+  std::chrono::steady_clock::time_point lastBeat;
   uint32_t *state = nullptr, *done = nullptr, *stop = nullptr, *headWord = nullptr, *compRing = nullptr;
   uint32_t* compCountDev = nullptr;  // device counter
   unsigned long long* ticksDev = nullptr;  // device [2]: busy / idle ticks of the session's workgroups
@@ -179,6 +188,11 @@ struct Ring {
   std::vector<uint8_t> slotSippFlags;         //       bit 0: it runs on the device-resident copy, bit 1: sipp_commit
   std::vector<int32_t> slotInit;   // initial_cost (A*) / start_time (SIPP) of the slot's job
 };
+// The host's stores into the push block are write-combined when it is device memory: everything written so far leaves
+// the core's buffers, in order, before whatever is stored next (x86 SFENCE; a no-op price for pinned host memory).
+static inline void pushFence(const Ring& g) {
+  if (g.pushInDevice) __builtin_ia32_sfence();
+}
 struct SessTicket {
   bool used = false;
   int32_t lane = 0;
@@ -1068,6 +1082,7 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
   if (ctx->ring.ev2) (void)hipEventDestroy(ctx->ring.ev2);
   if (ctx->ring.stream2) (void)hipStreamDestroy(ctx->ring.stream2);
   if (ctx->ring.block) (void)hipHostFree(ctx->ring.block);
+  if (ctx->ring.push) (void)(ctx->ring.pushInDevice ? hipFree(ctx->ring.push) : hipHostFree(ctx->ring.push));
   if (ctx->ring.sippCons) (void)hipHostFree(ctx->ring.sippCons);
   if (ctx->ring.compCountDev) (void)hipFree(ctx->ring.compCountDev);
   if (ctx->ring.ticksDev) (void)hipFree(ctx->ring.ticksDev);
@@ -1225,34 +1240,66 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
       off += (bytes + 255) & ~size_t(255);
       return o;
     };
-    size_t oState = take(Ring::kTickets * 4), oDone = take(R * 4), oComp = take(R * 4), oStop = take(256), oHead = take(256), oJobs = take(R * sizeof(DevJob)),
-           oRes = take(R * sizeof(DevResult)), oOut = take(static_cast<size_t>(R) * g.outStride * 2),
+    // device -> host
+    size_t oDone = take(R * 4), oComp = take(R * 4), oRes = take(R * sizeof(DevResult)),
+           oOut = take(static_cast<size_t>(R) * g.outStride * 2);
+    const size_t hostBytes = off;
+    // host -> device
+    off = 0;
+    size_t oState = take(Ring::kTickets * 4), oStop = take(256), oHead = take(256), oJobs = take(R * sizeof(DevJob)),
            oCons = take(static_cast<size_t>(R) * Ring::kSlotConsWords * 4),
            oPaths = take(static_cast<size_t>(R) * Ring::kSlotPathHalfs * 2);
-    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&g.block), off, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(g.block, 0, off);
-    g.state = reinterpret_cast<uint32_t*>(g.block + oState);
+    const size_t pushBytes = off;
+    g.pushBytes = pushBytes;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&g.block), hostBytes, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(g.block, 0, hostBytes);
+    {
+      hipDeviceProp_t prop;
+      std::memset(&prop, 0, sizeof(prop));
+      const bool largeBar = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.isLargeBar != 0;
+      // opt-in (MRP_LL_RING_IN_DEVICE=1): with the cache-wide fences gone from the resident loop the two placements
+      // measure within 1 % of each other, and pinned host memory does not depend on the BAR
+      const char* e = std::getenv("MRP_LL_RING_IN_DEVICE");
+      g.pushInDevice = largeBar && e && *e == '1';
+    }
+    if (g.pushInDevice) {
+      void* p = nullptr;
+      if (hipExtMallocWithFlags(&p, pushBytes, hipDeviceMallocUncached) == hipSuccess) {
+        g.push = static_cast<uint8_t*>(p);
+        std::memset(g.push, 0, pushBytes);  // (through the BAR, once per engine; no device-wide synchronisation — other
+        __builtin_ia32_sfence();            //  engines' resident kernels may be running)
+      } else {
+        (void)hipGetLastError();
+        g.pushInDevice = false;
+      }
+    }
+    if (!g.pushInDevice) {
+      HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&g.push), pushBytes, hipHostMallocMapped | hipHostMallocCoherent));
+      std::memset(g.push, 0, pushBytes);
+    }
+    g.state = reinterpret_cast<uint32_t*>(g.push + oState);
     g.done = reinterpret_cast<uint32_t*>(g.block + oDone);
-    g.stop = reinterpret_cast<uint32_t*>(g.block + oStop);
-    g.headWord = reinterpret_cast<uint32_t*>(g.block + oHead);
+    g.stop = reinterpret_cast<uint32_t*>(g.push + oStop);
+    g.headWord = reinterpret_cast<uint32_t*>(g.push + oHead);
     g.compRing = reinterpret_cast<uint32_t*>(g.block + oComp);
     HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&g.compCountDev), 256));
     HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&g.ticksDev), 256));
-    g.jobs = reinterpret_cast<DevJob*>(g.block + oJobs);
+    g.jobs = reinterpret_cast<DevJob*>(g.push + oJobs);
     g.results = reinterpret_cast<DevResult*>(g.block + oRes);
     g.outPaths = reinterpret_cast<uint16_t*>(g.block + oOut);
-    g.cons = reinterpret_cast<uint32_t*>(g.block + oCons);
-    g.paths = reinterpret_cast<uint16_t*>(g.block + oPaths);
+    g.cons = reinterpret_cast<uint32_t*>(g.push + oCons);
+    g.paths = reinterpret_cast<uint16_t*>(g.push + oPaths);
     HIPCHK(ctx, hipEventCreate(&g.ev0));
     HIPCHK(ctx, hipEventCreate(&g.ev1));
   }
-  std::memset(g.state, 0, Ring::kTickets * 4);
+  std::memset(g.state, 0, Ring::kTickets * 4);  // (write-combined stores through the BAR when the block is device memory)
   std::memset(g.done, 0, R * 4);
   std::memset(g.compRing, 0, R * 4);
   g.compCursor = 0;
   __atomic_store_n(g.stop, 0u, __ATOMIC_RELEASE);
   __atomic_store_n(g.headWord, 0u, __ATOMIC_RELEASE);
   __atomic_store_n(g.headWord + 16, 0u, __ATOMIC_RELEASE);
+  pushFence(g);
   g.head[0] = g.head[1] = 0;
   g.busy.assign(R, 0);
   g.slotTicket.assign(R, -1);
@@ -1282,6 +1329,9 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
   ctx->sess.clear();
   ctx->sessFree.clear();
   auto devPtr = [&](void* hostPtr) {
+    const uint8_t* b = static_cast<const uint8_t*>(hostPtr);
+    if (g.pushInDevice && b >= g.push && b < g.push + g.pushBytes)
+      return hostPtr;  // device memory the host writes through the BAR: one address for both sides
     void* d = nullptr;
     (void)hipHostGetDevicePointer(&d, hostPtr, 0);
     return d;
@@ -1317,6 +1367,8 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
   g.emptyPolls = 0;
   g.inFlightJobs = 0;
   __atomic_store_n(g.headWord + mrp::kHeartbeatWord, 0u, __ATOMIC_RELEASE);
+  pushFence(g);
+  g.lastBeat = std::chrono::steady_clock::now();
   uint32_t ldsBytes = 0;
   rc = fillCommonParams(ctx, t, P, ldsBytes, sipp ? 0 : kind);
   if (rc != MRP_LL_SUCCESS) return rc;
@@ -1375,6 +1427,7 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
   if (!g.active) return MRP_LL_E_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   __atomic_store_n(g.stop, 1u, __ATOMIC_RELEASE);
+  pushFence(g);
   HIPCHK(ctx, hipEventSynchronize(g.ev1));
   if (g.grid2) HIPCHK(ctx, hipEventSynchronize(g.ev2));
   float ms = 0.f;
@@ -1403,7 +1456,12 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
 }
 
 // Every host call into a live session moves the heartbeat word the resident workgroups watch (ll_kernel.hip residentLoop).
+// The resident workgroups look at the heartbeat once per idle limit (20 s): a store every 10 ms is plenty, and it is a
+// posted PCIe write when the word lives in device memory.
 static inline void sessionBeat(Ring& g) {
+  const auto now = std::chrono::steady_clock::now();
+  if (now - g.lastBeat < std::chrono::milliseconds(10)) return;
+  g.lastBeat = now;
   __atomic_store_n(g.headWord + mrp::kHeartbeatWord, ++g.heartbeat, __ATOMIC_RELAXED);
 }
 
@@ -1502,12 +1560,15 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
     g.tkSeq[qi] = g.slotGen[slot];
     st.slots[i] = slot;
     st.seq[i] = g.slotGen[slot];
+    pushFence(g);  // the job data above leaves before its ticket entry
     __atomic_store_n(g.state + qi, (gen << mrp::kRingSlotBits) | slot, __ATOMIC_RELEASE);  // publish: the job data above is visible first
   }
+  pushFence(g);    // ... and the entries before the count that covers them
   g.head[lane] += static_cast<uint64_t>(nJobs);
   g.inFlightJobs += static_cast<uint32_t>(nJobs);
   // after every ticket entry
   __atomic_store_n(g.headWord + 16 * lane, static_cast<uint32_t>(g.head[lane]), __ATOMIC_RELEASE);
+  pushFence(g);
   ctx->stats.pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - packT0).count();
   *ticketOut = ti;
   return MRP_LL_SUCCESS;

@@ -120,7 +120,11 @@ WV_FN void gStore32m(uint32_t* base, V idx, V val, B m) {
 WV_FN void gStore32and8m(uint32_t* base32, V idx, V val, uint8_t* base8, V off, V val8, B m) {  // two stores, one mask
   if (m) {
     WV_G(uint32_t, base32)[idx] = val;
+#ifndef MRP_CT_EXPERIMENT_NO_PARENT_STORE  // throughput experiment only (paths come out wrong): what the cameFrom bytes cost
     WV_G(uint8_t, base8)[off] = (uint8_t)val8;
+#else
+    (void)base8; (void)off; (void)val8;
+#endif
   }
 }
 WV_FN void gStore128(uint32_t* base, V idx16, V4 val) {  // idx16 counts 16-byte units
