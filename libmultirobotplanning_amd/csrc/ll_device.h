@@ -132,6 +132,7 @@ struct LaunchParams {
   uint16_t* path_store;       // device (uncached allocation: written by one workgroup, read by others of a resident kernel)
   uint32_t path_store_stride; // halfwords per slot (0 = no store)
   uint32_t path_store_slots;
+  uint32_t sipp_tables_uncached;  // the device-resident SIPP tables live in uncached memory: no cache fences around their use
 };
 
 }  // namespace mrp

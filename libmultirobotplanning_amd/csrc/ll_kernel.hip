@@ -1366,6 +1366,7 @@ struct SippView {
   const int32_t* ivals;
   uint32_t* status;
   uint32_t cells, epochBits;
+  uint32_t uncached;  // the table is in uncached memory (LaunchParams::sipp_tables_uncached)
   // nk != 0: the cell has its own interval list, `n` entries from ivals[2 * first]; nk == 0: the default [0, INT_MAX]
   DEVI void lookup(uint32_t cell, uint32_t& nk, uint32_t& first, uint32_t& n) const {
     if constexpr (RES) {
@@ -1882,13 +1883,21 @@ DEVI bool sippCommitPath(const SippView<true>& tv, const uint32_t* path, uint32_
       }
       todo &= ~ballot64(mine);
       if (todo) {  // the next turn reads rows this one wrote (other lanes of the same wave: through L2, not a stale L1 line)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (tv.uncached) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
       }
     }
     if (base + 64 < len) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (tv.uncached) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
     }
   }
   return ballot64(bad) == 0;
@@ -1928,6 +1937,7 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
   SippView<RES> tv;
   tv.cells = cells;
   tv.epochBits = 0;
+  tv.uncached = 0;
   if constexpr (RES) {
     uint8_t* rt = (uint8_t*)((uint64_t)J.n_agents_pad | ((uint64_t)J.path_off << 32));
     const uint32_t cntBytes = (cells + 255u) & ~255u;
@@ -1941,7 +1951,8 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
     tv.specFirst = nullptr;
     // the table was last written by another workgroup, possibly on another XCD (its results were released at system
     // scope before the host saw them and packed this job)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    tv.uncached = P.sipp_tables_uncached;
+    if (!tv.uncached) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const uint32_t nRec = J.ec_off & 0x7FFFFFFFu;
     if (J.ec_off >> 31) {  // first job of the table (or its epochs are used up): no cell has a list, no state is seen
       u32x4 z;
@@ -2332,11 +2343,11 @@ DEVI void processSippJob(const LaunchParams& P, const DevJob* jobSrc, DevResult*
   __syncthreads();
   resS = res;
   __syncthreads();
-  if (lane < sizeof(DevResult) / 4) ((uint32_t*)resDst)[lane] = ((const uint32_t*)&resS)[lane];
+  if (lane < sizeof(DevResult) / 4) hostStore32((uint32_t*)resDst + lane, ((const uint32_t*)&resS)[lane]);
   if (res.status == ST_OK) {  // one u32 (cell | g << 16) per raw A* state
     const uint32_t* src = (const uint32_t*)outPath;
     uint32_t* dst = (uint32_t*)pathDst;
-    for (uint32_t i = lane; i < (uint32_t)res.n_states; i += 64) dst[i] = src[i];
+    for (uint32_t i = lane; i < (uint32_t)res.n_states; i += 64) hostStore32(dst + i, src[i]);
   }
 }
 
@@ -2494,7 +2505,7 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
     // are complete — in order for the host — once vmcnt says so.  What other workgroups read (the path-store slot) was written with agent-scope stores that go
     // through to memory (processJob).  A system-scope release would add a buffer_wbl2 sc0 sc1: a write-back of EVERY
     // dirty line of this XCD's L2 (the bitmaps, cameFrom bytes, arena nodes and heaps of every search on the XCD), per job.
-    if (SIPP) __threadfence_system();  // (the SIPP kernels write results and table commits with plain stores)
+    if (SIPP && !P.sipp_tables_uncached) __threadfence_system();  // (cached tables: the commits are plain stores)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(P.ring_done + slot, doneVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring; it looks at the done

@@ -257,6 +257,16 @@ static const bool kDebug = std::getenv("MRP_LL_DEBUG") != nullptr;
     }                                                                                             \
   } while (0)
 
+// MRP_LL_SIPP_TABLES_UNCACHED=1: the device-resident SIPP tables in uncached device memory (no cache fences around
+// their use, every table access goes to memory); read once per process
+bool sippTablesUncached() {
+  static const bool v = [] {
+    const char* e = std::getenv("MRP_LL_SIPP_TABLES_UNCACHED");
+    return e && *e == '1';
+  }();
+  return v;
+}
+
 int actionFromDelta(int dx, int dy) {
   if (dx == 0 && dy == 0) return MRP_LL_ACT_WAIT;
   if (dx == -1 && dy == 0) return MRP_LL_ACT_LEFT;
@@ -875,6 +885,7 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
   P.path_store = ctx->pathStore;
   P.path_store_stride = ctx->pathStoreStride;
   P.path_store_slots = ctx->pathStore ? ctx->pathStoreSlots : 0;
+  P.sipp_tables_uncached = sippTablesUncached() ? 1u : 0u;
   P.lds_nodes = ldsNodes;
   P.lds_rows = rows;
   P.lds_row_words = rowWords;
@@ -1894,7 +1905,9 @@ int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t mapId, mrp_ll_sipp_table**
   } else {
     if (ctx->sippTabNext == static_cast<int32_t>(ctx->sippTabChunks.size()) * ctx->sippTabsPerChunk) {
       void* c = nullptr;
-      if (hipSetDevice(ctx->device) == hipSuccess && hipMalloc(&c, ctx->sippTabStride * ctx->sippTabsPerChunk) == hipSuccess)
+      if (hipSetDevice(ctx->device) == hipSuccess &&
+          (sippTablesUncached() ? hipExtMallocWithFlags(&c, ctx->sippTabStride * ctx->sippTabsPerChunk, hipDeviceMallocUncached)
+                                : hipMalloc(&c, ctx->sippTabStride * ctx->sippTabsPerChunk)) == hipSuccess)
         ctx->sippTabChunks.push_back(static_cast<uint8_t*>(c));
     }
     if (ctx->sippTabNext < static_cast<int32_t>(ctx->sippTabChunks.size()) * ctx->sippTabsPerChunk) t->devIndex = ctx->sippTabNext++;
