@@ -583,7 +583,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       progress = true;
       ticketsOut -= 1;
       jobsOut -= static_cast<int64_t>(P.res.size());
-      auto tu0 = nowS();
+      auto tu0 = timing ? nowS() : tC;  // (per-ticket clock reads only when somebody will look at them)
       ans.clear();
       for (size_t q = 0; q < P.res.size(); ++q) {
         ranExpansions += P.res[q].expanded;
@@ -591,14 +591,14 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       }
       const int32_t group = P.group;
       pendFree.push_back(donePend[d]);
-      auto tu1 = nowS();
+      auto tu1 = timing ? nowS() : tC;
       if (L.inst) {  // (else: a pre-computed expansion that came back after its instance had finished)
         L.inst->setSpecWidth(specNow());
         L.inst->deliver(group, ans, L.req);
         retire(k);
       }
       ans.clear();   // the paths nobody took go back to the slot pool now
-      auto tu2 = nowS();
+      auto tu2 = timing ? nowS() : tC;
       tmUnpack += secsS(tu0, tu1);
       tmAdvance += secsS(tu1, tu2);
       // publish the follow-up searches at once: a long conflict-tree chain must not wait for the rest of this pass
