@@ -65,6 +65,7 @@ extern "C" {
 #define MRP_LL_CAP_HORIZON 4    /* a state beyond mrp_ll_options.max_horizon would have been generated         */
 #define MRP_LL_BAD_JOB 5        /* job rejected on the host (unknown map, start/goal outside the grid, ...)    */
 #define MRP_LL_PATH_TRUNCATED 6 /* solved, but result.states_cap was too small; cost/fmin/expanded are valid    */
+#define MRP_LL_NOT_RUN 8        /* root chain (MRP_LL_JOB_ROOT_CHAIN): the chain ended before this agent's search            */
 #define MRP_LL_CAP_FOCAL 7      /* a node's focal value exceeded the 11-bit key field (2047 accumulated conflicts)  */
 
 /* Action codes == enum class Action of example/ecbs.cpp:49-55 */
@@ -142,9 +143,23 @@ typedef struct mrp_ll_job {
    * MRP_LL_JOB_NO_GOAL.  (Zero-initialised jobs of the other algorithms never look at it.) */
   int32_t heuristic_id;
   int32_t reserved3;
+  /* MRP_LL_JOB_ROOT_CHAIN only: [n_agents][4] = start x, start y, goal x, goal y of every agent of the instance. */
+  const int32_t* chain_starts_goals_xy;
 } mrp_ll_job;
 
 #define MRP_LL_JOB_STORE_RESULT 1 /* mrp_ll_job.flags: also leave the result path in path-store slot result_path_id */
+/* MRP_LL_JOB_ROOT_CHAIN (sessions of MRP_LL_ASTAR_EPS with a path store; maps up to 32 x 32, at most 32 agents): ONE job
+ * that is the root step of an ECBS conflict tree (ecbs.hpp:118-136) from agent `agent_idx` on: agent a = agent_idx ..
+ * n_agents - 1 is planned with no constraints against the paths of the agents 0 .. a - 1, one after the other, by one
+ * workgroup that keeps the focal context in LDS.  path_ids[n_agents] names the path-store slot of EVERY agent: where the
+ * paths of the agents before agent_idx are, and where the others' paths go (all >= 0).  max_expansions is the budget of
+ * the whole chain (each search gets what the ones before it left, like a caller that subtracts `expanded` itself).
+ * The job's result has chain_results -> [n_agents - agent_idx] ordinary results (each with its own buffers), filled in
+ * agent order: the chain ends BEHIND an agent whose search found no path or exceeded the budget, and IN FRONT OF one
+ * whose search outgrows the LDS tier — that one and every later agent come back as MRP_LL_NOT_RUN and are the caller's to
+ * submit as ordinary jobs (or as another chain).  The job's own n_states = results filled in, expanded = their sum.
+ * Every filled-in result is exactly what the ordinary job for that agent would have returned. */
+#define MRP_LL_JOB_ROOT_CHAIN 4
 #define MRP_LL_JOB_NO_GOAL 2      /* mrp_ll_job.flags, MRP_LL_ASTAR_TA: the agent has no task (cbs_ta.cpp:283-319: h = 0, every
                                    * cell ends the search once time > the agent's last vertex constraint, every Wait is free) */
 
@@ -161,6 +176,7 @@ typedef struct mrp_ll_result {
   int32_t* action_costs; /* caller buffer [states_cap] or NULL: PlanResult::actions[k].second (always 1 for
                           * MRP_LL_ASTAR / _EPS; 0 for a Wait at the goal with MRP_LL_ASTAR_TA; Wait durations for
                           * MRP_LL_SIPP, sipp.hpp:105-128)                                                     */
+  struct mrp_ll_result* chain_results; /* MRP_LL_JOB_ROOT_CHAIN jobs only: caller array [n_agents - agent_idx]  */
 } mrp_ll_result;
 
 typedef struct mrp_ll_stats {

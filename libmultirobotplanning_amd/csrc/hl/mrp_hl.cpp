@@ -296,6 +296,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     bool queued = false;          // in `backlog`
     bool counted = false;         // its completion has been taken off nActive
     double tAdmit = 0, tDone = 0;  // MRP_HL_TIMING only: seconds since the loop started
+    int32_t noChainAgent = -1;    // root agent whose search outgrew the compact tier inside a chain: it goes as its own job
     int64_t hl = 0, ll = 0, spec = 0;  // ... and what the instance had consumed when it was retired
     int32_t searches = 0;
   };
@@ -305,6 +306,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     std::vector<mrp_ll_result> res;
     std::vector<int32_t> states;
     std::vector<int32_t> outSlot;  // per job: the path-store slot its result path also goes to (-1: none)
+    // a root chain (MRP_LL_JOB_ROOT_CHAIN): ONE job whose result fans out into chainRes, one per agent from chainFirst on
+    std::vector<mrp_ll_result> chainRes;
+    int32_t chainFirst = -1;
+    std::vector<LLRequest> chainReq;  // the request the chain was made from (restored if the chain ran nothing)
   };
   // f2: slots of the engine's device-resident path store, handed to the searches of this worker for their result paths;
   // declared before `live` so that it outlives every Path that returns its slot to it
@@ -325,6 +330,11 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   std::vector<size_t> poolOff;
   std::vector<LLAnswer> ans;
 
+  std::vector<int32_t> chainIds, chainXy;
+  const bool chainDebug = std::getenv("MRP_HL_CHAIN_DEBUG") != nullptr;  // one line per chain answer on stderr
+  // MRP_HL_ROOT_CHAIN=0: every root search is its own job (A/B; results are the same)
+  const bool rootChains = pathSlots > 0 && opt.algo == MRP_HL_ECBS &&
+                          !(std::getenv("MRP_HL_ROOT_CHAIN") && std::atoi(std::getenv("MRP_HL_ROOT_CHAIN")) == 0);
   const bool timing = std::getenv("MRP_HL_TIMING") != nullptr;
   const int32_t specK = specWidthSetting();
   auto tg0 = std::chrono::steady_clock::now();
@@ -346,6 +356,90 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     idOff.clear();
     idOk.clear();
     const int32_t group = L.req[L.reqHead].group;
+    // ---- the root step of an ECBS tree as ONE job (MRP_LL_JOB_ROOT_CHAIN): the workgroup plans this agent and every
+    // later one against the paths before them and keeps the focal table in LDS; the host sees one completion instead of
+    // ten.  Only when every existing path sits in the device store and there are slots for the new ones.
+    if (rootChains && group == kRootGroup && I.algo() == MRP_HL_ECBS && L.req[L.reqHead].context &&
+        L.reqHead + 1 == L.req.size() && I.nAgents() >= 2 && I.nAgents() <= 32 && L.req[L.reqHead].agent != L.noChainAgent) {
+      const LLRequest& r = L.req[L.reqHead];
+      const int32_t nA = I.nAgents(), first = r.agent;
+      chainIds.assign(nA, -1);
+      bool ok = true;
+      for (int32_t a = 0; a < first && ok; ++a) {
+        chainIds[a] = (*r.context)[a]->devSlot;
+        ok = chainIds[a] >= 0;
+      }
+      for (int32_t a = first; a < nA && ok; ++a) {
+        chainIds[a] = slotPool.take();
+        ok = chainIds[a] >= 0;
+      }
+      if (!ok) {
+        for (int32_t a = first; a < nA; ++a) slotPool.give(chainIds[a]);
+      } else {
+        chainXy.resize(static_cast<size_t>(nA) * 4);
+        for (int32_t a = 0; a < nA; ++a) {
+          chainXy[4 * a] = I.start(a)[0];
+          chainXy[4 * a + 1] = I.start(a)[1];
+          chainXy[4 * a + 2] = I.goal(a)[0];
+          chainXy[4 * a + 3] = I.goal(a)[1];
+        }
+        mrp_ll_job j;
+        std::memset(&j, 0, sizeof(j));
+        j.map_id = I.mapId();
+        j.algo = MRP_LL_ASTAR_EPS;
+        j.w = I.w();
+        j.agent_idx = first;
+        j.n_agents = nA;
+        j.path_ids = chainIds.data();
+        j.chain_starts_goals_xy = chainXy.data();
+        j.max_expansions = I.remainingLL();
+        j.result_path_id = -1;
+        j.flags = MRP_LL_JOB_ROOT_CHAIN;
+        int32_t pi;
+        if (!pendFree.empty()) {
+          pi = pendFree.back();
+          pendFree.pop_back();
+        } else {
+          pend.emplace_back();
+          pi = static_cast<int32_t>(pend.size()) - 1;
+        }
+        Pending& P = pend[pi];
+        const int32_t cnt = nA - first;
+        P.live = k;
+        P.group = group;
+        P.chainFirst = first;
+        P.outSlot.assign(chainIds.begin() + first, chainIds.end());
+        P.chainRes.assign(static_cast<size_t>(cnt), mrp_ll_result());
+        P.states.resize(static_cast<size_t>(cnt) * static_cast<size_t>(cap) * 3);
+        for (int32_t q = 0; q < cnt; ++q) {
+          std::memset(&P.chainRes[q], 0, sizeof(mrp_ll_result));
+          P.chainRes[q].states_txy = P.states.data() + static_cast<size_t>(q) * static_cast<size_t>(cap) * 3;
+          P.chainRes[q].states_cap = cap;
+        }
+        P.res.assign(1, mrp_ll_result());
+        std::memset(&P.res[0], 0, sizeof(mrp_ll_result));
+        P.res[0].chain_results = P.chainRes.data();
+        int32_t ticket = -1;
+        int rc = mrp_ll_submit(ctx, 1, &j, P.res.data(), &ticket);
+        if (rc != MRP_LL_SUCCESS) {
+          for (int32_t sl : P.outSlot) slotPool.give(sl);
+          P.chainFirst = -1;
+          pendFree.push_back(pi);
+          if (rc == MRP_LL_E_BUSY) return 0;
+          out.err = std::string("mrp_ll_submit (root chain): ") + mrp_ll_last_error(ctx);
+          return -1;
+        }
+        if (static_cast<size_t>(ticket) >= ticketPend.size()) ticketPend.resize(ticket + 1, -1);
+        ticketPend[ticket] = pi;
+        P.chainReq.assign(1, L.req[L.reqHead]);
+        L.req.clear();
+        L.reqHead = 0;
+        ticketsOut += 1;
+        jobsOut += 1;
+        out.rounds += 1;
+        return 1;
+      }
+    }
     size_t end = L.reqHead;
     while (end < L.req.size() && L.req[end].group == group) {
       mrp_ll_job j;
@@ -374,6 +468,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     Pending& P = pend[pi];
     P.live = k;
     P.group = group;
+    P.chainFirst = -1;
     P.outSlot.assign(jobs.size(), -1);
     if (pathSlots > 0)
       for (size_t q = 0; q < jobs.size(); ++q) {
@@ -583,6 +678,49 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       progress = true;
       ticketsOut -= 1;
       jobsOut -= static_cast<int64_t>(P.res.size());
+      if (P.chainFirst >= 0) {  // a root chain: its answers are delivered one by one, exactly like ten separate jobs
+        if (P.res[0].status != MRP_LL_OK) {
+          out.err = "root chain rejected by the engine (status " + std::to_string(P.res[0].status) + ")";
+          failed = true;
+          break;
+        }
+        const size_t cnt = P.chainRes.size();
+        size_t q = 0;
+        for (; q < cnt; ++q) {
+          const mrp_ll_result& r = P.chainRes[q];
+          if (chainDebug)
+            std::fprintf(stderr, "[chain] inst %d agent %d: status %d cost %d fmin %d n %d expanded %lld\n", gidx[k],
+                         P.chainFirst + static_cast<int>(q), r.status, r.cost, r.fmin, r.n_states, (long long)r.expanded);
+          if (r.status == MRP_LL_NOT_RUN || !L.inst) break;
+          ranExpansions += r.expanded;
+          out.searches += 1;
+          ans.clear();
+          ans.push_back(answerOf(r, P.outSlot[q], &slotPool));
+          L.req.clear();  // (the request for the next root agent, which the chain has already answered — or not, below)
+          L.reqHead = 0;
+          L.inst->setSpecWidth(specNow());
+          L.inst->deliver(P.group, ans, L.req);
+          ans.clear();
+          retire(k);
+        }
+        if (L.inst && q < cnt && P.chainRes[q].status == MRP_LL_NOT_RUN) {
+          // the search of this agent did not fit the compact tier: it goes as an ordinary job (any tier), chains resume behind it
+          L.noChainAgent = P.chainFirst + static_cast<int32_t>(q);
+          if (q == 0) {  // nothing was delivered, so nothing re-created the request
+            L.req = P.chainReq;
+            L.reqHead = 0;
+          }
+        }
+        for (; q < cnt; ++q) slotPool.give(P.outSlot[q]);  // agents the chain did not reach
+        P.chainFirst = -1;
+        P.chainReq.clear();
+        pendFree.push_back(donePend[d]);
+        if (L.inst && L.reqHead < L.req.size() && !L.queued && !submitAll(k)) {
+          failed = true;
+          break;
+        }
+        continue;
+      }
       auto tu0 = timing ? nowS() : tC;  // (per-ticket clock reads only when somebody will look at them)
       ans.clear();
       for (size_t q = 0; q < P.res.size(); ++q) {

@@ -55,6 +55,18 @@ struct DevJob {            // 96 bytes, 16-byte aligned
 };
 constexpr uint32_t kNoStoreSlot = 0xFFFFFFFFu;
 constexpr uint32_t kCtxById = 1u;
+// ctx_flags bit 5: a ROOT CHAIN of an ECBS conflict tree (ecbs.hpp:118-136; mrp_ll_submit_root_chain): the workgroup plans
+// agents t_pad .. n_ctx - 1 of one instance one after the other, each against the paths of the agents before it, and keeps
+// the focal table in LDS between the searches.  cons[vc_off + a] = sx | sy << 8 | gx << 16 | gy << 24 of agent a,
+// cons[vc_off + n_ctx + a] = its path-store slot (agents before t_pad: where their paths ARE; the others: where theirs go).
+// Output (the job slot's host area, words): per planned agent eight words {status, cost, fmin, n_states, expanded,
+// offset of its path in words, 0, 0}, then the paths (x | y << 8 halfwords).  DevResult: n_states = entries written,
+// expanded = their sum.  The chain stops behind a search that found no path or ran into the expansion budget, and IN
+// FRONT OF one that outgrows the compact tier (the caller submits that one as an ordinary job).
+constexpr uint32_t kCtxChain = 32u;
+constexpr uint32_t kChainEntryWords = 8;
+constexpr uint32_t kChainMaxAgents = 32;
+constexpr uint32_t kChainRows = 64;                                // rows of the chain's focal table (the compact tier ends at t = 62)
 // MRP_LL_SIPP with a device-resident table (mrp_ll_sipp_table_* in a session): ctx_flags bit 1.  The table lives in
 // device memory at the 64-bit address (n_agents_pad | path_off << 32), in a fixed-capacity layout the search reads directly:
 //   cnt[cells] bytes (0 = the default single interval, n + 1 = n safe intervals), padded to 256 bytes,
@@ -107,7 +119,8 @@ struct LaunchParams {
   uint32_t arena_paths_bytes; // capacity of the path-table copy in the arena slot
   uint32_t lds_paths_bytes;   // capacity of the path-table copy in LDS
   uint32_t n_jobs;
-  uint32_t out_stride;
+  uint32_t out_stride;        // halfwords of the path scratch in an arena slot (= max_horizon)
+  uint32_t out_host_stride;   // halfwords per job of out_paths (sessions: room for a root chain's output)
   uint32_t arena_nodes;       // node capacity in the HBM tier
   uint32_t arena_rows;        // bitmap rows (time steps) in the HBM tier == max_horizon
   uint32_t arena_row_words;   // words per bitmap row the arena was sized for (>= job.words_per_row)

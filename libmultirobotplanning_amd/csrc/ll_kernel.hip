@@ -1289,6 +1289,123 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
 }
 
 
+// The root chain of one ECBS conflict tree (ecbs.hpp:118-136; ll_device.h kCtxChain): agent a is planned against the
+// paths of the agents in front of it, the focal table [kChainRows][n_agents_pad] stays in the window between the
+// searches and gains one column per path.  Everything runs in the compact tier; a search that outgrows it ends the chain
+// in front of it.  Written for the A*-epsilon-only kernels (BG window).
+DEVI void runChain(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t* arenaSlot, DevResult& res,
+                   uint16_t* outPath, uint16_t* hostOut) {
+  constexpr bool BG = true;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t n = J.n_ctx, first = J.t_pad, npad = J.n_agents_pad;
+  res.tier = 0;
+  res.n_states = 0;
+  res.expanded = 0;
+  if (P.lds_nodes == 0 || J.dimx > 32u || J.dimy > 32u || n > kChainMaxAgents || first >= n || npad < n || npad > 128u ||
+      (npad & 1u) || kChainRows * npad * 2u > P.lds_paths_bytes ||
+      (uint64_t)P.arena_nodes * 16u < ct::kParentBytes + ct::kBitsBytes ||
+      (uint64_t)n * kChainEntryWords * 2u + (uint64_t)n * 64u > (uint64_t)P.out_host_stride) {
+    res.status = ST_BAD;  // (the host packer refuses such a job)
+    return;
+  }
+  const uint32_t* who = P.cons + J.vc_off;   // starts / goals
+  const uint32_t* ids = who + n;             // path-store slots
+  uint16_t* table = (uint16_t*)(smem + ldsBytes(0, BG));
+  for (uint32_t i = lane; i < kChainRows * npad / 2u; i += 64) ((uint32_t*)table)[i] = 0xFFFFFFFFu;  // nobody anywhere
+  __syncthreads();
+  for (uint32_t a = 0; a < first; ++a) {  // the paths that exist already: lane = time step
+    const uint32_t id = rfl(hostLoad32(ids + a));
+    if (id >= P.path_store_slots) continue;
+    const uint16_t* slot = P.path_store + (size_t)id * P.path_store_stride;
+    uint32_t len = rfl(storeLoad(slot));
+    if (len > P.path_store_stride - 1) len = P.path_store_stride - 1;
+    if (len == 0) continue;
+    table[lane * npad + a] = (uint16_t)storeLoad(slot + 1 + (lane < len ? lane : len - 1));
+  }
+  __syncthreads();
+  int64_t budget = J.max_expansions;  // < 0: unlimited
+  uint32_t* hostW = (uint32_t*)hostOut;
+  uint32_t pathOff = n * kChainEntryWords;  // words
+  uint32_t done = 0;
+  int64_t total = 0;
+  for (uint32_t a = first; a < n; ++a) {
+    const uint32_t sg = rfl(hostLoad32(who + a));
+    ct::CJob cj;
+    cj.dimx = J.dimx; cj.dimy = J.dimy;
+    cj.sx = sg & 0xFFu; cj.sy = (sg >> 8) & 0xFFu; cj.gx = (sg >> 16) & 0xFFu; cj.gy = sg >> 24;
+    cj.lastGoal = -1;
+    cj.w = J.w;
+    cj.nVc = 0; cj.nEc = 0;
+    cj.obstWords = J.words_per_row;
+    cj.nAgentsPad = npad; cj.tPad = kChainRows;
+    cj.maxExp = budget < 0 ? 0xFFFFFFFFu : (budget > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)budget);
+    cj.openCap = P.lds_nodes / 2u < ct::kCap ? P.lds_nodes / 2u : ct::kCap;
+    cj.maxT = P.lds_rows >= 3u && P.lds_rows - 2u < ct::kMaxT ? P.lds_rows - 2u : ct::kMaxT;
+    cj.taNoGoal = 0;
+    cj.vc = 0; cj.ec = 0;
+    cj.obst = (uint64_t)(P.maps + J.map_word_off);
+    cj.pathsG = 0;
+    cj.parentTab = (uint64_t)arenaSlot;
+    cj.outPath = (uint64_t)outPath;
+    cj.bitsG = (uint64_t)(arenaSlot + ct::kParentBytes);
+    __syncthreads();
+    {
+      auto w32 = (__attribute__((address_space(3))) uint32_t*)((wv::Lds)smem + ct::oJob);
+      const uint32_t* src = (const uint32_t*)&cj;
+#pragma unroll
+      for (uint32_t q = 0; q < sizeof(ct::CJob) / 4; ++q) w32[q] = src[q];
+    }
+#ifndef MRP_LL_TRACE
+    const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int32_t crc = ct::compactSearch<true, true, BG>((wv::Lds)smem);
+    auto r32 = (__attribute__((address_space(3))) const uint32_t*)((wv::Lds)smem + ct::oRes);
+    const int32_t cost = (int32_t)rfl(r32[1]), fmin = (int32_t)rfl(r32[2]), nStates = (int32_t)rfl(r32[3]);
+    const uint32_t expanded = rfl(r32[4]);
+#ifndef MRP_LL_TRACE
+    res.prof[0] += (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);
+    res.prof[1] += expanded;
+#endif
+    if (crc == ct::C_OVERFLOW) {
+#ifndef MRP_LL_TRACE
+      res.prof[6] += expanded;
+      res.prof[7] += 1;
+#endif
+      break;  // not a search of this tier: the caller runs it as an ordinary job
+    }
+    {  // the agent's entry
+      uint32_t v = 0;
+      v = lane == 0 ? (uint32_t)crc : lane == 1 ? (uint32_t)cost : lane == 2 ? (uint32_t)fmin
+          : lane == 3 ? (crc == ct::C_OK ? (uint32_t)nStates : 0u) : lane == 4 ? expanded : lane == 5 ? pathOff : 0u;
+      if (lane < kChainEntryWords) hostStore32(hostW + (size_t)done * kChainEntryWords + lane, v);
+    }
+    done += 1;
+    total += expanded;
+    if (crc != ct::C_OK) break;  // no path / expansion budget: the conflict tree ends with this answer
+    const uint32_t len = (uint32_t)nStates;
+    {  // the path: to the host, to its path-store slot, into the table
+      const uint32_t words = (len + 1u) / 2u;
+      const uint32_t* src = (const uint32_t*)outPath;
+      for (uint32_t i = lane; i < words; i += 64) hostStore32(hostW + pathOff + i, src[i]);
+      pathOff += words;
+      const uint32_t sid = rfl(hostLoad32(ids + a));
+      if (sid < P.path_store_slots && len < P.path_store_stride) {
+        uint16_t* slot = P.path_store + (size_t)sid * P.path_store_stride;
+        for (uint32_t i = lane; i < len; i += 64) __hip_atomic_store(slot + 1 + i, outPath[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot, (uint16_t)len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      table[lane * npad + a] = outPath[lane < len ? lane : len - 1];
+    }
+    if (budget >= 0) budget = budget > (int64_t)expanded ? budget - (int64_t)expanded : 0;  // Instance::remainingLL()
+  }
+  __syncthreads();
+  res.status = ST_OK;
+  res.n_states = (int32_t)done;
+  res.expanded = total;
+  res.cost = 0;
+  res.fmin = 0;
+}
+
 // MRP_LL_ASTAR_TA: the low level of the task-assignment callers, served by the compact tier alone
 // (ll_compact.h compactSearchTA).  The job's constraint words are read where the host put them; the goal's shortest-path
 // table sits in the maps buffer (mrp_ll_upload_heuristic).
@@ -2229,7 +2346,12 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
     else
       runJob<false, false>(P, J, smem, arenaSlot, res, outPath);
   } else if (KIND == 1) {  // the A*-epsilon-only kernels: the small window (mrp_ll_lds_bytes(kind = 1))
-    if (algo == 1) runJob<true, true>(P, J, smem, arenaSlot, res, outPath);
+    if (algo == 1) {
+      if (rfl(J.ctx_flags) & kCtxChain)
+        runChain(P, J, smem, arenaSlot, res, outPath, pathDst);
+      else
+        runJob<true, true>(P, J, smem, arenaSlot, res, outPath);
+    }
   } else {
     if (algo == 0) runJob<false, false>(P, J, smem, arenaSlot, res, outPath);
     if (algo == 3) runJobTA(P, J, smem, arenaSlot, res, outPath);
@@ -2245,7 +2367,7 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
   resS = res;
   __syncthreads();
   if (lane < sizeof(DevResult) / 4) hostStore32((uint32_t*)resDst + lane, ((const uint32_t*)&resS)[lane]);
-  if (res.status == ST_OK) {
+  if (res.status == ST_OK && !(KIND == 1 && (rfl(J.ctx_flags) & kCtxChain))) {  // (a root chain wrote its own output)
     const uint32_t words = ((uint32_t)res.n_states + 1) / 2;
     const uint32_t* src = (const uint32_t*)outPath;
     uint32_t* dst = (uint32_t*)pathDst;
@@ -2286,7 +2408,7 @@ DEVI void batchLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevResul
     j = rfl(j) - P.queue_base;
     DBG(P, 1, j + 1);
     if (j >= P.n_jobs) break;
-    processJob<KIND>(P, P.jobs + j, P.results + j, P.out_paths + (size_t)j * P.out_stride, smem, arenaSlot, jobS, resS);
+    processJob<KIND>(P, P.jobs + j, P.results + j, P.out_paths + (size_t)j * P.out_host_stride, smem, arenaSlot, jobS, resS);
     DBG(P, 3, j + 1);
   }
   DBG(P, 4, 1);
@@ -2363,7 +2485,7 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams
     uint32_t j = atomicAdd(P.queue_head, lane == 0 ? 1u : 0u);
     j = rfl(j) - P.queue_base;
     if (j >= P.n_jobs) break;
-    processSippJob(P, P.jobs + j, P.results + j, P.out_paths + (size_t)j * P.out_stride, arenaSlot, nullptr, jobS, resS);
+    processSippJob(P, P.jobs + j, P.results + j, P.out_paths + (size_t)j * P.out_host_stride, arenaSlot, nullptr, jobS, resS);
   }
 }
 
@@ -2486,10 +2608,10 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
     idleTicks += t1c - t0;
     if (stop) break;
     if (SIPP)
-      processSippJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, arenaSlot, smem, jobS,
+      processSippJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_host_stride, arenaSlot, smem, jobS,
                      resS);
     else
-      processJob<KIND>(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_stride, smem, arenaSlot,
+      processJob<KIND>(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_host_stride, smem, arenaSlot,
                        jobS, resS);
 #ifdef MRP_LL_SESSION_FENCES
     __threadfence_system();

@@ -187,6 +187,7 @@ struct Ring {
   std::vector<mrp_ll_sipp_table*> slotTable;  // SIPP: the table of the slot's job when the job has to report back to it
   std::vector<uint8_t> slotSippFlags;         //       bit 0: it runs on the device-resident copy, bit 1: sipp_commit
   std::vector<int32_t> slotInit;   // initial_cost (A*) / start_time (SIPP) of the slot's job
+  std::vector<int32_t> slotChain;  // MRP_LL_JOB_ROOT_CHAIN: results the slot's job fills (n_agents - agent_idx), else 0
 };
 // The host's stores into the push block are write-combined when it is device memory: everything written so far leaves
 // the core's buffers, in order, before whatever is stored next (x86 SFENCE; a no-op price for pinned host memory).
@@ -715,6 +716,39 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   if (j.algo != MRP_LL_ASTAR && j.algo != MRP_LL_ASTAR_EPS && j.algo != MRP_LL_SIPP && j.algo != MRP_LL_ASTAR_TA) return false;
   if (j.algo == MRP_LL_ASTAR_EPS && j.initial_cost != 0) return false;  // AStarEpsilon::search has no initialCost
   if (j.initial_cost < 0) return false;
+  if (j.flags & MRP_LL_JOB_ROOT_CHAIN) {  // the root step of an ECBS conflict tree as one job (mrp_ll.h; ll_device.h kCtxChain)
+    const int n = j.n_agents, first = j.agent_idx;
+    if (j.algo != MRP_LL_ASTAR_EPS || !ctx->ring.active || ctx->ring.sipp || ctx->ring.kind != 1) return false;
+    if (n < 1 || n > static_cast<int>(mrp::kChainMaxAgents) || first < 0 || first >= n) return false;
+    if (!j.path_ids || !j.chain_starts_goals_xy || !ctx->pathStore || mp.dimx > 32 || mp.dimy > 32) return false;
+    std::memset(&d, 0, sizeof(d));
+    d.map_word_off = mp.wordOff;
+    d.dimx = mp.dimx;
+    d.dimy = mp.dimy;
+    d.words_per_row = mp.wpr;
+    d.algo = j.algo;
+    d.w = j.w;
+    d.max_expansions = j.max_expansions;
+    d.last_goal_constraint = -1;
+    d.ctx_flags = mrp::kCtxChain;
+    d.n_ctx = static_cast<uint32_t>(n);
+    d.t_pad = static_cast<uint32_t>(first);
+    d.n_agents_pad = static_cast<uint32_t>((n + 15) & ~15);
+    d.store_out_id = mrp::kNoStoreSlot;
+    d.vc_off = static_cast<uint32_t>(cs.size());
+    for (int a = 0; a < n; ++a) {
+      const int32_t* q = j.chain_starts_goals_xy + 4 * a;
+      if (q[0] < 0 || q[0] >= mp.dimx || q[1] < 0 || q[1] >= mp.dimy || q[2] < 0 || q[2] >= mp.dimx || q[3] < 0 || q[3] >= mp.dimy)
+        return false;
+      cs.push(static_cast<uint32_t>(q[0]) | (static_cast<uint32_t>(q[1]) << 8) | (static_cast<uint32_t>(q[2]) << 16) |
+              (static_cast<uint32_t>(q[3]) << 24));
+    }
+    for (int a = 0; a < n; ++a) {
+      if (j.path_ids[a] < 0 || static_cast<uint32_t>(j.path_ids[a]) >= ctx->pathStoreSlots) return false;
+      cs.push(static_cast<uint32_t>(j.path_ids[a]));
+    }
+    return !cs.failed;
+  }
   auto inGrid = [&](int x, int y) { return x >= 0 && x < mp.dimx && y >= 0 && y < mp.dimy; };
   if (!inGrid(j.start_x, j.start_y)) return false;
   if (j.n_vertex_constraints < 0 || j.n_edge_constraints < 0 || j.n_agents < 0) return false;
@@ -851,6 +885,41 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   return true;
 }
 
+void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool rejected, mrp_ll_result& r, bool sipp, int dimx,
+                  int32_t init);
+// The output of a root chain (ll_device.h kCtxChain) -> the caller's per-agent results; `count` = results the job may fill.
+void unpackChain(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* out, bool rejected, mrp_ll_result& r, int32_t count) {
+  r.status = rejected ? MRP_LL_BAD_JOB : d.status;
+  r.cost = r.fmin = 0;
+  r.tier = 0;
+  const int32_t done = (rejected || d.status != mrp::ST_OK) ? 0 : std::min<int32_t>(d.n_states, count);
+  r.n_states = done;
+  r.expanded = rejected ? 0 : d.expanded;
+  if (!rejected)
+    for (int q = 0; q < 8; ++q) ctx->stats.prof[q] += d.prof[q];
+  if (!r.chain_results) return;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(out);
+  for (int32_t i = 0; i < count; ++i) {
+    mrp_ll_result& ri = r.chain_results[i];
+    if (i < done) {
+      const uint32_t* e = w + static_cast<size_t>(i) * mrp::kChainEntryWords;
+      DevResult f;
+      std::memset(&f, 0, sizeof(f));
+      f.status = static_cast<int32_t>(e[0]);
+      f.cost = static_cast<int32_t>(e[1]);
+      f.fmin = static_cast<int32_t>(e[2]);
+      f.n_states = static_cast<int32_t>(e[3]);
+      f.expanded = e[4];
+      unpackResult(ctx, f, reinterpret_cast<const uint16_t*>(w + e[5]), false, ri, false, 0, 0);
+    } else {
+      ri.status = MRP_LL_NOT_RUN;
+      ri.cost = ri.fmin = ri.n_states = 0;
+      ri.expanded = 0;
+      ri.tier = 0;
+    }
+  }
+}
+
 // Fills the launch parameters that do not depend on where the jobs live; returns the dynamic LDS size.
 // kind: the kernel family the launch uses (0 mixed, 1 A*-epsilon only, 2 A* only): the A*-epsilon-only kernels keep the
 // (time, cell) bitmap of the compact tier in the arena slot and take a smaller LDS window.
@@ -862,6 +931,7 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
   P.arena_scratch_off = ctx->arenaScratchOff;
   P.arena_paths_bytes = ctx->arenaPathsBytes;
   P.out_stride = static_cast<uint32_t>(ctx->opt.max_horizon);
+  P.out_host_stride = P.out_stride;  // (sessions: the ring's stride, sessionBegin)
   P.arena_nodes = static_cast<uint32_t>(ctx->opt.arena_nodes);
   P.arena_rows = static_cast<uint32_t>(ctx->opt.max_horizon);
   P.arena_row_words = ctx->arenaRowWords;
@@ -906,7 +976,7 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
 
 // Device result -> caller's mrp_ll_result (+ statistics).
 void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool rejected, mrp_ll_result& r,
-                  bool sipp = false, int dimx = 0, int32_t init = 0) {
+                  bool sipp, int dimx, int32_t init) {
   if (rejected) {
     r.status = MRP_LL_BAD_JOB;
     r.cost = r.fmin = r.n_states = 0;
@@ -1243,7 +1313,8 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
   int rc = syncMaps(ctx);
   if (rc != MRP_LL_SUCCESS) return rc;
   const uint32_t R = Ring::kSlots;
-  g.outStride = static_cast<uint32_t>(ctx->opt.max_horizon);
+  // halfwords per job slot of the host output area: a path, or the output of a root chain (ll_device.h kCtxChain)
+  g.outStride = std::max<uint32_t>(static_cast<uint32_t>(ctx->opt.max_horizon), 4096u);
   if (!g.block) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -1337,6 +1408,7 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
     g.slotSippFlags.assign(R, 0);
   }
   g.slotInit.assign(R, 0);
+  g.slotChain.assign(R, 0);
   ctx->sess.clear();
   ctx->sessFree.clear();
   auto devPtr = [&](void* hostPtr) {
@@ -1383,6 +1455,7 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
   uint32_t ldsBytes = 0;
   rc = fillCommonParams(ctx, t, P, ldsBytes, sipp ? 0 : kind);
   if (rc != MRP_LL_SUCCESS) return rc;
+  P.out_host_stride = g.outStride;
   ctx->sessionRowWords = P.lds_row_words;
   g.grid = static_cast<uint32_t>(workgroups > 0 ? std::min(workgroups, ctx->opt.slots) : ctx->opt.slots);
   HIPCHK(ctx, hipMemsetAsync(t.queueHead, 0, 256, t.stream));  // session tickets of both lanes count from 0
@@ -1562,6 +1635,7 @@ static int sessionSubmit(mrp_ll_ctx* ctx, int32_t lane, int32_t nJobs, const mrp
     ctx->stats.staged_bytes += static_cast<int64_t>(sizeof(DevJob)) + 4 * static_cast<int64_t>(g.sipp ? sippWords : cs.used) +
                                (g.sipp || (d.ctx_flags & mrp::kCtxById) ? 0 : 2 * static_cast<int64_t>(d.t_pad) * d.n_agents_pad);
     g.slotInit[slot] = jobInitOf(jobs[i], ok);
+    g.slotChain[slot] = ((jobs[i].flags & MRP_LL_JOB_ROOT_CHAIN) && !g.sipp) ? std::max(1, jobs[i].n_agents - jobs[i].agent_idx) : 0;
     g.busy[slot] = 1;
     g.slotTicket[slot] = ti;
     g.slotJob[slot] = i;
@@ -1605,8 +1679,12 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
     if (st.state[i] == 1) continue;
     const uint32_t slot = st.slots[i];
     if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != st.seq[i]) continue;
-    unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
-                 st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);
+    if (g.slotChain[slot])
+      unpackChain(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2, st.res[i],
+                  g.slotChain[slot]);
+    else
+      unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
+                   st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);
     if (g.sipp && g.slotTable[slot]) {
       finishSippTableJob(g.slotTable[slot], g.slotSippFlags[slot], g.results[slot],
                          g.outPaths + static_cast<size_t>(slot) * g.outStride);
@@ -1645,8 +1723,12 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
     if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != g.slotGen[slot]) continue;
     SessTicket& st = ctx->sess[g.slotTicket[slot]];
     const int32_t i = g.slotJob[slot];
-    unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
-                 st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);
+    if (g.slotChain[slot])
+      unpackChain(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2, st.res[i],
+                  g.slotChain[slot]);
+    else
+      unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
+                   st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);
     if (g.sipp && g.slotTable[slot]) {
       finishSippTableJob(g.slotTable[slot], g.slotSippFlags[slot], g.results[slot],
                          g.outPaths + static_cast<size_t>(slot) * g.outStride);

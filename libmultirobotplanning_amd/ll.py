@@ -40,14 +40,15 @@ class mrp_ll_job(ctypes.Structure):
                 ("n_collision_locations", ctypes.c_int32), ("collision_xy", I32P), ("collision_count", I32P),
                 ("collision_intervals", I32P), ("initial_cost", ctypes.c_int32), ("sipp_commit", ctypes.c_int32),
                 ("sipp_table", ctypes.c_void_p), ("path_ids", I32P), ("result_path_id", ctypes.c_int32),
-                ("flags", ctypes.c_int32), ("heuristic_id", ctypes.c_int32), ("reserved3", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("heuristic_id", ctypes.c_int32), ("reserved3", ctypes.c_int32),
+                ("chain_starts_goals_xy", I32P)]
 
 
 class mrp_ll_result(ctypes.Structure):
     _fields_ = [("status", ctypes.c_int32), ("cost", ctypes.c_int32), ("fmin", ctypes.c_int32),
                 ("n_states", ctypes.c_int32), ("expanded", ctypes.c_int64), ("states_txy", I32P),
                 ("actions", I32P), ("states_cap", ctypes.c_int32), ("tier", ctypes.c_int32),
-                ("action_costs", I32P)]
+                ("action_costs", I32P), ("chain_results", ctypes.c_void_p)]
 
 
 class mrp_ll_conflict(ctypes.Structure):

@@ -44,6 +44,6 @@ def test_struct_layouts_match_header(built):
     from libmultirobotplanning_amd import ll
     # sizes the C compiler produces for the structs of mrp_ll.h on LP64
     assert ctypes.sizeof(ll.mrp_ll_options) == 32
-    assert ctypes.sizeof(ll.mrp_ll_job) == 168
-    assert ctypes.sizeof(ll.mrp_ll_result) == 56
+    assert ctypes.sizeof(ll.mrp_ll_job) == 176
+    assert ctypes.sizeof(ll.mrp_ll_result) == 64
     assert ctypes.sizeof(ll.mrp_ll_stats) == 176
