@@ -195,6 +195,31 @@ def test_prioritized_sipp_capacity_status_is_per_instance(solver, oracle_mod, re
     assert 0 < stopped < len(insts)
 
 
+def test_root_chains_change_nothing_but_the_number_of_jobs(solver, oracle_mod, bench_instances):
+    """MRP_LL_JOB_ROOT_CHAIN (the root step of an ECBS tree as one job, ecbs.hpp:118-136): same results as one job per root
+    search — every counter, every path — on shipped inputs (whose long root searches break chains and resume them) and
+    synthetic ones, against the oracle and against the driver with chains switched off; far fewer tickets."""
+    import os
+    from libmultirobotplanning_amd import hl
+    insts = [bench_instances["map_32by32_obst204_agents%d_ex%d" % (a, k)] for a, k in ((10, 13), (10, 0), (20, 3), (30, 2), (30, 7))]
+    insts += [hl.generate_instance(1000 * 10 + 91000 + k, 32, 32, 204, 10) for k in range(600)]
+    insts += [hl.generate_instance(1000 * 24 + 300 + k, 32, 32, 204, 24) for k in range(40)]
+    res_on, st_on = solver.solve(insts, algo=hl.ECBS, w=1.3, max_ll_expansions=200000)
+    os.environ["MRP_HL_ROOT_CHAIN"] = "0"
+    try:
+        res_off, st_off = solver.solve(insts, algo=hl.ECBS, w=1.3, max_ll_expansions=200000)
+    finally:
+        del os.environ["MRP_HL_ROOT_CHAIN"]
+    assert st_on["rounds"] * 3 < st_off["rounds"]  # the chains were really used
+    keys = ("status", "cost", "makespan", "hl_expanded", "ll_expanded", "ll_searches", "paths")
+    for i, (a, b) in enumerate(zip(res_on, res_off)):
+        assert [a.get(k) for k in keys] == [b.get(k) for k in keys], i
+    for inst, r in list(zip(insts, res_on))[:40]:
+        o = oracle_mod.mapf_solve(oracle_mod.ECBS, inst, w=1.3, cap_total=200000)
+        assert o["rc"] == 1 and (r["status"], r["cost"], r["hl_expanded"], r["ll_expanded"]) == (
+            hl.SOLVED, o["cost"], o["hl_expanded"], o["ll_expanded"])
+
+
 def test_bench_scale_properties_and_determinism(solver):
     """At the bench workload's size the oracle is too slow to check everything, so size-independent properties are
     checked on 4096 synthetic agents10 instances (and the oracle on a sample):
