@@ -2,6 +2,7 @@
 // Implements the C-ABI of include/mrp_ll.h on top of the ORACLE's low-level search (oracle_ll_search) so that the
 // host-side conflict-tree drivers (csrc/hl/) can be exercised on a machine without a GPU (`-m "not gpu"` tests).
 // The product library has no such path: libmrp_ll.so fails with MRP_LL_E_DEVICE when no HIP device exists.
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +30,7 @@ struct mrp_ll_ctx {
   int32_t nextTicket = 0;
   const mrp_ll_job* jobs = nullptr;
   mrp_ll_result* results = nullptr;
+  std::vector<std::vector<int32_t>> store;  // MRP_MOCK_PATH_STORE=1: the "device" path store, slot -> x, y, x, y, ...
 };
 
 extern "C" {
@@ -46,10 +48,80 @@ int mrp_ll_upload_map(mrp_ll_ctx* c, int32_t dimx, int32_t dimy, int32_t n, cons
   *id = static_cast<int32_t>(c->maps.size()) - 1;
   return MRP_LL_SUCCESS;
 }
+// MRP_LL_JOB_ROOT_CHAIN on the mock: agent after agent through the oracle, contexts from the mock's path store.
+// MRP_MOCK_CHAIN_BREAK=K: a search of more than K expansions "does not fit the LDS tier" and ends the chain in front of it.
+static void mockChain(mrp_ll_ctx* c, const mrp_ll_job& j, mrp_ll_result& r) {
+  const MockMap& m = c->maps[j.map_id];
+  const int n = j.n_agents, first = j.agent_idx;
+  const char* bk = std::getenv("MRP_MOCK_CHAIN_BREAK");
+  const int64_t breakAt = bk ? std::atoll(bk) : -1;
+  int64_t budget = j.max_expansions, total = 0;
+  int done = 0;
+  bool stopped = false;
+  r.status = MRP_LL_OK;
+  for (int a = first; a < n; ++a) {
+    mrp_ll_result& ri = r.chain_results[a - first];
+    ri.status = MRP_LL_NOT_RUN;
+    ri.cost = ri.fmin = ri.n_states = 0;
+    ri.expanded = 0;
+    if (stopped) continue;
+    std::vector<int32_t> ctxLen, ctxXY;
+    for (int b = 0; b < n; ++b) {
+      const std::vector<int32_t>* p = b < a ? &c->store[j.path_ids[b]] : nullptr;
+      ctxLen.push_back(p ? static_cast<int32_t>(p->size() / 2) : 0);
+      if (p) ctxXY.insert(ctxXY.end(), p->begin(), p->end());
+    }
+    const int32_t* q = j.chain_starts_goals_xy + 4 * a;
+    int32_t out[4];
+    int64_t expanded = 0;
+    std::vector<int32_t> st(3 * 2048), ac(2048);
+    int rc = oracle_ll_search(MRP_LL_ASTAR_EPS, j.w, m.dimx, m.dimy, static_cast<int>(m.obst.size() / 2), m.obst.data(), a, q[0],
+                              q[1], q[2], q[3], 0, nullptr, 0, nullptr, n, ctxLen.data(), ctxXY.data(), budget, out, &expanded,
+                              st.data(), ac.data(), 2048);
+    if (breakAt >= 0 && expanded > breakAt) {  // (the device would have found out on the way; the answer is not used)
+      stopped = true;
+      continue;
+    }
+    ri.expanded = expanded;
+    ri.tier = 0;
+    total += expanded;
+    done += 1;
+    c->stats.jobs += 1;
+    c->stats.expansions += expanded;
+    if (rc == -1) {
+      ri.status = MRP_LL_CAP_EXPANSIONS;
+      stopped = true;
+      continue;
+    }
+    ri.status = out[0] ? MRP_LL_OK : MRP_LL_NO_SOLUTION;
+    ri.cost = out[1];
+    ri.fmin = out[2];
+    ri.n_states = out[0] ? out[3] : 0;
+    if (!out[0]) {
+      stopped = true;
+      continue;
+    }
+    std::vector<int32_t>& slot = c->store[j.path_ids[a]];
+    slot.clear();
+    for (int k = 0; k < ri.n_states; ++k) {
+      if (ri.states_txy && k < ri.states_cap) std::memcpy(ri.states_txy + 3 * k, st.data() + 3 * k, 12);
+      slot.push_back(st[3 * k + 1]);
+      slot.push_back(st[3 * k + 2]);
+    }
+    if (budget >= 0) budget = budget > expanded ? budget - expanded : 0;
+  }
+  r.n_states = done;
+  r.expanded = total;
+}
+
 int mrp_ll_search_batch(mrp_ll_ctx* c, int32_t n, const mrp_ll_job* jobs, mrp_ll_result* res) {
   for (int i = 0; i < n; ++i) {
     const mrp_ll_job& j = jobs[i];
     mrp_ll_result& r = res[i];
+    if ((j.flags & MRP_LL_JOB_ROOT_CHAIN) && j.map_id >= 0 && j.map_id < static_cast<int>(c->maps.size()) && !c->store.empty()) {
+      mockChain(c, j, r);
+      continue;
+    }
     if (j.map_id < 0 || j.map_id >= static_cast<int>(c->maps.size())) {
       r.status = MRP_LL_BAD_JOB;
       continue;
@@ -82,6 +154,14 @@ int mrp_ll_search_batch(mrp_ll_ctx* c, int32_t n, const mrp_ll_job* jobs, mrp_ll
     for (int k = 0; k < r.n_states && k < r.states_cap; ++k) {
       if (r.states_txy) std::memcpy(r.states_txy + 3 * k, st.data() + 3 * k, 12);
       if (r.actions && k + 1 < r.n_states) r.actions[k] = ac[k];
+    }
+    if ((j.flags & MRP_LL_JOB_STORE_RESULT) && j.result_path_id >= 0 && j.result_path_id < static_cast<int>(c->store.size())) {
+      std::vector<int32_t>& slot = c->store[j.result_path_id];
+      slot.clear();
+      for (int k = 0; k < r.n_states; ++k) {
+        slot.push_back(st[3 * k + 1]);
+        slot.push_back(st[3 * k + 2]);
+      }
     }
     c->stats.jobs += 1;
     c->stats.expansions += expanded;
@@ -157,7 +237,14 @@ int mrp_ll_poll(mrp_ll_ctx*, int32_t, int32_t* done) {
 int mrp_ll_conflict_scan(mrp_ll_ctx*, int32_t, const int32_t*, const int32_t*, const int32_t*, mrp_ll_conflict*) {
   return MRP_LL_E_DEVICE;  // the scan kernel has no stand-in: the host drivers do not call it
 }
-int mrp_ll_path_store_reserve(mrp_ll_ctx*, int32_t) { return MRP_LL_E_DEVICE; }  // no store here: the drivers fall back to tables
+// no store by default: the drivers fall back to tables.  MRP_MOCK_PATH_STORE=1: a host-side one, so that the drivers' path
+// ids and root chains run on the CPU too
+int mrp_ll_path_store_reserve(mrp_ll_ctx* c, int32_t n) {
+  const char* e = std::getenv("MRP_MOCK_PATH_STORE");
+  if (!e || *e != '1') return MRP_LL_E_DEVICE;
+  c->store.assign(static_cast<size_t>(std::max(n, 0)), std::vector<int32_t>());
+  return MRP_LL_SUCCESS;
+}
 struct mrp_ll_sipp_table {};  // SIPP has no stand-in here: the prioritized-SIPP driver is covered by the GPU tests
 int mrp_ll_sipp_table_create(mrp_ll_ctx*, int32_t, mrp_ll_sipp_table** out) {
   *out = new mrp_ll_sipp_table();

@@ -148,3 +148,36 @@ def test_speculative_expansion_changes_nothing_but_the_schedule(cpu_solver, benc
         assert len(deep) == 3
         res, _ = cpu_solver.solve([bench_instances[n] for n in deep], algo=hl.CBS, max_hl_expansions=7)
         assert all(r["status"] == hl.CAP and r["hl_expanded"] == 8 for r in res)
+
+
+def test_root_chains_on_the_mock(cpu_solver, bench_instances, oracle_expected, monkeypatch):
+    """The drivers' root chains (MRP_LL_JOB_ROOT_CHAIN) on the CPU: the mock keeps a host-side path store and runs a chain
+    through the oracle; with MRP_MOCK_CHAIN_BREAK a search of more than that many expansions ends its chain in front of
+    it, as a search that outgrows the LDS tier does on the device — the driver must run it as its own job and chain on."""
+    from libmultirobotplanning_amd import hl
+    names = ["map_32by32_obst204_agents10_ex%d" % k for k in range(0, 40, 3)] + ["map_32by32_obst204_agents20_ex1",
+                                                                                "map_32by32_obst204_agents30_ex2"]
+    lib = os.path.join(BUILD, "libmrp_hl_cpu.so")
+    monkeypatch.setenv("MRP_MOCK_PATH_STORE", "1")
+    for brk in (None, "150", "0"):
+        if brk is None:
+            monkeypatch.delenv("MRP_MOCK_CHAIN_BREAK", raising=False)
+        else:
+            monkeypatch.setenv("MRP_MOCK_CHAIN_BREAK", brk)
+        s = hl.BatchSolver(device=0, n_threads=2, _lib_path=lib)
+        try:
+            res, st = s.solve([bench_instances[n] for n in names], algo=hl.ECBS, w=1.3)
+        finally:
+            s.close()
+        searches = 0
+        for n, r in zip(names, res):
+            e = oracle_expected[n]["ecbs_w1.3"]
+            assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
+                hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"]), (n, brk)
+            assert _digest(r["paths"]) == e["digest"], (n, brk)
+            searches += r["ll_searches"]
+        # chains: far fewer tickets than searches; "0": every chain breaks at its first search, one ticket more per search
+        if brk is None:
+            assert st["rounds"] * 3 < searches
+        if brk == "0":
+            assert st["rounds"] > searches
