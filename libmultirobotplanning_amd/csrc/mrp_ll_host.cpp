@@ -235,6 +235,7 @@ struct mrp_ll_ctx {
   std::vector<uint8_t*> sippTabChunks;
   std::vector<int32_t> sippTabFree;
   int32_t sippTabNext = 0;
+  bool sippUncached = false;       // MRP_LL_SIPP_TABLES_UNCACHED at creation
   size_t sippTabStride = 0;
   int32_t sippTabsPerChunk = 64;
   uint16_t* pathStore = nullptr;   // device-resident path store (mrp_ll_path_store_reserve)
@@ -258,14 +259,11 @@ static const bool kDebug = std::getenv("MRP_LL_DEBUG") != nullptr;
     }                                                                                             \
   } while (0)
 
-// MRP_LL_SIPP_TABLES_UNCACHED=1: the device-resident SIPP tables in uncached device memory (no cache fences around
-// their use, every table access goes to memory); read once per process
-bool sippTablesUncached() {
-  static const bool v = [] {
-    const char* e = std::getenv("MRP_LL_SIPP_TABLES_UNCACHED");
-    return e && *e == '1';
-  }();
-  return v;
+// MRP_LL_SIPP_TABLES_UNCACHED=1 (read when a context is created): the device-resident SIPP tables in uncached device
+// memory — no cache fences around their use, every table access goes to memory
+bool sippTablesUncachedEnv() {
+  const char* e = std::getenv("MRP_LL_SIPP_TABLES_UNCACHED");
+  return e && *e == '1';
 }
 
 int actionFromDelta(int dx, int dy) {
@@ -955,7 +953,7 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
   P.path_store = ctx->pathStore;
   P.path_store_stride = ctx->pathStoreStride;
   P.path_store_slots = ctx->pathStore ? ctx->pathStoreSlots : 0;
-  P.sipp_tables_uncached = sippTablesUncached() ? 1u : 0u;
+  P.sipp_tables_uncached = ctx->sippUncached ? 1u : 0u;
   P.lds_nodes = ldsNodes;
   P.lds_rows = rows;
   P.lds_row_words = rowWords;
@@ -1120,6 +1118,7 @@ int mrp_ll_create(const mrp_ll_options* optIn, mrp_ll_ctx** out) {
   }
   mrp_ll_ctx* ctx = new mrp_ll_ctx();
   ctx->opt = o;
+  ctx->sippUncached = sippTablesUncachedEnv();
   ctx->device = o.device;
   std::memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (hipSetDevice(o.device) != hipSuccess) {
@@ -1988,7 +1987,7 @@ int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t mapId, mrp_ll_sipp_table**
     if (ctx->sippTabNext == static_cast<int32_t>(ctx->sippTabChunks.size()) * ctx->sippTabsPerChunk) {
       void* c = nullptr;
       if (hipSetDevice(ctx->device) == hipSuccess &&
-          (sippTablesUncached() ? hipExtMallocWithFlags(&c, ctx->sippTabStride * ctx->sippTabsPerChunk, hipDeviceMallocUncached)
+          (ctx->sippUncached ? hipExtMallocWithFlags(&c, ctx->sippTabStride * ctx->sippTabsPerChunk, hipDeviceMallocUncached)
                                 : hipMalloc(&c, ctx->sippTabStride * ctx->sippTabsPerChunk)) == hipSuccess)
         ctx->sippTabChunks.push_back(static_cast<uint8_t*>(c));
     }

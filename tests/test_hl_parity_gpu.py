@@ -220,6 +220,38 @@ def test_root_chains_change_nothing_but_the_number_of_jobs(solver, oracle_mod, b
             hl.SOLVED, o["cost"], o["hl_expanded"], o["ll_expanded"])
 
 
+def test_opt_in_memory_placements_give_the_same_results(oracle_mod, ref_tests):
+    """MRP_LL_RING_IN_DEVICE=1 (the host-to-device half of the job ring in uncached device memory, written through the BAR)
+    and MRP_LL_SIPP_TABLES_UNCACHED=1 (SIPP tables in uncached device memory, no fences around their use): off by
+    default, same answers."""
+    import os
+    from libmultirobotplanning_amd import hl
+    insts = [hl.generate_instance(1000 * 10 + 55000 + k, 32, 32, 204, 10) for k in range(512)]
+    sipp = [hl.generate_instance(64000 + 100 + k, 64, 64, 410, 40) for k in range(24)]
+    base = hl.BatchSolver(device=0, n_threads=4)
+    try:
+        want, _ = base.solve(insts, algo=hl.ECBS, w=1.3, max_ll_expansions=50000)
+        want_sipp, _ = base.prioritized_sipp(sipp)
+    finally:
+        base.close()
+    os.environ["MRP_LL_RING_IN_DEVICE"] = "1"
+    os.environ["MRP_LL_SIPP_TABLES_UNCACHED"] = "1"
+    try:
+        s = hl.BatchSolver(device=0, n_threads=4)
+        try:
+            got, _ = s.solve(insts, algo=hl.ECBS, w=1.3, max_ll_expansions=50000)
+            got_sipp, _ = s.prioritized_sipp(sipp)
+        finally:
+            s.close()
+    finally:
+        del os.environ["MRP_LL_RING_IN_DEVICE"]
+        del os.environ["MRP_LL_SIPP_TABLES_UNCACHED"]
+    assert got == want
+    assert got_sipp == want_sipp
+    o = oracle_mod.prioritized_sipp(sipp[0])
+    assert (got_sipp[0]["cost"], got_sipp[0]["planned"], got_sipp[0]["schedules"]) == (o["cost"], o["planned"], o["schedules"])
+
+
 def test_bench_scale_properties_and_determinism(solver):
     """At the bench workload's size the oracle is too slow to check everything, so size-independent properties are
     checked on 4096 synthetic agents10 instances (and the oracle on a sample):
