@@ -876,3 +876,20 @@ def test_zero_initialised_job_struct(oracle_mod, bench_instances):
             assert (res.status, res.cost, res.expanded) == (ll.OK, want["cost"], want["expanded"])
         finally:
             eng.close()
+
+
+@pytest.mark.gpu
+def test_session_occupancy_depends_on_the_kernel_family():
+    """mrp_ll_session_occupancy: what the runtime grants a session's resident kernel.  The A*-epsilon-only kernels keep the
+    compact tier's bitmap in device memory, so their LDS window is 8 KB smaller than the CBS / mixed kernels' and more of
+    their searches fit a CU; a larger path-table allowance lowers both."""
+    from libmultirobotplanning_amd import ll
+    eng = ll.LowLevelEngine(device=0, n_tickets=1, slots=64)
+    try:
+        eng.configure_tiers(2048, 64, 2048)
+        eps, astar = eng.session_occupancy(ll.ASTAR_EPS), eng.session_occupancy(ll.ASTAR)
+        assert 1 <= astar < eps <= 16, (eps, astar)
+        eng.configure_tiers(2048, 64, 16384)
+        assert eng.session_occupancy(ll.ASTAR_EPS) < eps
+    finally:
+        eng.close()
