@@ -247,7 +247,7 @@ def main():
             issue_bound = {"instructions_per_expansion": ipe, "ceiling_expansions_per_s": ceiling,
                            "frac": (exp_all / elapsed_max) / world / ceiling,
                            "source": "scaled from the committed PMC pass profiles/hbm_traffic_pmc.json "
-                                     "(SQ_INSTS_* passes, scripts/pmc_ll.sh), not measured in this run"}
+                                     "(SQ_INSTS_* passes over the resident kernel, scripts/r3_pmc_resident.sh), not measured in this run"}
         except (OSError, KeyError, ValueError):
             pass
         out = {
