@@ -333,8 +333,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   std::vector<int32_t> chainIds, chainXy;
   const bool chainDebug = std::getenv("MRP_HL_CHAIN_DEBUG") != nullptr;  // one line per chain answer on stderr
   // MRP_HL_ROOT_CHAIN=0: every root search is its own job (A/B; results are the same)
-  const bool rootChains = pathSlots > 0 && opt.algo == MRP_HL_ECBS &&
-                          !(std::getenv("MRP_HL_ROOT_CHAIN") && std::atoi(std::getenv("MRP_HL_ROOT_CHAIN")) == 0);
+  // (not const: an engine that cannot run chains — no compact tier, a window too small for the chain's focal table —
+  // rejects the first one, and this worker goes on with one job per root search)
+  bool rootChains = pathSlots > 0 && opt.algo == MRP_HL_ECBS &&
+                    !(std::getenv("MRP_HL_ROOT_CHAIN") && std::atoi(std::getenv("MRP_HL_ROOT_CHAIN")) == 0);
   const bool timing = std::getenv("MRP_HL_TIMING") != nullptr;
   const int32_t specK = specWidthSetting();
   auto tg0 = std::chrono::steady_clock::now();
@@ -679,8 +681,26 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       ticketsOut -= 1;
       jobsOut -= static_cast<int64_t>(P.res.size());
       if (P.chainFirst >= 0) {  // a root chain: its answers are delivered one by one, exactly like ten separate jobs
+        if (P.res[0].status == MRP_LL_BAD_JOB) {
+          // chains are unavailable on this engine (mrp_ll.h MRP_LL_JOB_ROOT_CHAIN: needs the compact tier and room for the
+          // focal table): nothing ran; the request goes out again as an ordinary job, and so does every later root search
+          rootChains = false;
+          for (int32_t sl : P.outSlot) slotPool.give(sl);
+          if (L.inst) {
+            L.req = P.chainReq;
+            L.reqHead = 0;
+          }
+          P.chainFirst = -1;
+          P.chainReq.clear();
+          pendFree.push_back(donePend[d]);
+          if (L.inst && L.reqHead < L.req.size() && !L.queued && !submitAll(k)) {
+            failed = true;
+            break;
+          }
+          continue;
+        }
         if (P.res[0].status != MRP_LL_OK) {
-          out.err = "root chain rejected by the engine (status " + std::to_string(P.res[0].status) + ")";
+          out.err = "root chain failed on the engine (status " + std::to_string(P.res[0].status) + ")";
           failed = true;
           break;
         }

@@ -111,7 +111,7 @@ struct CRes {              // at oRes
 };
 // -DMRP_CT_PROF (diagnostic build): shader cycles per phase of the search loop, in eight words behind the CRes:
 // 0 loop top + goal test, 1 ordered walk, 2 successor probes / row loads issued, 3 pop + erase, 4 successor entries,
-// 5 pushes, 6 nodes visited by walks, 7 set-up
+// 5 pushes, 6 nodes visited by walks, 7 walks skipped (no open node in the band); set-up counts as loop top
 #ifdef MRP_CT_PROF
 #define MRP_CT_PROF_DECL uint32_t prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t profT_ = wv::clock64()
 #define MRP_CT_PROF_MARK(k) do { const uint64_t n_ = wv::clock64(); prof_[k] += (uint32_t)(n_ - profT_); profT_ = n_; } while (0)
@@ -401,7 +401,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     if (EPS) ldsStoreS(lds, oFocal + 4u, e0);
   }
   sync();
-  MRP_CT_PROF_MARK(7);
+  MRP_CT_PROF_MARK(0);
 
   for (;;) {
     if (nOpen == 0u) {
@@ -421,6 +421,33 @@ WV_ENTRY int32_t compactSearch(Lds window) {
         // list, in the order of open.ordered_begin(): a best-first walk of the open array through a std::priority_queue
         // (libstdc++ push_heap / pop_heap restated: push = sift-up, pop = hole down to a leaf, then sift-up)
         const float lo = fmulRn((float)oldBest, wBound), hi = fmulRn((float)fTop, wBound);  // binary32, no contraction
+        // The walk changes nothing but the focal list, and only through the nodes of the band old * w < f <= new * w (its
+        // queue is dropped afterwards): when no open node has such an f, it is skipped.  f is an integer below 127 here, so
+        // the band is f in [floor(lo) + 1, floor(hi)]; one 16-byte read per lane looks at 256 open entries.  Slots that
+        // hold no element read as f = 127 (kEmpty) or f = 0 (the word in front of element 0): never inside.
+        // (-DMRP_CT_FORCE_WALK: always walk — the emulator's A/B for "skipping is unobservable")
+        bool bandEmpty = false;
+#ifndef MRP_CT_FORCE_WALK
+        {
+          const int32_t fA = (int32_t)lo + 1, fBraw = (int32_t)hi;  // lo, hi >= 0: truncation is floor
+          const int32_t fB = fBraw > 126 ? 126 : fBraw;
+          bandEmpty = true;
+          if (fB >= fA) {
+            const V base = splat(127u - (uint32_t)fB), span = splat((uint32_t)(fB - fA));
+            for (uint32_t g = 0; g < kGroups && g * 256u <= nOpen; ++g) {  // (element 256 g - 1 belongs to group g)
+              const V4 grp = ldsLoad128(lds, splat(oOpen + g * 1024u) + lane * 16u);
+              const B in = ((((grp.x >> 16) & 127u) - base) <= span) | ((((grp.y >> 16) & 127u) - base) <= span) |
+                           ((((grp.z >> 16) & 127u) - base) <= span) | ((((grp.w >> 16) & 127u) - base) <= span);
+              if (ballot(in)) {
+                bandEmpty = false;
+                break;
+              }
+            }
+          }
+        }
+#endif
+        MRP_CT_PROF_ADD(7, bandEmpty ? 1u : 0u);
+        if (!bandEmpty) {
         uint32_t npq = 0, npqHigh = 0;
         uint32_t cur = 0, curKey = topO & kMO, eCur = topO;  // the node being visited: open index, open key, entry
         // lanes 0, 1: the children of the node in the open array (past the end of the list: "no element"); lane 2: the node
@@ -500,6 +527,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
         }
         if (status == C_OVERFLOW) break;
         curE = ldsLoadS(lds, oFocal + 4u);
+        }
         MRP_CT_PROF_MARK(1);
       }
     }

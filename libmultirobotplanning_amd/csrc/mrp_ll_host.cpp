@@ -220,6 +220,7 @@ struct mrp_ll_ctx {
   uint32_t extraHbmWgs = 0;       // session mode: additional resident workgroups without an LDS tier (see Ring::grid2)
   uint32_t tierRows = 64, tierPathBytes = 4096;  // LDS tier geometry (mrp_ll_configure_tiers); nodes live in opt.lds_nodes
   uint32_t sessionRowWords = 0;   // LDS bitmap row width the resident kernel was launched with
+  uint32_t sessionLdsPathBytes = 0;  // ... and the bytes of its window that hold the focal path table (0: no compact tier)
   uint32_t arenaRowWords = 0;
   uint64_t arenaStride = 0;
   uint32_t arenaScratchOff = 0;
@@ -713,12 +714,20 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   const MapRec& mp = ctx->maps[j.map_id];
   if (j.algo != MRP_LL_ASTAR && j.algo != MRP_LL_ASTAR_EPS && j.algo != MRP_LL_SIPP && j.algo != MRP_LL_ASTAR_TA) return false;
   if (j.algo == MRP_LL_ASTAR_EPS && j.initial_cost != 0) return false;  // AStarEpsilon::search has no initialCost
-  if (j.initial_cost < 0) return false;
+  if (j.initial_cost < 0 || j.initial_cost >= 0x40000000) return false;  // (bit 30 of the per-job word marks MRP_LL_ASTAR_TA, jobInitOf)
   if (j.flags & MRP_LL_JOB_ROOT_CHAIN) {  // the root step of an ECBS conflict tree as one job (mrp_ll.h; ll_device.h kCtxChain)
     const int n = j.n_agents, first = j.agent_idx;
     if (j.algo != MRP_LL_ASTAR_EPS || !ctx->ring.active || ctx->ring.sipp || ctx->ring.kind != 1) return false;
     if (n < 1 || n > static_cast<int>(mrp::kChainMaxAgents) || first < 0 || first >= n) return false;
     if (!j.path_ids || !j.chain_starts_goals_xy || !ctx->pathStore || mp.dimx > 32 || mp.dimy > 32) return false;
+    {  // what runChain (ll_kernel.hip) needs of the session: the compact tier, room for its focal table in the window,
+       // an arena slot that holds the cameFrom table and the (time, cell) bitmap, room for the output in the job's host area
+      const uint32_t npad = static_cast<uint32_t>((n + 15) & ~15);
+      if (ctx->opt.lds_nodes == 0 || ctx->sessionLdsPathBytes == 0 || mrp::kChainRows * npad * 2u > ctx->sessionLdsPathBytes ||
+          static_cast<uint64_t>(ctx->opt.arena_nodes) * 16u < 64u * 1024u + 8192u ||
+          static_cast<uint64_t>(n) * mrp::kChainEntryWords * 2u + static_cast<uint64_t>(n) * 64u > ctx->ring.outStride)
+        return false;
+    }
     std::memset(&d, 0, sizeof(d));
     d.map_word_off = mp.wordOff;
     d.dimx = mp.dimx;
@@ -886,7 +895,8 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
 void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool rejected, mrp_ll_result& r, bool sipp, int dimx,
                   int32_t init);
 // The output of a root chain (ll_device.h kCtxChain) -> the caller's per-agent results; `count` = results the job may fill.
-void unpackChain(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* out, bool rejected, mrp_ll_result& r, int32_t count) {
+void unpackChain(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* out, bool rejected, mrp_ll_result& r, int32_t count,
+                 uint32_t outWords) {
   r.status = rejected ? MRP_LL_BAD_JOB : d.status;
   r.cost = r.fmin = 0;
   r.tier = 0;
@@ -908,7 +918,13 @@ void unpackChain(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* out, bool 
       f.fmin = static_cast<int32_t>(e[2]);
       f.n_states = static_cast<int32_t>(e[3]);
       f.expanded = e[4];
-      unpackResult(ctx, f, reinterpret_cast<const uint16_t*>(w + e[5]), false, ri, false, 0, 0);
+      // (the path offset is a word the device wrote: never read past the job's host area)
+      const uint32_t pathWords = (static_cast<uint32_t>(std::max(f.n_states, 0)) + 1u) / 2u;
+      if (e[5] > outWords || pathWords > outWords - e[5]) {
+        f.status = mrp::ST_BAD;
+        f.n_states = 0;
+      }
+      unpackResult(ctx, f, reinterpret_cast<const uint16_t*>(w + (f.status == mrp::ST_BAD ? 0u : e[5])), false, ri, false, 0, 0);
     } else {
       ri.status = MRP_LL_NOT_RUN;
       ri.cost = ri.fmin = ri.n_states = 0;
@@ -1203,8 +1219,10 @@ int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t nObst
   m.dimx = dimx;
   m.dimy = dimy;
   m.wpr = (static_cast<uint32_t>(dimx * dimy) + 31u) / 32u;
-  // keep every bitmap 16-byte aligned
-  while (ctx->mapWords.size() & 3u) ctx->mapWords.push_back(0);
+  // Every bitmap starts on its own 128-byte line: a map uploaded while a resident kernel runs (below) must not share a
+  // cache line with an older one — the kernels read obstacle words with plain cached loads, and an XCD's L2 may still
+  // hold the line's previous contents (nothing invalidates it between jobs, ll_kernel.hip residentLoop).
+  while (ctx->mapWords.size() & 31u) ctx->mapWords.push_back(0);
   m.wordOff = static_cast<uint32_t>(ctx->mapWords.size());
   ctx->mapWords.resize(ctx->mapWords.size() + m.wpr, 0u);
   uint32_t* w = ctx->mapWords.data() + m.wordOff;
@@ -1245,7 +1263,7 @@ int mrp_ll_upload_heuristic(mrp_ll_ctx* ctx, int32_t mapId, const int32_t* dist,
     ctx->err = "mrp_ll_upload_heuristic: MRP_LL_ASTAR_TA serves maps up to 32 x 32";
     return MRP_LL_E_INVALID;
   }
-  while (ctx->mapWords.size() & 3u) ctx->mapWords.push_back(0);
+  while (ctx->mapWords.size() & 31u) ctx->mapWords.push_back(0);  // own 128-byte lines, as the bitmaps
   HeurRec h;
   h.mapId = mapId;
   h.wordOff = static_cast<uint32_t>(ctx->mapWords.size());
@@ -1456,6 +1474,7 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
   if (rc != MRP_LL_SUCCESS) return rc;
   P.out_host_stride = g.outStride;
   ctx->sessionRowWords = P.lds_row_words;
+  ctx->sessionLdsPathBytes = P.lds_paths_bytes;
   g.grid = static_cast<uint32_t>(workgroups > 0 ? std::min(workgroups, ctx->opt.slots) : ctx->opt.slots);
   HIPCHK(ctx, hipMemsetAsync(t.queueHead, 0, 256, t.stream));  // session tickets of both lanes count from 0
   HIPCHK(ctx, hipMemsetAsync(g.compCountDev, 0, 4, t.stream));
@@ -1680,7 +1699,7 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
     if (__atomic_load_n(g.done + slot, __ATOMIC_ACQUIRE) != st.seq[i]) continue;
     if (g.slotChain[slot])
       unpackChain(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2, st.res[i],
-                  g.slotChain[slot]);
+                  g.slotChain[slot], g.outStride / 2u);
     else
       unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
                    st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);
@@ -1724,7 +1743,7 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
     const int32_t i = g.slotJob[slot];
     if (g.slotChain[slot])
       unpackChain(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2, st.res[i],
-                  g.slotChain[slot]);
+                  g.slotChain[slot], g.outStride / 2u);
     else
       unpackResult(ctx, g.results[slot], g.outPaths + static_cast<size_t>(slot) * g.outStride, st.state[i] == 2,
                    st.res[i], g.sipp, g.sipp ? g.slotDimx[slot] : 0, g.slotInit[slot]);

@@ -18,6 +18,9 @@
 
 namespace oracle {
 namespace mapf {
+#ifdef ORACLE_SEARCH_STATS
+void searchStatsSink(const SearchStats& st);  // oracle_capi.cpp (diagnostic build)
+#endif
 
 inline void hashCombine(std::size_t& seed, std::size_t v) {  // boost::hash_combine formula
   seed ^= v + 0x9e3779b9 + (seed << 6) + (seed >> 2);
@@ -500,7 +503,15 @@ class ECBS {  // ecbs.hpp:103-423
     if (recorder) ctxCopy = context;
     LLEnv llenv(m_env, agent, c, context, m_lim);
     AStarEpsilon<State, Action, int, LLEnv, StateHash> ll(llenv, m_w);
+#ifdef ORACLE_SEARCH_STATS
+    SearchStats st;
+    g_stats = &st;
+#endif
     bool ok = ll.search(start, out);
+#ifdef ORACLE_SEARCH_STATS
+    g_stats = nullptr;
+    searchStatsSink(st);
+#endif
     if (recorder) recorder->push_back(LowLevelCall{agent, c, ctxCopy, ok, out, m_env.m_llExpandedThisSearch});
     return ok;
   }

@@ -539,4 +539,37 @@ int64_t oracle_ta_cbs_fixed(int dimx, int dimy, int nObst, const int32_t* obstXY
   return w;
 }
 
+#ifdef ORACLE_SEARCH_STATS
+// Diagnostic build (scripts/search_stats.py): one row of 13 counters per A*-epsilon search since the last call.
+int64_t oracle_search_stats_take(int64_t* out, int64_t capRows);
+#endif
 }  // extern "C"
+
+#ifdef ORACLE_SEARCH_STATS
+#include <mutex>
+namespace {
+std::mutex g_statMu;
+std::vector<oracle::SearchStats> g_statRows;
+}  // namespace
+namespace oracle {
+namespace mapf {
+void searchStatsSink(const SearchStats& st) {
+  std::lock_guard<std::mutex> lock(g_statMu);
+  g_statRows.push_back(st);
+}
+}  // namespace mapf
+}  // namespace oracle
+extern "C" int64_t oracle_search_stats_take(int64_t* out, int64_t capRows) {
+  std::lock_guard<std::mutex> lock(g_statMu);
+  const int64_t n = std::min<int64_t>(capRows, static_cast<int64_t>(g_statRows.size()));
+  for (int64_t k = 0; k < n; ++k) {
+    const oracle::SearchStats& s = g_statRows[k];
+    const long v[13] = {s.expansions, s.maxOpen, s.maxFocal, s.maxG, s.maxF, s.maxFocalH, s.walks, s.visited,
+                        s.walksEmpty, s.visitedEmpty, s.walksDistinct, s.visitedDistinct, s.bandNodes};
+    for (int q = 0; q < 13; ++q) out[k * 13 + q] = v[q];
+  }
+  const int64_t total = static_cast<int64_t>(g_statRows.size());
+  g_statRows.clear();
+  return total;
+}
+#endif

@@ -25,6 +25,21 @@
 
 namespace oracle {
 
+#ifdef ORACLE_SEARCH_STATS
+// Diagnostic build only (scripts/search_stats.py): what one AStarEpsilon::search did, for sizing the device tiers.
+struct SearchStats {
+  long expansions = 0, maxOpen = 0, maxFocal = 0, maxG = 0, maxF = 0, maxFocalH = 0;
+  long walks = 0, visited = 0;                 // ordered walks, nodes they visited
+  long walksEmpty = 0, visitedEmpty = 0;       // walks whose band (old * w, new * w] holds no open node
+  long walksDistinct = 0, visitedDistinct = 0; // non-empty band, all band nodes have pairwise distinct (f, g)
+  long bandNodes = 0;
+};
+inline thread_local SearchStats* g_stats = nullptr;
+#define ORACLE_STAT(x) do { if (g_stats) { x; } } while (0)
+#else
+#define ORACLE_STAT(x) do { } while (0)
+#endif
+
 template <typename State, typename Action, typename Cost>
 struct Neighbor {  // neighbor.hpp:14-25
   Neighbor(const State& s, const Action& a, Cost c) : state(s), action(a), cost(c) {}
@@ -198,18 +213,48 @@ class AStarEpsilon {
         Cost oldBestF = bestF;
         bestF = open.top().f;
         if (bestF > oldBestF) {
+#ifdef ORACLE_SEARCH_STATS
+          long vis = 0;
+          std::vector<std::pair<Cost, Cost>> band;
+#endif
           open.orderedWalk([&](OpenHandle h) {
             Cost val = open[h].f;
-            if (val > oldBestF * m_w && val <= bestF * m_w) focal.push(h);
+            ORACLE_STAT(vis += 1);
+            if (val > oldBestF * m_w && val <= bestF * m_w) {
+              focal.push(h);
+              ORACLE_STAT(band.push_back(std::make_pair(open[h].f, open[h].g)));
+            }
             if (val > bestF * m_w) return false;
             return true;
           });
+#ifdef ORACLE_SEARCH_STATS
+          if (g_stats) {
+            g_stats->walks += 1;
+            g_stats->visited += vis;
+            g_stats->bandNodes += static_cast<long>(band.size());
+            if (band.empty()) {
+              g_stats->walksEmpty += 1;
+              g_stats->visitedEmpty += vis;
+            } else {
+              std::sort(band.begin(), band.end());
+              bool distinct = true;
+              for (size_t q = 1; q < band.size(); ++q) distinct = distinct && band[q] != band[q - 1];
+              if (distinct) {
+                g_stats->walksDistinct += 1;
+                g_stats->visitedDistinct += vis;
+              }
+            }
+          }
+#endif
         }
       }
 
       OpenHandle curH = focal.top();
       OpenRec cur = open[curH];
       m_env.onExpandNode(cur.state, cur.f, cur.g);
+      ORACLE_STAT(g_stats->expansions += 1; g_stats->maxOpen = std::max<long>(g_stats->maxOpen, (long)open.size());
+                  g_stats->maxFocal = std::max<long>(g_stats->maxFocal, (long)focal.size());
+                  g_stats->maxG = std::max<long>(g_stats->maxG, (long)cur.g));
 
       if (m_env.isSolution(cur.state)) {
         out.states.clear();
@@ -244,6 +289,8 @@ class AStarEpsilon {
           Cost fh2 = cur.focalH + m_env.focalStateHeuristic(nb.state, g2) +
                      m_env.focalTransitionHeuristic(cur.state, nb.state, cur.g, g2);
           OpenHandle h = open.push(OpenRec{nb.state, f2, g2, fh2});
+          ORACLE_STAT(g_stats->maxF = std::max<long>(g_stats->maxF, (long)f2);
+                      g_stats->maxFocalH = std::max<long>(g_stats->maxFocalH, (long)fh2));
           if (f2 <= bestF * m_w) focal.push(h);
           inOpen.emplace(nb.state, h);
           m_env.onDiscover(nb.state, f2, g2);

@@ -15,17 +15,22 @@ I32P = ctypes.POINTER(ctypes.c_int32)
 I64P = ctypes.POINTER(ctypes.c_int64)
 
 
-def _emu_lib():
+def _emu_lib(force_walk=False):
     build = os.path.join(ROOT, "tests", "_build")
     os.makedirs(build, exist_ok=True)
     groups = os.environ.get("MRP_CT_GROUPS")  # experiments with larger open lists (the product builds the default)
-    lib = os.path.join(build, "libemu_ll%s.so" % ("_g" + groups if groups else ""))
+    sanitize = bool(os.environ.get("MRP_EMU_SANITIZE"))
+    # the build flavour is part of the file name: a sanitizer build left behind can never be picked up by a plain run
+    # (dlopen of an ASan library into a plain interpreter ends the process without a report)
+    lib = os.path.join(build, "libemu_ll%s%s%s.so" % ("_g" + groups if groups else "", "_san" if sanitize else "",
+                                                      "_fw" if force_walk else ""))
     deps = [os.path.join(ROOT, "tests", "support", "emu_ll.cpp"), os.path.join(ROOT, "tests", "support", "wave_emu.h"),
             os.path.join(ROOT, "libmultirobotplanning_amd", "csrc", "ll_compact.h")]
     if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
-        san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if os.environ.get("MRP_EMU_SANITIZE") else []
+        san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if sanitize else []
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"] + san +
-                              (["-DMRP_CT_GROUPS=" + groups] if groups else []) + ["-o", lib, deps[0]])
+                              (["-DMRP_CT_GROUPS=" + groups] if groups else []) +
+                              (["-DMRP_CT_FORCE_WALK"] if force_walk else []) + ["-o", lib, deps[0]])
     L = ctypes.CDLL(lib)
     L.emu_compact_search.restype = ctypes.c_int
     L.emu_compact_search.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_int, ctypes.c_int,
@@ -97,6 +102,25 @@ def test_ecbs_agents10_all_searches(emu, oracle_mod, bench_instances):
         done += d
         over += o
     assert done > 200 and over < done // 3, (done, over)
+
+
+def test_skipping_walks_with_an_empty_band_is_unobservable(oracle_mod, bench_instances):
+    """a_star_epsilon.hpp:141-152: the ordered walk only pushes the open nodes of the band old * w < f <= new * w into the
+    focal list; the tier skips it when no open node is in the band.  Same searches through a build that always walks
+    (-DMRP_CT_FORCE_WALK): every output word equal."""
+    skip, walk = _emu_lib(), _emu_lib(force_walk=True)
+    n = 0
+    for bg in (False, True):
+        skip._bg = walk._bg = bg
+        for name in ["map_32by32_obst204_agents10_ex%d" % k for k in (1, 5, 9, 13)] + ["map_32by32_obst204_agents50_ex3"]:
+            inst = bench_instances[name]
+            _, calls = oracle_mod.mapf_record(oracle_mod.ECBS, inst, w=1.3)
+            for c in calls:
+                args = (True, inst, c["agent"], inst["starts"][c["agent"]], inst["goals"][c["agent"]],
+                        c["vertex_constraints"], c["edge_constraints"], c["ctx_paths"], 1.3)
+                assert emu_search(skip, *args) == emu_search(walk, *args), (name, c["agent"])
+                n += 1
+    assert n >= 200
 
 
 def test_ecbs_denser_instances_tables_in_lds_and_in_memory(emu, oracle_mod, bench_instances):

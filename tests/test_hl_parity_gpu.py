@@ -220,6 +220,23 @@ def test_root_chains_change_nothing_but_the_number_of_jobs(solver, oracle_mod, b
             hl.SOLVED, o["cost"], o["hl_expanded"], o["ll_expanded"])
 
 
+def test_ecbs_without_the_compact_tier(oracle_mod, bench_instances):
+    """mrp_ll_options.lds_nodes < 0 switches the compact tier off; results never depend on it (mrp_ll.h).  The engine then
+    cannot run root chains either: it rejects the first one and the driver goes on with one job per root search."""
+    from libmultirobotplanning_amd import hl
+    insts = [bench_instances["map_32by32_obst204_agents10_ex%d" % k] for k in range(6)]
+    insts += [hl.generate_instance(1000 * 10 + 77000 + k, 32, 32, 204, 10) for k in range(60)]
+    s = hl.BatchSolver(device=0, n_threads=2, slots=128, lds_nodes=-1)
+    try:
+        res, st = s.solve(insts, algo=hl.ECBS, w=1.3, max_ll_expansions=200000)
+    finally:
+        s.close()
+    for inst, r in zip(insts, res):
+        o = oracle_mod.mapf_solve(oracle_mod.ECBS, inst, w=1.3, cap_total=200000)
+        assert o["rc"] == 1 and (r["status"], r["cost"], r["hl_expanded"], r["ll_expanded"]) == (
+            hl.SOLVED, o["cost"], o["hl_expanded"], o["ll_expanded"])
+
+
 def test_opt_in_memory_placements_give_the_same_results(oracle_mod, ref_tests):
     """MRP_LL_RING_IN_DEVICE=1 (the host-to-device half of the job ring in uncached device memory, written through the BAR)
     and MRP_LL_SIPP_TABLES_UNCACHED=1 (SIPP tables in uncached device memory, no fences around their use): off by

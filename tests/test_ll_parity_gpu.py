@@ -267,6 +267,28 @@ def test_session_mode_matches_oracle(oracle_mod, bench_instances):
         eng.close()
 
 
+def test_small_maps_uploaded_during_a_session(oracle_mod, bench_instances):
+    """Maps smaller than a cache line uploaded while the resident kernel runs, each right after its predecessor has been
+    searched: every bitmap has its own 128-byte line in the device buffer, so no XCD's L2 can serve a stale copy of the
+    line a new map lands in (the kernels read obstacle words with plain cached loads)."""
+    from libmultirobotplanning_amd import ll
+    names = ["map_8by8_obst12_agents5_ex%d" % k for k in range(6)] + ["map_8by8_obst12_agents8_ex%d" % k for k in range(4)]
+    eng = ll.LowLevelEngine(device=0, n_tickets=1, slots=256)
+    try:
+        first = bench_instances[names[0]]
+        map_ids = {names[0]: eng.upload_map(first["dimx"], first["dimy"], first["obstacles"])}
+        per_map = {name: _harvest(oracle_mod, bench_instances, [name], oracle_mod.ECBS, 1.3, 100000) for name in names}
+        eng.session_begin(128)
+        try:
+            for rep in range(3):  # the searches of a map run on many workgroups (every XCD reads its line) before the next upload
+                for name in names:
+                    _run_and_compare(eng, per_map[name] * 8, ll.ASTAR_EPS, 1.3, map_ids)
+        finally:
+            eng.session_end()
+    finally:
+        eng.close()
+
+
 def test_edge_cases(engine, oracle_mod):
     from libmultirobotplanning_amd import ll
     open_map = dict(dimx=4, dimy=3, obstacles=[])
