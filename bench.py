@@ -41,10 +41,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# One HIP stream per host worker thread: give each its own hardware queue (the ROCm default of 4 makes streams that
-# share a queue serialise their kernels — fatal for resident kernels, which only end when their host thread is done;
-# 24 > 16 worker streams + torch's own).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# Every host worker thread keeps up to two resident kernels (front + heavy workgroups) on streams of their own, and each
+# needs its own hardware queue (the ROCm default of 4 makes streams share queues and serialise their kernels — fatal for
+# resident kernels, which only end when their host thread is done; measured on this box, scripts/micro/hw_queues.hip: 64
+# streams hold 64 resident kernels at once with GPU_MAX_HW_QUEUES=64).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "64")
 
 ALGO_BYTES_PER_EXPANSION = 128
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s

@@ -160,6 +160,9 @@ typedef struct mrp_ll_job {
  * submit as ordinary jobs (or as another chain).  The job's own n_states = results filled in, expanded = their sum.
  * Every filled-in result is exactly what the ordinary job for that agent would have returned. */
 #define MRP_LL_JOB_ROOT_CHAIN 4
+/* MRP_LL_JOB_HEAVY (hint, MRP_LL_ASTAR_EPS): the caller knows that this search outgrows the LDS tier every search starts in
+ * (e.g. a root chain ended in front of it): no attempt is made there.  Results never depend on it. */
+#define MRP_LL_JOB_HEAVY 8
 #define MRP_LL_JOB_NO_GOAL 2      /* mrp_ll_job.flags, MRP_LL_ASTAR_TA: the agent has no task (cbs_ta.cpp:283-319: h = 0, every
                                    * cell ends the search once time > the agent's last vertex constraint, every Wait is free) */
 
@@ -172,7 +175,7 @@ typedef struct mrp_ll_result {
   int32_t* states_txy; /* caller buffer [states_cap][3] = time, x, y ; may be NULL                            */
   int32_t* actions;    /* caller buffer [states_cap]    = MRP_LL_ACT_* ; may be NULL                          */
   int32_t states_cap;
-  int32_t tier;     /* 0 = finished in the LDS tier, 1 = run by the arena tier (diagnostic)                    */
+  int32_t tier;     /* 0 = finished in the LDS tier, 1 = run by the arena tier, 2 = by a heavy workgroup's wide LDS tier (diagnostic) */
   int32_t* action_costs; /* caller buffer [states_cap] or NULL: PlanResult::actions[k].second (always 1 for
                           * MRP_LL_ASTAR / _EPS; 0 for a Wait at the goal with MRP_LL_ASTAR_TA; Wait durations for
                           * MRP_LL_SIPP, sipp.hpp:105-128)                                                     */
@@ -194,6 +197,9 @@ typedef struct mrp_ll_stats {
                              /* to pinned host memory for the device to read over PCIe                                    */
   int64_t prof[8];           /* diagnostic (-DMRP_LL_TRACE library only, else 0): shader cycles in walk, pops,  */
                              /* pushes, successor generation, row init, whole job; #walks; nodes visited by walks */
+  double heavy_busy_ms, heavy_idle_ms;     /* mrp_ll_session_begin_tiers: the same two sums over the heavy workgroups    */
+  int64_t heavy_active_wgs;                /* ... and how many of them ran at least one search                           */
+  int64_t heavy_fallbacks;                 /* sessions that fell back to a single launch (no heavy workgroup became resident) */
 } mrp_ll_stats;
 
 int mrp_ll_create(const mrp_ll_options* opt, mrp_ll_ctx** out);
@@ -281,6 +287,26 @@ int mrp_ll_session_begin_sipp(mrp_ll_ctx* ctx, int32_t workgroups);
  * specialised for it — half the code and fewer registers than the mixed kernel of mrp_ll_session_begin, same results;
  * jobs of another algorithm come back as MRP_LL_BAD_JOB.  What the conflict-tree drivers use. */
 int mrp_ll_session_begin_algo(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups);
+/* An MRP_LL_ASTAR_EPS session as a PAIR of resident launches: `workgroups` front workgroups that run every search in the
+ * LDS tier (1023 open entries, 64 time steps) and nothing else, and `heavy_workgroups` heavy ones with a 41.6 KB window
+ * (4095 open entries, 128 time steps; the arena tier behind it) that take over — through a device-side queue, without the
+ * host — the searches that outgrow it.  Same jobs, same results as mrp_ll_session_begin_algo; the split keeps the long
+ * searches out of the many small windows and gives them an LDS-resident tier of their own.
+ * workgroups + heavy_workgroups <= mrp_ll_options.slots (each needs an arena slot).  If the heavy workgroups do not become
+ * resident (no room left on the device), the call falls back to mrp_ll_session_begin_algo's single launch.
+ * heavy_workgroups = 0 is that call. */
+int mrp_ll_session_begin_tiers(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups, int32_t heavy_workgroups);
+/* The same for SEVERAL contexts that begin their sessions on one device at the same time (one per host thread): a heavy
+ * workgroup needs 41.6 KB of one CU's LDS in one piece, which no CU has left once the front workgroups of another context
+ * have spread over the device.  Every caller passes the same `gate` (zero before the first call) and `parties` (the number
+ * of callers): each launches its heavy workgroups, waits until they run, arrives at the gate, and launches its front
+ * workgroups only when all parties have arrived (or 2 s have passed).  gate == NULL: no waiting. */
+int mrp_ll_session_begin_tiers_gated(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups, int32_t heavy_workgroups,
+                                     int32_t* gate, int32_t parties);
+/* Resident workgroups per CU of such a session's front kernel with the current tier limits, and the LDS bytes one heavy
+ * workgroup takes: a caller sizes the pair with 256 CUs x (160 KiB - its share of heavy windows) / front window. */
+int mrp_ll_session_tiers_geometry(mrp_ll_ctx* ctx, int32_t* front_occupancy_out, int32_t* front_lds_bytes_out,
+                                  int32_t* heavy_lds_bytes_out);
 int mrp_ll_session_end(mrp_ll_ctx* ctx);
 /* Session mode: the same as mrp_ll_submit.  There is one device queue and it is first in, first out; which search
  * starts next is decided by the ORDER in which the caller publishes — keep the queue shallow (about two searches per

@@ -11,7 +11,7 @@ The product path never imports ``oracle`` and has no CPU fallback.
 import os as _os
 
 # one hardware queue per host worker stream (ROCm default: 4); only effective if set before HIP initialises
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "64")
 
 from . import _build  # noqa: F401,E402
 

@@ -286,7 +286,8 @@ void pinWorker(int32_t t) {
 void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_instance* instIn, mrp_hl_solution* sols,
                      const std::vector<int32_t>& idx, const std::vector<int32_t>& mapIds, int32_t horizon,
                      int32_t workgroups, int32_t pathSlots, GroupResult& out, std::atomic<int32_t>* shared = nullptr,
-                     int32_t nTotal = 0, int32_t mapBase = 0, int32_t nWorkersIn = 1) {
+                     int32_t nTotal = 0, int32_t mapBase = 0, int32_t nWorkersIn = 1, int32_t heavyWgs = 0,
+                     int32_t* gate = nullptr) {
   const size_t nWorkers = static_cast<size_t>(std::max(nWorkersIn, 1));
   const size_t n = shared ? static_cast<size_t>(nTotal) : idx.size();
   struct Live {
@@ -340,8 +341,11 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   const bool timing = std::getenv("MRP_HL_TIMING") != nullptr;
   const int32_t specK = specWidthSetting();
   auto tg0 = std::chrono::steady_clock::now();
-  if (mrp_ll_session_begin_algo(ctx, opt.algo == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR, workgroups) != MRP_LL_SUCCESS) {
-    out.err = std::string("mrp_ll_session_begin_algo: ") + mrp_ll_last_error(ctx);
+  // ECBS: front workgroups (the LDS tier alone) + heavy workgroups that take over the searches that outgrow it; all
+  // workers' heavy launches go first (the gate), then the front ones (mrp_ll.h mrp_ll_session_begin_tiers_gated)
+  if (mrp_ll_session_begin_tiers_gated(ctx, opt.algo == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR, workgroups,
+                                       opt.algo == MRP_HL_ECBS ? heavyWgs : 0, gate, nWorkersIn) != MRP_LL_SUCCESS) {
+    out.err = std::string("mrp_ll_session_begin_tiers: ") + mrp_ll_last_error(ctx);
     return;
   }
   size_t ticketsOut = 0;
@@ -449,6 +453,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       idOff.push_back(idPool.size());
       bool ok = false;
       fillJob(I, L.req[end], j, pathLenPool, pathPtrPool, pathSlots > 0 ? &idPool : nullptr, &ok);
+      // a root search that ended a chain outgrows the LDS tier: no second attempt there
+      if (group == kRootGroup && L.req[end].agent == L.noChainAgent) j.flags |= MRP_LL_JOB_HEAVY;
       idOk.push_back(ok ? 1 : 0);
       jobs.push_back(j);
       ++end;
@@ -795,9 +801,11 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     mrp_ll_stats ls;
     mrp_ll_get_stats(ctx, &ls);
     std::fprintf(stderr, "[mrp_hl] group of %zu: session_begin %.2f ms, build instances %.2f ms, loop %.2f ms, session_end %.2f ms; "
-                 "cumulative: active wgs %lld, busy %.0f ms, idle %.0f ms, searches %lld, expansions %lld\n", live.size(),
+                 "cumulative: active wgs %lld, busy %.0f ms, idle %.0f ms, heavy wgs %lld busy %.0f ms idle %.0f ms, searches %lld, "
+                 "expansions %lld\n", live.size(),
                  ms(tg0, tg1), ms(tg1, tg2), ms(tg2, tg3), ms(tg3, tg4), (long long)ls.session_active_wgs,
-                 ls.session_busy_ms, ls.session_idle_ms, (long long)ls.jobs, (long long)ls.expansions);
+                 ls.session_busy_ms, ls.session_idle_ms, (long long)ls.heavy_active_wgs, ls.heavy_busy_ms, ls.heavy_idle_ms,
+                 (long long)ls.jobs, (long long)ls.expansions);
     std::fprintf(stderr, "[mrp_hl]   host ms: admit+submit %.1f, poll empty %.1f (%llu), poll hit %.1f (%llu), "
                  "unpack %.1f, advance %.1f; tickets %lld searches %lld\n", tmSubmit * 1e3, tmPollEmpty * 1e3,
                  (unsigned long long)nPollEmpty, tmPollHit * 1e3, (unsigned long long)nPollHit, tmUnpack * 1e3,
@@ -845,7 +853,7 @@ int mrp_hl_solver_create(int32_t device, int32_t nThreads, const mrp_ll_options*
   }
   // One HIP stream (= one resident kernel) per worker: each needs its own hardware queue, the ROCm default is 4.  Only
   // effective if the HIP runtime has not been initialised yet in this process; never overrides the caller.
-  (void)setenv("GPU_MAX_HW_QUEUES", "24", 0);
+  (void)setenv("GPU_MAX_HW_QUEUES", "64", 0);
   auto* s = new mrp_hl_solver();
   s->device = device;
   std::memset(&s->llOpt, 0, sizeof(s->llOpt));
@@ -900,6 +908,10 @@ int mrp_hl_solver_ll_stats(mrp_hl_solver* s, mrp_ll_stats* out, int32_t reset) {
     out->session_idle_ms += st.session_idle_ms;
     out->session_active_wgs += st.session_active_wgs;
     out->unpack_ms += st.unpack_ms;
+    out->heavy_busy_ms += st.heavy_busy_ms;
+    out->heavy_idle_ms += st.heavy_idle_ms;
+    out->heavy_active_wgs += st.heavy_active_wgs;
+    out->heavy_fallbacks += st.heavy_fallbacks;
     for (int q = 0; q < 8; ++q) out->prof[q] += st.prof[q];
     if (reset) mrp_ll_reset_stats(e);
   }
@@ -1019,6 +1031,29 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   }
   // resident wavefronts per engine: the chip holds 256 CUs x `occupancy` workgroups of this kernel at once
   int32_t sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, (256 * occupancy) / nThreads));
+  // ECBS: some of the device's LDS goes to heavy workgroups (wide LDS tier + arena tier: the searches that outgrow the
+  // front tier — 6 % of the expansions at ten agents, 17 % at a hundred, scripts/search_stats.py).  One takes the LDS of
+  // `displaced` front workgroups; about a quarter / half / three quarters of the CUs get one.
+  int32_t heavyPer = 0;
+  if (opt.algo == MRP_HL_ECBS && opt.mode != 1 && !s->engines.empty() && s->llOpt.lds_nodes >= 0) {
+    int32_t frontOcc = 0, frontLds = 0, heavyLds = 0;
+    if (mrp_ll_session_tiers_geometry(s->engines[0], &frontOcc, &frontLds, &heavyLds) == MRP_LL_SUCCESS && frontOcc > 0 &&
+        frontLds > 0) {
+      int32_t heavyTotal = maxAgents <= 16 ? 64 : maxAgents <= 64 ? 128 : 192;
+      if (const char* e = std::getenv("MRP_HL_HEAVY_WGS")) heavyTotal = std::max(0, std::atoi(e));  // tuning knob (0: one launch)
+      heavyPer = heavyTotal / nThreads + (heavyTotal % nThreads ? 1 : 0);
+      if (heavyPer > 0) {
+        const int32_t granule = 512;  // LDS allocation granularity
+        const int32_t fl = (frontLds + granule - 1) / granule * granule, hl = (heavyLds + granule - 1) / granule * granule;
+        const int32_t cuLds = 160 * 1024;
+        const int32_t frontBeside = std::max(0, (cuLds - hl) / fl);          // front workgroups on a CU that hosts a heavy one
+        const int32_t displaced = std::max(0, std::min(frontOcc, cuLds / fl) - frontBeside);
+        const int32_t frontTotal = 256 * std::min(frontOcc, cuLds / fl) - displaced * heavyPer * nThreads;
+        sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots - heavyPer, frontTotal / nThreads));
+        if (sessionWgs + heavyPer > s->llOpt.slots || frontTotal <= 0) heavyPer = 0;  // (tiny engines: one launch serves all)
+      }
+    }
+  }
   if (const char* e = std::getenv("MRP_HL_SESSION_WGS")) sessionWgs = std::max(1, std::atoi(e));  // tuning knob
   // f2: the engines' device-resident path stores (ECBS only: CBS's low level has no focal context).  A search leaves its
   // path there, and later jobs name the paths of their CT node by slot instead of shipping a [t][agent] table.
@@ -1045,6 +1080,7 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   }
   // one pool of instances for all workers (MRP_HL_STATIC_SPLIT=1 restores the fixed interleaved split)
   std::atomic<int32_t> nextInstance(0);
+  int32_t sessionGate = 0;  // mrp_ll_session_begin_tiers_gated: every worker's heavy launch before anybody's front launch
   const bool sharedPool = std::getenv("MRP_HL_STATIC_SPLIT") == nullptr;
   auto t0 = std::chrono::steady_clock::now();
   batchEpoch() = t0;
@@ -1057,10 +1093,10 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
           runGroup(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, gr[t]);
         else if (sharedPool)
           runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, pathSlots,
-                          gr[t], &nextInstance, nInst, pre->mapBase[t], nThreads);
+                          gr[t], &nextInstance, nInst, pre->mapBase[t], nThreads, heavyPer, &sessionGate);
         else
           runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, pathSlots,
-                          gr[t]);
+                          gr[t], nullptr, 0, 0, nThreads, heavyPer, &sessionGate);
       });
     for (auto& x : th) x.join();
   }

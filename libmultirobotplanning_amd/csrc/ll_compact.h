@@ -42,46 +42,76 @@ using namespace wv;
 // ---- LDS window of one search (byte offsets) ------------------------------------------------------------------
 // A heap area: element i at byte 4 * (i + 1), so that the children (2i + 1, 2i + 2) of any node are one aligned 8-byte
 // pair and lane L's 16-byte group of 256-entry group g holds elements 256 g + 4L - 1 .. 256 g + 4L + 2.
-constexpr uint32_t kGroups = 4;                   // 256-entry groups of the open / focal arrays (one scan instruction each)
-constexpr uint32_t kCap = 256u * kGroups - 1u;    // entries of the open / focal list
-constexpr uint32_t kHeapBytes = 1024u * kGroups + 16u;
-constexpr uint32_t kHeapClamp = kCap + 2u;        // odd; elements kCap .. kCap + 3 exist and always hold kEmpty
-constexpr uint32_t kAuxCap = 128u * kGroups + 2u; // walk queue of the ordered walk: at most (n + 1) / 2 + 1 entries
-constexpr uint32_t kAuxBytes = 512u * kGroups + 32u;
-constexpr uint32_t kAuxClamp = kAuxCap + 1u;      // odd; elements kAuxCap .. kAuxCap + 4 always hold kEmpty
-constexpr uint32_t kRows = 64, kRowBytes = 128;   // (time, cell) bitmap: 32 words (one per y) of 32 bits (x) per time step
+//
+// Two geometries of the same program (template parameter C of compactSearch):
+//   Narrow — the tier every search starts in: 1023 open entries, t <= 61, 12.9 KB of LDS with ten agents (12 searches per CU);
+//            entry  [31:23] 511 - focalH   [22:16] 127 - f   [15:10] g   [9:0] cell
+//   Wide   — the tier of the searches that outgrow it (the "heavy" resident workgroups, ll_kernel.hip): 4095 open entries,
+//            t <= 125, 41.6 KB;  entry  [31:25] 127 - focalH   [24:17] 255 - f   [16:10] g   [9:0] cell
+constexpr uint32_t kRowBytes = 128;               // (time, cell) bitmap: 32 words (one per y) of 32 bits (x) per time step
 constexpr uint32_t oCtl = 0;                      // 256 bytes for the kernel that hosts the tier (job descriptor, result)
 constexpr uint32_t oJob = 256;                    // CJob
 constexpr uint32_t oRes = 384;                    // CRes (+ eight profile words in the diagnostic build)
 constexpr uint32_t oOpen = 448;
-constexpr uint32_t oFocal = oOpen + kHeapBytes;
-constexpr uint32_t oAux = oFocal + kHeapBytes;
-constexpr uint32_t oBits = oAux + kAuxBytes;
-constexpr uint32_t oObst = oBits + kRows * kRowBytes;
-constexpr uint32_t oPaths = oObst + kRowBytes;    // the focal path table follows (size chosen by the launcher)
-constexpr uint32_t kLdsBytes = oPaths;
-// BG ("bitmap in global memory", the A*-epsilon-only kernels): the (time, cell) bitmap lives in the search's arena slot
-// (CJob::bitsG) instead of the window, which then ends right behind the walk queue: obstacle row, path table.  8 KB less
-// LDS per search = 12 instead of 7 searches per CU at ten agents.
-constexpr uint32_t obstOff(bool bg) { return bg ? oBits : oObst; }
-constexpr uint32_t pathsOff(bool bg) { return obstOff(bg) + kRowBytes; }
-constexpr uint32_t windowBytes(bool bg) { return pathsOff(bg); }
-constexpr uint32_t kBitsBytes = kRows * kRowBytes;
-static_assert(oFocal == oOpen + kHeapBytes && 2u * kHeapBytes >= kBitsBytes,
-              "BG builds the bitmap in the (not yet initialised) open + focal areas before it copies it out");
-static_assert(oOpen % 16 == 0 && oFocal % 16 == 0 && oAux % 16 == 0 && oBits % 16 == 0 && oObst % 16 == 0 && oPaths % 16 == 0,
-              "LDS areas are 16-byte aligned");
-static_assert((kHeapClamp & 1u) == 1u && 4u * (kHeapClamp + 3u) <= kHeapBytes, "clamped child pair stays inside the heap area");
-static_assert((kAuxClamp & 1u) == 1u && 4u * (kAuxClamp + 3u) <= kAuxBytes, "clamped child pair stays inside the walk queue");
-static_assert(kGroups >= 1 && kGroups <= 4, "the walk queue keeps an open index in the ten bits below the key");
-
-constexpr uint32_t kMO = 0x007FFC00u;             // open key:  f, g
-constexpr uint32_t kMF = 0xFFFFFC00u;             // focal key: focalH, f, g
-constexpr uint32_t kEmpty = 0x0000FFFFu;          // "no element": its key is below every real key (f <= 124 in this tier) and
-                                                  // its low half never names a state (g = 63 is never pushed: kMaxT)
 constexpr uint32_t kFront = 0xFFFFFFFFu;          // the word in front of element 0: above every key, names no state
-constexpr uint32_t kMaxT = 61;                    // the last time step whose nodes are expanded here (successors: g <= 62)
-constexpr uint32_t kParentBytes = kRows * 1024;   // cameFrom table in the arena slot
+template <uint32_t GROUPS, uint32_t FH_BITS, uint32_t F_BITS, uint32_t G_BITS>
+struct TierCfg {
+  static constexpr uint32_t kGroups = GROUPS;                  // 256-entry groups of the open / focal arrays (one scan instruction each)
+  static constexpr uint32_t kCap = 256u * GROUPS - 1u;         // entries of the open / focal list
+  static constexpr uint32_t kHeapBytes = 1024u * GROUPS + 16u;
+  static constexpr uint32_t kHeapClamp = kCap + 2u;            // odd; elements kCap .. kCap + 3 exist and always hold kEmpty
+  static constexpr uint32_t kAuxCap = 128u * GROUPS + 2u;      // walk queue of the ordered walk: at most (n + 1) / 2 + 1 entries
+  static constexpr uint32_t kAuxBytes = 512u * GROUPS + 32u;
+  static constexpr uint32_t kAuxClamp = kAuxCap + 1u;          // odd; elements kAuxCap .. kAuxCap + 4 always hold kEmpty
+  static constexpr uint32_t kRows = 1u << G_BITS;              // time steps of the (time, cell) bitmap and of the cameFrom table
+  static constexpr uint32_t kFShift = 10u + G_BITS, kFhShift = 10u + G_BITS + F_BITS;
+  static constexpr uint32_t kGMax = (1u << G_BITS) - 1u, kFMax = (1u << F_BITS) - 1u, kFhMax = (1u << FH_BITS) - 1u;
+  static constexpr uint32_t kMO = ((1u << (F_BITS + G_BITS)) - 1u) << 10;  // open key:  f, g
+  static constexpr uint32_t kMF = 0xFFFFFC00u;                             // focal key: focalH, f, g
+  static constexpr uint32_t kStateMask = (1u << kFShift) - 1u;             // g (== time), cell: what names a state
+  // "no element": its key is below every real key (f <= kFMax - 3 in a tier) and its state bits never name a state
+  // (g = kGMax is never pushed: kMaxT)
+  static constexpr uint32_t kEmpty = kStateMask;
+  static constexpr uint32_t kMaxT = kGMax - 2u;                // the last time step whose nodes are expanded here
+  // walk-queue entries: the open key of an element above its index in the open array (10 bits, 12 beyond 1023 entries)
+  static constexpr uint32_t kAuxShift = GROUPS > 4u ? 2u : 0u;
+  static constexpr uint32_t kAuxIdxMask = (1u << (10u + kAuxShift)) - 1u;
+  static constexpr uint32_t kMOAux = kMO << kAuxShift;
+  static constexpr bool kExactFhCheck = FH_BITS < 9u;          // Narrow: two conflicts per agent always fit or the job leaves first
+  static constexpr uint32_t oFocal = oOpen + kHeapBytes;
+  static constexpr uint32_t oAux = oFocal + kHeapBytes;
+  static constexpr uint32_t oBits = oAux + kAuxBytes;
+  static constexpr uint32_t oObst = oBits + kRows * kRowBytes;
+  static constexpr uint32_t oPaths = oObst + kRowBytes;        // the focal path table follows (size chosen by the launcher)
+  static constexpr uint32_t kBitsBytes = kRows * kRowBytes;
+  static constexpr uint32_t kParentBytes = kRows * 1024u;      // cameFrom table in the arena slot
+  // BG ("bitmap in global memory", the A*-epsilon-only kernels): the (time, cell) bitmap lives in the search's arena slot
+  // (CJob::bitsG) instead of the window, which then ends right behind the walk queue: obstacle row, path table.
+  static constexpr uint32_t obstOff(bool bg) { return bg ? oBits : oObst; }
+  static constexpr uint32_t pathsOff(bool bg) { return obstOff(bg) + kRowBytes; }
+  static constexpr uint32_t windowBytes(bool bg) { return pathsOff(bg); }
+  static_assert(kFhShift + FH_BITS == 32u, "an entry is 32 bits");
+  static_assert(2u * kHeapBytes >= kBitsBytes, "BG builds the bitmap in the (not yet initialised) open + focal areas");
+  static_assert(oFocal % 16 == 0 && oAux % 16 == 0 && oBits % 16 == 0 && oObst % 16 == 0 && oPaths % 16 == 0, "16-byte aligned areas");
+  static_assert((kHeapClamp & 1u) == 1u && 4u * (kHeapClamp + 3u) <= kHeapBytes, "clamped child pair stays inside the heap area");
+  static_assert((kAuxClamp & 1u) == 1u && 4u * (kAuxClamp + 3u) <= kAuxBytes, "clamped child pair stays inside the walk queue");
+  static_assert(256u * GROUPS <= kAuxIdxMask + 1u && 10u + F_BITS + G_BITS + kAuxShift <= 32u, "walk-queue entry: key above index");
+  static_assert(kMaxT + 1u + 62u <= kFMax - 3u, "f = g + h (h <= 62 on a 32 x 32 map) fits its field");
+};
+typedef TierCfg<4, 9, 7, 6> Narrow;
+typedef TierCfg<16, 7, 8, 7> Wide;
+// (names the hosting kernels and the host tests use: the narrow geometry)
+constexpr uint32_t kGroups = Narrow::kGroups, kCap = Narrow::kCap, kHeapBytes = Narrow::kHeapBytes, kAuxBytes = Narrow::kAuxBytes;
+constexpr uint32_t kRows = Narrow::kRows;
+constexpr uint32_t oFocal = Narrow::oFocal, oAux = Narrow::oAux, oBits = Narrow::oBits, oObst = Narrow::oObst, oPaths = Narrow::oPaths;
+constexpr uint32_t kLdsBytes = oPaths;
+constexpr uint32_t obstOff(bool bg) { return Narrow::obstOff(bg); }
+constexpr uint32_t pathsOff(bool bg) { return Narrow::pathsOff(bg); }
+constexpr uint32_t windowBytes(bool bg) { return Narrow::windowBytes(bg); }
+constexpr uint32_t kBitsBytes = Narrow::kBitsBytes, kParentBytes = Narrow::kParentBytes;
+constexpr uint32_t kMO = Narrow::kMO, kMF = Narrow::kMF, kEmpty = Narrow::kEmpty, kMaxT = Narrow::kMaxT;
+constexpr uint32_t kHeapClamp = Narrow::kHeapClamp;
+static_assert(oOpen % 16 == 0, "LDS areas are 16-byte aligned");
 
 enum : int32_t { C_OK = 0, C_NO_SOLUTION = 1, C_CAP_EXP = 2, C_OVERFLOW = -1 };
 
@@ -170,27 +200,25 @@ WV_FN Sides makeSides() {
 WV_FN V bothSides(const Sides& S, uint32_t a, uint32_t b) { return sel(S.isB, splat(b), splat(a)); }  // side A: a, side B: b
 
 // Sift-downs of two heaps at once, five levels per LDS round trip.  Each side moves a hole, starting at its root, down
-// its heap (element 0 at byte address hb, keys under mask km, child pairs clamped to element cMax):
-//   STL = false (boost siftdown): prefer the FIRST maximal child; stop in front of a child that is less than x (key xk);
-//   STL = true  (libstdc++ __adjust_heap): prefer the right child unless it is less than the left one; descend to a leaf.
+// its heap (element 0 at byte address hb, keys under mask km, child pairs clamped to element cMax) as boost's siftdown
+// does: prefer the FIRST maximal child; stop in front of a child that is less than x (key xk).
 // Which child is the larger one does not depend on the element being sifted, so a lane decides from two ballots whether
 // its node is on the path (every ancestor let the hole pass and turned towards it), and the nodes on the path pull their
-// chosen child up in one store.  Slots past a heap's end hold kEmpty: the hole stops by itself at a leaf, and a side with
-// nothing (left) to do repeats a block in which nothing moves.  Returns the holes (per lane: the hole of the lane's side).
-template <bool STL>
+// chosen child up in one store.  Slots past a heap's end hold "no element" (a key below every real key): the hole stops
+// by itself at a leaf, and a side with nothing (left) to do repeats a block in which nothing moves.  Returns the holes
+// (per lane: the hole of the lane's side).
 WV_FN V dualDescend(Lds lds, const Sides& S, V hb, V km, V cMax, V xk) {
   V idx = splat(0u);
-  const V tiny = km & kEmpty;
   for (;;) {
     const V node = ((idx + 1u) << S.lvl) + S.off1;
     V c = node * 2u + 1u;
     c = sel(c < cMax, c, cMax);
     const V2 pr = ldsLoad64(lds, hb + c * 4u);          // children (c, c + 1): one aligned pair
     const V kl = pr.x & km, kr = pr.y & km;
-    const B right = STL ? (kr >= kl) : (kl < kr);
+    const B right = kl < kr;
     const V pe = sel(right, pr.y, pr.x);
     const V pk = sel(right, kr, kl);
-    const B go = STL ? (kl > tiny) : (pk >= xk);        // the hole moves below this node (a missing child: key `tiny`)
+    const B go = pk >= xk;                              // the hole moves below this node
     const uint64_t goM = ballot(go), rM = ballot(right);
     const V g32 = bothSides(S, lo32(goM), hi32(goM));
     const V r32 = bothSides(S, lo32(rM), hi32(rM));
@@ -288,9 +316,15 @@ WV_FN void pushPairs(Lds lds, const Rows& R, uint32_t hbX, uint32_t kmX, uint32_
 // vector-memory instruction is the cameFrom store — so nothing in it ever waits on vmcnt.
 // BG: the (time, cell) bitmap is in device memory (CJob::bitsG): one masked load per expansion, requested before the pops,
 // and one merged store per touched word (the Wait / Left / Right successors share theirs).
-template <bool EPS, bool PLDS, bool BG = false>
+template <bool EPS, bool PLDS, bool BG = false, class C = Narrow>
 WV_ENTRY int32_t compactSearch(Lds window) {
-  constexpr uint32_t oObstX = obstOff(BG), oPathsX = pathsOff(BG);
+  // the geometry of this instance (the names below hide the narrow tier's at namespace scope)
+  constexpr uint32_t kGroups = C::kGroups, kHeapClamp = C::kHeapClamp, kAuxCap = C::kAuxCap, kAuxBytes = C::kAuxBytes,
+                     kAuxClamp = C::kAuxClamp, kRows = C::kRows, kBitsBytes = C::kBitsBytes;
+  constexpr uint32_t oFocal = C::oFocal, oAux = C::oAux, oBits = C::oBits;
+  constexpr uint32_t kMO = C::kMO, kMF = C::kMF, kEmpty = C::kEmpty, kMOAux = C::kMOAux, kAuxShift = C::kAuxShift;
+  constexpr uint32_t kFShift = C::kFShift, kFhShift = C::kFhShift, kFMax = C::kFMax, kFhMax = C::kFhMax, kGMax = C::kGMax;
+  constexpr uint32_t oObstX = C::obstOff(BG), oPathsX = C::pathsOff(BG);
   constexpr uint32_t oBuild = BG ? oOpen : oBits;   // where the bitmap is put together / where the goal branch stages rows
   const Lds lds = windowBase(window);
   const Sides S = makeSides();
@@ -298,7 +332,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
   const V lane = S.lane;
   const V hb = bothSides(S, oOpen + 4u, oFocal + 4u);  // side A = open list, side B = focal list
   const V km = bothSides(S, kMO, kMF);
-  const V hbAux = splat(oAux + 4u), kmAux = splat(kMO);  // the walk queue: both sides do the same work on it
+  const V hbAux = splat(oAux + 4u), kmAux = splat(kMOAux);  // the walk queue: both sides do the same work on it
   const uint32_t dimx = MRP_CT_JOB_U32(lds, dimx), dimy = MRP_CT_JOB_U32(lds, dimy);
   const uint32_t gx = MRP_CT_JOB_U32(lds, gx), gy = MRP_CT_JOB_U32(lds, gy);
   const uint32_t nEc = MRP_CT_JOB_U32(lds, nEc);
@@ -396,7 +430,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     const uint32_t sx = MRP_CT_JOB_U32(lds, sx), sy = MRP_CT_JOB_U32(lds, sy);
     const uint32_t h0 = (sx > gx ? sx - gx : gx - sx) + (sy > gy ? sy - gy : gy - sy);
     bestF = (int32_t)h0;
-    const uint32_t e0 = (511u << 23) | ((127u - h0) << 16) | (0u << 10) | (sx | (sy << 5));
+    const uint32_t e0 = (kFhMax << kFhShift) | ((kFMax - h0) << kFShift) | (0u << 10) | (sx | (sy << 5));
     ldsStoreS(lds, oOpen + 4u, e0);
     if (EPS) ldsStoreS(lds, oFocal + 4u, e0);
   }
@@ -412,7 +446,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     const uint32_t topO = readlane(tops, 0);
     uint32_t curE = EPS ? readlane(tops, 32) : topO;
     if (EPS) {
-      const int32_t fTop = (int32_t)(127u - ((topO >> 16) & 127u));
+      const int32_t fTop = (int32_t)(kFMax - ((topO >> kFShift) & kFMax));
       const int32_t oldBest = bestF;
       bestF = fTop;                                      // bestFScore = openSet.top().fScore (a_star_epsilon.hpp:136)
       if (fTop > oldBest) {
@@ -424,20 +458,20 @@ WV_ENTRY int32_t compactSearch(Lds window) {
         // The walk changes nothing but the focal list, and only through the nodes of the band old * w < f <= new * w (its
         // queue is dropped afterwards): when no open node has such an f, it is skipped.  f is an integer below 127 here, so
         // the band is f in [floor(lo) + 1, floor(hi)]; one 16-byte read per lane looks at 256 open entries.  Slots that
-        // hold no element read as f = 127 (kEmpty) or f = 0 (the word in front of element 0): never inside.
+        // hold no element read as f = kFMax (kEmpty) or f = 0 (the word in front of element 0): never inside.
         // (-DMRP_CT_FORCE_WALK: always walk — the emulator's A/B for "skipping is unobservable")
         bool bandEmpty = false;
 #ifndef MRP_CT_FORCE_WALK
         {
           const int32_t fA = (int32_t)lo + 1, fBraw = (int32_t)hi;  // lo, hi >= 0: truncation is floor
-          const int32_t fB = fBraw > 126 ? 126 : fBraw;
+          const int32_t fB = fBraw > (int32_t)kFMax - 1 ? (int32_t)kFMax - 1 : fBraw;
           bandEmpty = true;
           if (fB >= fA) {
-            const V base = splat(127u - (uint32_t)fB), span = splat((uint32_t)(fB - fA));
+            const V base = splat(kFMax - (uint32_t)fB), span = splat((uint32_t)(fB - fA));
             for (uint32_t g = 0; g < kGroups && g * 256u <= nOpen; ++g) {  // (element 256 g - 1 belongs to group g)
               const V4 grp = ldsLoad128(lds, splat(oOpen + g * 1024u) + lane * 16u);
-              const B in = ((((grp.x >> 16) & 127u) - base) <= span) | ((((grp.y >> 16) & 127u) - base) <= span) |
-                           ((((grp.z >> 16) & 127u) - base) <= span) | ((((grp.w >> 16) & 127u) - base) <= span);
+              const B in = ((((grp.x >> kFShift) & kFMax) - base) <= span) | ((((grp.y >> kFShift) & kFMax) - base) <= span) |
+                           ((((grp.z >> kFShift) & kFMax) - base) <= span) | ((((grp.w >> kFShift) & kFMax) - base) <= span);
               if (ballot(in)) {
                 bandEmpty = false;
                 break;
@@ -463,9 +497,10 @@ WV_ENTRY int32_t compactSearch(Lds window) {
           }
           // discover the children (index order) before the node is tested; the node joins the focal list if it is in the band
           const uint32_t e1 = readlane(trio, 0), e2 = readlane(trio, 1);
-          const float fv = (float)(int32_t)(127u - ((curKey >> 16) & 127u));
+          const float fv = (float)(int32_t)(kFMax - ((curKey >> kFShift) & kFMax));
           const bool inBand = fv > lo && fv <= hi;
-          pushPairs(lds, Rw, oAux + 4u, kMO, npq, nCh, (e1 & kMO) | firstC, (e2 & kMO) | (firstC + 1u), oFocal + 4u, kMF, nFocal,
+          pushPairs(lds, Rw, oAux + 4u, kMOAux, npq, nCh, ((e1 & kMO) << kAuxShift) | firstC, ((e2 & kMO) << kAuxShift) | (firstC + 1u),
+                    oFocal + 4u, kMF, nFocal,
                     inBand ? 1u : 0u, eCur, 0u);
           npq += nCh;
           nFocal += inBand ? 1u : 0u;
@@ -491,16 +526,16 @@ WV_ENTRY int32_t compactSearch(Lds window) {
               first = false;
               const uint32_t curA = readlane(two, 0);
               value = readlane(two, 1);
-              cur = curA & 0x3FFu;                           // (ten bits below the key: up to 1023 entries)
-              curKey = curA & kMO;
+              cur = curA & C::kAuxIdxMask;                   // (the bits below the key)
+              curKey = (curA >> kAuxShift) & kMO;
               // the next node's entry and children, for the next turn of the loop
               trio = ldsLoad32(lds, splat(oOpen + 4u) + sel(lane == 2u, splat(cur), splat(2u * cur + 1u) + (lane & 1u)) * 4u);
               if (npq == 0u) break;
             }
-            const V kl = pr.x & kMO, kr = pr.y & kMO;
+            const V kl = pr.x & kMOAux, kr = pr.y & kMOAux;
             const B right = kr >= kl;                        // prefer the right child unless it is less than the left one
             const V pe = sel(right, pr.y, pr.x);
-            const B go = kl > (kEmpty & kMO);                // down to a leaf: as long as there is a child
+            const B go = kl > (kEmpty & kMOAux);             // down to a leaf: as long as there is a child
             const uint32_t goM = lo32(ballot(go)), rM = lo32(ballot(right));
             const B onPath = ((S.anc & goM) == S.anc) & (((S.needR ^ rM) & S.anc) == 0u) & go;
             const uint32_t pm = lo32(ballot(onPath & !S.isB));
@@ -513,7 +548,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
           }
           eCur = readlane(trio, 2);
           if (npq > 0u) {
-            if (hole == 0u || !((above & kMO) < (value & kMO)))
+            if (hole == 0u || !((above & kMOAux) < (value & kMOAux)))
               ldsStoreS(lds, oAux + 4u + 4u * hole, value);  // the usual case: the last element stays at the leaf
             else
               dualSiftUp(lds, S, hbAux, kmAux, splat(hole + 1u), value, false, false);
@@ -532,12 +567,12 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       }
     }
     // f, g (== time) and focalH of the popped node are in its entry
-    const uint32_t cell = curE & 1023u, t = (curE >> 10) & 63u, curFh = 511u - (curE >> 23);
+    const uint32_t cell = curE & 1023u, t = (curE >> 10) & kGMax, curFh = kFhMax - (curE >> kFhShift);
     const uint32_t x = cell & 31u, y = cell >> 5;
     const bool isGoal = cell == goalCell && (int32_t)t > lastGoal;
     if (!isGoal) {
       // (cost names the limit and `expanded` how far the search got: statistics for the caller, not results)
-      if (nOpen + 5u > openCap || t > maxT || (EPS && curFh + 2u * nAgentsPad > 511u)) {
+      if (nOpen + 5u > openCap || t > maxT || (EPS && !C::kExactFhCheck && curFh + 2u * nAgentsPad > kFhMax)) {
         status = C_OVERFLOW;
         cost = nOpen + 5u > openCap ? 1 : t > maxT ? 2 : 3;
         break;
@@ -553,7 +588,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       // 1 KB rows of the table) are fetched per round trip into the bitmap's LDS area, which the search no longer needs
       status = C_OK;
       cost = (int32_t)t;
-      fmin = (int32_t)(127u - (((EPS ? topO : curE) >> 16) & 127u));
+      fmin = (int32_t)(kFMax - (((EPS ? topO : curE) >> kFShift) & kFMax));
       nStates = (int32_t)t + 1;
       uint16_t* outPath = MRP_CT_JOB_PTR(uint16_t, lds, outPath);
       sync();  // this wave's action stores have left the CU
@@ -628,11 +663,11 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       const V lastV = ldsLoad32(lds, lastAddr);
       uint32_t p = 0;
       if (EPS) {  // where is the popped node in the open array?  Lane L looks at elements 4L - 1 .. 4L + 2 of a group.
-        const V key = splat(curE & 0xFFFFu);
+        const V key = splat(curE & C::kStateMask);
         for (uint32_t g = 0; g < kGroups && g * 256u <= nOld; ++g) {  // (element 256 g - 1 belongs to group g)
           const V4 grp = ldsLoad128(lds, splat(oOpen + g * 1024u) + lane * 16u);
-          const B m0 = (grp.x & 0xFFFFu) == key, m1 = (grp.y & 0xFFFFu) == key, m2 = (grp.z & 0xFFFFu) == key,
-                  m3 = (grp.w & 0xFFFFu) == key;
+          const B m0 = (grp.x & C::kStateMask) == key, m1 = (grp.y & C::kStateMask) == key, m2 = (grp.z & C::kStateMask) == key,
+                  m3 = (grp.w & C::kStateMask) == key;
           const uint64_t any = ballot(m0 | m1 | m2 | m3);
           if (any) {
             const V pos = lane * 4u + sel(m0, splat(0xFFFFFFFFu), sel(m1, splat(0u), sel(m2, splat(1u), splat(2u))));
@@ -658,7 +693,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
         }
       }
       const V xk = bothSides(S, lastO & kMO, lastF & kMF);
-      const V hole = dualDescend<false>(lds, S, hb, km, splat(kHeapClamp), xk);
+      const V hole = dualDescend(lds, S, hb, km, splat(kHeapClamp), xk);
       ldsStore32m(lds, hb + hole * 4u, bothSides(S, lastO, lastF), (S.l5 == 0u) & (bothSides(S, nOpen, EPS ? nFocal : 0u) != 0u));
     }
 
@@ -698,7 +733,12 @@ WV_ENTRY int32_t compactSearch(Lds window) {
         fhV = writelane(fhV, curFh + cnt, k);
       }
     }
-    const V eV = ((splat(511u) - fhV) << 23) | ((splat(127u) - f) << 16) | (t1 << 10) | ncell;
+    if (EPS && C::kExactFhCheck && ballot(mine & (fhV > kFhMax))) {  // a focalH beyond the entry's field: not a search of this tier
+      status = C_OVERFLOW;
+      cost = 3;
+      break;
+    }
+    const V eV = ((splat(kFhMax) - fhV) << kFhShift) | ((splat(kFMax) - f) << kFShift) | (t1 << 10) | ncell;
     uint32_t maskF = 0;
     if (EPS) {
       const float bound = fmulRn((float)bestF, wBound);  // a_star_epsilon.hpp:240, binary32
@@ -888,7 +928,7 @@ WV_ENTRY int32_t compactSearchTA(Lds window) {
       nOpen -= 1u;
       const uint32_t last = ldsLoadS(lds, oOpen + 4u + 4u * nOpen);
       ldsStoreS(lds, oOpen + 4u + 4u * nOpen, kEmpty);
-      const V hole = dualDescend<false>(lds, S, hbO, kmO, splat(kHeapClamp), splat(last & kTaKm));
+      const V hole = dualDescend(lds, S, hbO, kmO, splat(kHeapClamp), splat(last & kTaKm));
       if (nOpen) ldsStoreS(lds, oOpen + 4u + 4u * first(hole), last);
     }
     // getNeighbors (cbs_ta.cpp:321-367): the five probes on lanes 0..4 — bounds, obstacle, vertex constraint (stateValid),

@@ -64,6 +64,10 @@ constexpr uint32_t kCtxById = 1u;
 // expanded = their sum.  The chain stops behind a search that found no path or ran into the expansion budget, and IN
 // FRONT OF one that outgrows the compact tier (the caller submits that one as an ordinary job).
 constexpr uint32_t kCtxChain = 32u;
+// ctx_flags bit 6 (MRP_LL_JOB_HEAVY): the caller knows that this search outgrows the compact tier (a root chain stopped in
+// front of it): no attempt there — a front workgroup hands it to the heavy workgroups at once, an all-tier kernel starts
+// it in the arena tier.
+constexpr uint32_t kCtxHeavy = 64u;
 constexpr uint32_t kChainEntryWords = 8;
 constexpr uint32_t kChainMaxAgents = 32;
 constexpr uint32_t kChainRows = 64;                                // rows of the chain's focal table (the compact tier ends at t = 62)
@@ -146,6 +150,15 @@ struct LaunchParams {
   uint32_t path_store_stride; // halfwords per slot (0 = no store)
   uint32_t path_store_slots;
   uint32_t sipp_tables_uncached;  // the device-resident SIPP tables live in uncached memory: no cache fences around their use
+  // ---- heavy workgroups (A*-epsilon sessions): a second resident launch with the WIDE window (ll_compact.h) that takes
+  // over the searches the front workgroups' compact tier cannot hold.  Device-side queue, device memory:
+  //   heavy_ctr[0] = entries written so far (front workgroups: fetch-add), heavy_ctr[16] = tickets taken (heavy workgroups),
+  //   heavy_q[t % kRingSlots] = done value << 32 | (t / kRingSlots + 1) << 11 | job slot   (one 8-byte store)
+  // heavy_alive (host-mapped): word w = 1 once heavy workgroup w runs (the host checks residency before it relies on them).
+  unsigned long long* heavy_q;
+  uint32_t* heavy_ctr;
+  uint32_t* heavy_alive;
+  uint32_t heavy_wgs;         // 0: no heavy launch — the resident kernel serves every tier itself
 };
 
 }  // namespace mrp

@@ -1006,10 +1006,26 @@ DEVI uint32_t storeLoad(const uint16_t* p) {
 DEVI uint32_t hostLoad32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 DEVI void hostStore32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-template <bool EPS, bool BG>
-DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t* arenaSlot, DevResult& res,
+// Which tiers a kernel carries:
+//   kTiersAll   — compact (narrow) tier, then the arena tier: batch kernels, CBS / mixed sessions, A*-epsilon sessions
+//                 without heavy workgroups;
+//   kTiersFront — the compact (narrow) tier only: a search it cannot hold is handed to the heavy workgroups (runJob returns
+//                 true, nothing of the job has been reported); no arena-tier code in the kernel;
+//   kTiersHeavy — the compact tier in its WIDE geometry (4095 open entries, t <= 125, ll_compact.h), then the arena tier.
+enum : int { kTiersAll = 0, kTiersFront = 1, kTiersHeavy = 2 };
+
+// Returns true when the job has to be handed to the heavy workgroups (kTiersFront only).
+template <bool EPS, bool BG, int TIERS>
+DEVI bool runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t* arenaSlot, DevResult& res,
                  uint16_t* outPath) {
+  typedef typename std::conditional<TIERS == kTiersHeavy, ct::Wide, ct::Narrow>::type Geo;
+  constexpr bool kTableMayBeInLds = TIERS != kTiersHeavy;  // the wide window holds no path table
   const uint32_t lane = threadIdx.x;
+  const bool heavyHint = (J.ctx_flags & kCtxHeavy) != 0;
+  if (TIERS == kTiersFront) {
+    // not a search of the narrow tier (the caller says so, or the job's shape does): nothing to set up here
+    if (heavyHint || P.lds_nodes == 0 || J.dimx > 32u || J.dimy > 32u || J.n_agents_pad > 128u || J.n_ec > 64u) return true;
+  }
   Ctx c;
   c.dimx = J.dimx; c.dimy = J.dimy; c.wpr = J.words_per_row;
   c.gx = J.gx; c.gy = J.gy; c.sx = J.sx; c.sy = J.sy;
@@ -1039,18 +1055,18 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     }
     const uint32_t pathBytes = c.tPad * c.nAgentsPad * 2;  // multiple of 32
     const uint32_t* psrc = (const uint32_t*)(P.paths + J.path_off);
-    uint8_t* ldsPaths = smem + ldsBytes(0, BG);
+    uint8_t* ldsPaths = smem + Geo::windowBytes(BG);
     c.pathsLds = nullptr;
     if (pathBytes != 0 && (J.ctx_flags & kCtxById)) {
       // f2: the CT node's paths are named by their slots in the device-resident path store (each was written there by
       // the search that produced it); the time-major table [t][agent] is built here, on the device, instead of being
       // packed by the host and read over PCIe.  One coalesced read per agent (lane = time step).
-      const bool inLds = P.lds_nodes != 0 && pathBytes <= P.lds_paths_bytes;
+      const bool inLds = kTableMayBeInLds && P.lds_nodes != 0 && pathBytes <= P.lds_paths_bytes;
       if (!inLds && pathBytes > P.arena_paths_bytes) {  // (the host packer refuses such a job; never write past the slot)
         res.status = ST_BAD;
         res.expanded = 0;
         res.nodes_created = 0;
-        return;
+        return false;
       }
       uint16_t* dst = inLds ? (uint16_t*)ldsPaths : (uint16_t*)pathsArena;
       {
@@ -1126,7 +1142,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
       if (inLds) c.pathsLds = (__attribute__((address_space(3))) const uint16_t*)ldsPaths;
     } else if (pathBytes == 0) {
       c.paths = nullptr;
-    } else if (P.lds_nodes != 0 && pathBytes <= P.lds_paths_bytes) {
+    } else if (kTableMayBeInLds && P.lds_nodes != 0 && pathBytes <= P.lds_paths_bytes) {
       uint32_t* dst = (uint32_t*)ldsPaths;
       for (uint32_t i = lane; i < pathBytes / 4; i += 64) dst[i] = hostLoad32(psrc + i);
       c.paths = (const uint16_t*)ldsPaths;
@@ -1143,61 +1159,15 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   __syncthreads();
 
   SState s;
-  int rc;
+  int rc = ST_BAD;
   res.tier = 0;
-
-  // HBM tier view of this workgroup's arena slot
-  Mem<TierHbm> g;
-  {
-    uint8_t* p = arenaSlot;
-    g.nodes = (Mem<TierHbm>::PN32)p;             p += (size_t)P.arena_nodes * 16;
-    g.pos = nullptr;
-    g.open = (Mem<TierHbm>::PE)(p + 8);          p += (size_t)P.arena_nodes * 8 + 16;
-    g.focal = (Mem<TierHbm>::PE)(p + 8);         p += (size_t)P.arena_nodes * 8 + 16;
-    g.aux = (Mem<TierHbm>::PE)(p + 8);           p += (size_t)P.arena_nodes * 8 + 16;
-    g.bits = (Mem<TierHbm>::P32)p;
-    g.capNodes = P.arena_nodes; g.capHeap = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
-  }
-
-  // ... and the view the arena tier actually runs on: the same arrays, the heaps' first nTop entries in this workgroup's
-  // LDS (the compact tier's area, free once a search has left it)
-  Mem<TierHyb> gh;
-  {
-    const uint32_t area = ct::windowBytes(BG) - ct::oOpen;  // (the window's control blocks in front of it stay as they are)
-    // the open list gets half of the area, the focal list five sixteenths, the walk queue the rest (MRP_LL_TOPS_EQUAL:
-    // thirds, as before the A*-epsilon kernels' window shrank)
-#ifdef MRP_LL_TOPS_EQUAL
-    const uint32_t perO = (area / 3u) & ~15u, perF = perO, perA = perO;
-#else
-    const uint32_t perO = (area / 2u) & ~15u, perF = (area * 5u / 16u) & ~15u, perA = (area - perO - perF) & ~15u;
-#endif
-    auto tops = [&](uint32_t per) {
-      uint32_t n = per >= 32u ? ((per - 8u) / 8u) : 0u;
-      if (n > 4095u) n = 4095u;
-      n = n ? ((n - 1u) | 1u) : 0u;  // odd (or 0: no LDS tier configured)
-      return P.lds_nodes == 0 ? 0u : n;
-    };
-    auto l8 = (__attribute__((address_space(3))) uint8_t*)smem + ct::oOpen;
-    gh.nodes = g.nodes;
-    gh.pos = nullptr;
-    gh.gOf = nullptr;
-    gh.open = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + 8), (uint64_t*)g.open, tops(perO)};
-    gh.focal = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + perO + 8), (uint64_t*)g.focal, tops(perF)};
-    gh.aux = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + perO + perF + 8), (uint64_t*)g.aux, tops(perA)};
-    gh.bits = g.bits;
-    gh.capNodes = g.capNodes; gh.capHeap = g.capHeap; gh.capRows = g.capRows; gh.rowWords = g.rowWords;
-  }
-  const bool xyEntries = P.arena_nodes <= 65536u;  // TierHybXy: 16-bit node ids leave room for the cell in the entry
-  Mem<TierHybXy> ghx;
-  ghx.nodes = gh.nodes; ghx.pos = nullptr; ghx.gOf = nullptr;
-  ghx.open = gh.open; ghx.focal = gh.focal; ghx.aux = gh.aux; ghx.bits = gh.bits;
-  ghx.capNodes = gh.capNodes; ghx.capHeap = gh.capHeap; ghx.capRows = gh.capRows; ghx.rowWords = gh.rowWords;
 
   // ---- compact tier (ll_compact.h): the whole search in LDS, a state = its 32-bit heap entry.  Maps up to 32 x 32 and
   // up to 128 agents in the focal context; a search that outgrows the tier (open list, time steps, focalH field) comes
-  // back as C_OVERFLOW with nothing of it observable, and is run again from the start by the arena tier below.
-  const bool compactOk = P.lds_nodes != 0 && c.dimx <= 32u && c.dimy <= 32u && c.nAgentsPad <= 128u && c.nEc <= 64u &&
-                         (uint64_t)P.arena_nodes * 16u >= ct::kParentBytes + (BG ? ct::kBitsBytes : 0u);
+  // back as C_OVERFLOW with nothing of it observable, and is run again from the start by the next tier.
+  const bool compactOk = !(TIERS == kTiersAll && heavyHint) && P.lds_nodes != 0 && c.dimx <= 32u && c.dimy <= 32u &&
+                         c.nAgentsPad <= 128u && c.nEc <= 64u &&
+                         (uint64_t)P.arena_nodes * 16u >= Geo::kParentBytes + (BG ? Geo::kBitsBytes : 0u);
   bool done = false;
   if (compactOk) {
     // the job goes into its block of the LDS window (every lane stores the same words), the result comes back from there:
@@ -1210,15 +1180,21 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     cj.obstWords = c.wpr;
     cj.nAgentsPad = EPS ? c.nAgentsPad : 0u; cj.tPad = c.tPad;
     cj.maxExp = c.maxExp < 0 ? 0xFFFFFFFFu : (c.maxExp > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)c.maxExp);
-    // mrp_ll_configure_tiers: lds_nodes / 2 = open-list entries, lds_rows = time steps a search may use inside the tier
-    cj.openCap = P.lds_nodes / 2u < ct::kCap ? P.lds_nodes / 2u : ct::kCap;
-    cj.maxT = P.lds_rows >= 3u && P.lds_rows - 2u < ct::kMaxT ? P.lds_rows - 2u : ct::kMaxT;
+    if (TIERS == kTiersHeavy) {  // the wide geometry at its full size
+      cj.openCap = Geo::kCap;
+      cj.maxT = Geo::kMaxT;
+    } else {
+      // mrp_ll_configure_tiers: lds_nodes / 2 = open-list entries, lds_rows = time steps a search may use inside the tier
+      cj.openCap = P.lds_nodes / 2u < Geo::kCap ? P.lds_nodes / 2u : Geo::kCap;
+      cj.maxT = P.lds_rows >= 3u && P.lds_rows - 2u < Geo::kMaxT ? P.lds_rows - 2u : Geo::kMaxT;
+    }
+    cj.taNoGoal = 0;
     cj.vc = (uint64_t)c.vc; cj.ec = (uint64_t)c.ec;
     cj.obst = (uint64_t)c.obst;
     cj.pathsG = (uint64_t)c.paths;
     cj.parentTab = (uint64_t)arenaSlot;  // the arena's node area: unused while the search is in this tier
     cj.outPath = (uint64_t)outPath;
-    cj.bitsG = (uint64_t)(arenaSlot + ct::kParentBytes);  // (BG) ... and its (time, cell) bitmap behind it
+    cj.bitsG = (uint64_t)(arenaSlot + Geo::kParentBytes);  // (BG) ... and its (time, cell) bitmap behind it
     {
       auto w32 = (__attribute__((address_space(3))) uint32_t*)((wv::Lds)smem + ct::oJob);
       const uint32_t* src = (const uint32_t*)&cj;
@@ -1229,7 +1205,11 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
 #ifndef MRP_LL_TRACE  // (the trace build uses prof[] for its phase counters)
     const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int32_t crc = tableInLds ? ct::compactSearch<EPS, true, BG>((wv::Lds)smem) : ct::compactSearch<EPS, false, BG>((wv::Lds)smem);
+    int32_t crc;
+    if constexpr (TIERS == kTiersHeavy)
+      crc = ct::compactSearch<EPS, false, BG, ct::Wide>((wv::Lds)smem);
+    else
+      crc = tableInLds ? ct::compactSearch<EPS, true, BG>((wv::Lds)smem) : ct::compactSearch<EPS, false, BG>((wv::Lds)smem);
     ct::CRes cr;
     {
       auto r32 = (__attribute__((address_space(3))) const uint32_t*)((wv::Lds)smem + ct::oRes);
@@ -1237,8 +1217,10 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
       cr.nStates = (int32_t)rfl(r32[3]); cr.expanded = rfl(r32[4]); cr.nodes = rfl(r32[5]);
     }
 #ifndef MRP_LL_TRACE
-    res.prof[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);  // 100 MHz ticks / expansions in the compact tier
-    res.prof[1] = cr.expanded;                                         // (of a search that was handed over: until then)
+    // 100 MHz ticks / expansions in the compact tier (of a search that was handed over: until then); the wide geometry
+    // reports into the arena tier's pair — "the searches that outgrew the narrow tier"
+    res.prof[TIERS == kTiersHeavy ? 2 : 0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);
+    res.prof[TIERS == kTiersHeavy ? 3 : 1] = cr.expanded;
 #endif
 #ifdef MRP_CT_PROF  // diagnostic build: the compact tier's own phase counters instead of the tier statistics
     {
@@ -1254,6 +1236,7 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
       s.expansions = cr.expanded;
       s.nNodes = cr.nodes;
       done = true;
+      if (TIERS == kTiersHeavy) res.tier = 2;
     } else {
 #ifndef MRP_LL_TRACE
       res.prof[6] = cr.expanded;  // expansions thrown away with the attempt
@@ -1261,31 +1244,83 @@ DEVI void runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
 #endif
     }
   }
-  if (!done) {
-    res.tier = 1;
-    __syncthreads();  // previous job's / the compact attempt's LDS accesses are done
-    if (xyEntries)
-      initSearch<TierHybXy, EPS>(ghx, s, c);
-    else
-      initSearch<TierHyb, EPS>(gh, s, c);
-    __syncthreads();
-#ifndef MRP_LL_TRACE
-    const uint64_t th0 = __builtin_amdgcn_s_memrealtime();
+  if constexpr (TIERS == kTiersFront) {
+    if (!done) return true;  // the heavy workgroups run it from the start
+  } else {
+    if (!done) {
+      // HBM tier view of this workgroup's arena slot
+      Mem<TierHbm> g;
+      {
+        uint8_t* p = arenaSlot;
+        g.nodes = (Mem<TierHbm>::PN32)p;             p += (size_t)P.arena_nodes * 16;
+        g.pos = nullptr;
+        g.open = (Mem<TierHbm>::PE)(p + 8);          p += (size_t)P.arena_nodes * 8 + 16;
+        g.focal = (Mem<TierHbm>::PE)(p + 8);         p += (size_t)P.arena_nodes * 8 + 16;
+        g.aux = (Mem<TierHbm>::PE)(p + 8);           p += (size_t)P.arena_nodes * 8 + 16;
+        g.bits = (Mem<TierHbm>::P32)p;
+        g.capNodes = P.arena_nodes; g.capHeap = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
+      }
+      // ... and the view the arena tier actually runs on: the same arrays, the heaps' first nTop entries in this
+      // workgroup's LDS (the compact tier's area, free once a search has left it)
+      Mem<TierHyb> gh;
+      {
+        const uint32_t area = Geo::windowBytes(BG) - ct::oOpen;  // (the window's control blocks in front of it stay as they are)
+        // the open list gets half of the area, the focal list five sixteenths, the walk queue the rest (MRP_LL_TOPS_EQUAL:
+        // thirds, as before the A*-epsilon kernels' window shrank)
+#ifdef MRP_LL_TOPS_EQUAL
+        const uint32_t perO = (area / 3u) & ~15u, perF = perO, perA = perO;
+#else
+        const uint32_t perO = (area / 2u) & ~15u, perF = (area * 5u / 16u) & ~15u, perA = (area - perO - perF) & ~15u;
 #endif
-    if (xyEntries)
-      rc = runSearch<TierHybXy, EPS>(ghx, s, c, (Mem<TierHybXy>::P32)c.obst, false, res, outPath);
-    else
-      rc = runSearch<TierHyb, EPS>(gh, s, c, (Mem<TierHyb>::P32)c.obst, false, res, outPath);
+        auto tops = [&](uint32_t per) {
+          uint32_t n = per >= 32u ? ((per - 8u) / 8u) : 0u;
+          if (n > 4095u) n = 4095u;
+          n = n ? ((n - 1u) | 1u) : 0u;  // odd (or 0: no LDS tier configured)
+          return P.lds_nodes == 0 ? 0u : n;
+        };
+        auto l8 = (__attribute__((address_space(3))) uint8_t*)smem + ct::oOpen;
+        gh.nodes = g.nodes;
+        gh.pos = nullptr;
+        gh.gOf = nullptr;
+        gh.open = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + 8), (uint64_t*)g.open, tops(perO)};
+        gh.focal = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + perO + 8), (uint64_t*)g.focal, tops(perF)};
+        gh.aux = HybPtr{(__attribute__((address_space(3))) uint64_t*)(l8 + perO + perF + 8), (uint64_t*)g.aux, tops(perA)};
+        gh.bits = g.bits;
+        gh.capNodes = g.capNodes; gh.capHeap = g.capHeap; gh.capRows = g.capRows; gh.rowWords = g.rowWords;
+      }
+      const bool xyEntries = P.arena_nodes <= 65536u;  // TierHybXy: 16-bit node ids leave room for the cell in the entry
+      Mem<TierHybXy> ghx;
+      ghx.nodes = gh.nodes; ghx.pos = nullptr; ghx.gOf = nullptr;
+      ghx.open = gh.open; ghx.focal = gh.focal; ghx.aux = gh.aux; ghx.bits = gh.bits;
+      ghx.capNodes = gh.capNodes; ghx.capHeap = gh.capHeap; ghx.capRows = gh.capRows; ghx.rowWords = gh.rowWords;
+      res.tier = 1;
+      __syncthreads();  // previous job's / the compact attempt's LDS accesses are done
+      if (xyEntries)
+        initSearch<TierHybXy, EPS>(ghx, s, c);
+      else
+        initSearch<TierHyb, EPS>(gh, s, c);
+      __syncthreads();
 #ifndef MRP_LL_TRACE
-    res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);
-    res.prof[3] = (uint32_t)s.expansions;
+      const uint64_t th0 = __builtin_amdgcn_s_memrealtime();
 #endif
+      if (xyEntries)
+        rc = runSearch<TierHybXy, EPS>(ghx, s, c, (Mem<TierHybXy>::P32)c.obst, false, res, outPath);
+      else
+        rc = runSearch<TierHyb, EPS>(gh, s, c, (Mem<TierHyb>::P32)c.obst, false, res, outPath);
+#ifndef MRP_LL_TRACE
+      if (TIERS != kTiersHeavy) {
+        res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);
+        res.prof[3] = (uint32_t)s.expansions;
+      }
+#endif
+    }
   }
   if (rc == RUN_MIGRATE_NODES) rc = ST_CAP_NODES;
   if (rc == RUN_MIGRATE_ROWS) rc = ST_CAP_HORIZON;
   res.status = rc;
   res.expanded = s.expansions;
   res.nodes_created = s.nNodes;
+  return false;
 }
 
 
@@ -2317,9 +2352,12 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
 // only (CBS).  The specialised kernels carry one search loop per memory tier instead of two, which halves their code
 // (instruction-cache footprint) and takes the other algorithm's live ranges out of the register allocation; a job of
 // the other kind comes back as ST_BAD.
-template <int KIND>
-DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* resDst, uint16_t* pathDst, uint8_t* smem,
+// Returns true when the job was NOT run here and has to be handed to the heavy workgroups (TIERS == kTiersFront only):
+// nothing has been written to the job's result area then.
+template <int KIND, int TIERS = kTiersAll>
+DEVI bool processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* resDst, uint16_t* pathDst, uint8_t* smem,
                      uint8_t* arenaSlot, DevJob& jobS, DevResult& resS) {
+  static_assert(TIERS == kTiersAll || KIND == 1, "front / heavy workgroups exist for the A*-epsilon sessions");
   const uint32_t lane = threadIdx.x;
   __syncthreads();
   {  // one coalesced read of the 80-byte descriptor from host memory
@@ -2338,24 +2376,27 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
 #endif
   uint16_t* outPath = (uint16_t*)(arenaSlot + P.arena_scratch_off);  // device scratch; copied out below
   const uint32_t algo = rfl(J.algo);
-  if (KIND == 0) {
+  bool handOver = false;
+  if constexpr (KIND == 0) {
     if (algo == 1)
-      runJob<true, false>(P, J, smem, arenaSlot, res, outPath);
+      runJob<true, false, kTiersAll>(P, J, smem, arenaSlot, res, outPath);
     else if (algo == 3)
       runJobTA(P, J, smem, arenaSlot, res, outPath);
     else
-      runJob<false, false>(P, J, smem, arenaSlot, res, outPath);
-  } else if (KIND == 1) {  // the A*-epsilon-only kernels: the small window (mrp_ll_lds_bytes(kind = 1))
+      runJob<false, false, kTiersAll>(P, J, smem, arenaSlot, res, outPath);
+  } else if constexpr (KIND == 1) {  // the A*-epsilon-only kernels: the small window (mrp_ll_lds_bytes(kind = 1))
     if (algo == 1) {
-      if (rfl(J.ctx_flags) & kCtxChain)
-        runChain(P, J, smem, arenaSlot, res, outPath, pathDst);
-      else
-        runJob<true, true>(P, J, smem, arenaSlot, res, outPath);
+      if (rfl(J.ctx_flags) & kCtxChain) {
+        if constexpr (TIERS != kTiersHeavy) runChain(P, J, smem, arenaSlot, res, outPath, pathDst);  // (heavy: stays ST_BAD)
+      } else {
+        handOver = runJob<true, true, TIERS>(P, J, smem, arenaSlot, res, outPath);
+      }
     }
   } else {
-    if (algo == 0) runJob<false, false>(P, J, smem, arenaSlot, res, outPath);
+    if (algo == 0) runJob<false, false, kTiersAll>(P, J, smem, arenaSlot, res, outPath);
     if (algo == 3) runJobTA(P, J, smem, arenaSlot, res, outPath);
   }
+  if (TIERS == kTiersFront && handOver) return true;
   PROF_ADD(res, 5);
 #if !defined(MRP_LL_TRACE) && !defined(MRP_CT_PROF)
   res.prof[4] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tj0);  // the whole job on the device (tables, search)
@@ -2384,6 +2425,7 @@ DEVI void processJob(const LaunchParams& P, const DevJob* jobSrc, DevResult* res
       __hip_atomic_store(slot, (uint16_t)res.n_states, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  return false;
 }
 
 // Batch mode.  One workgroup == one wavefront; pulls jobs from the batch's queue (exit: queue exhausted).
@@ -2500,7 +2542,47 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_sipp_kernel(LaunchParams
 // completion queue.
 // Exit conditions every wave reaches: *ring_stop != 0, or the host's heartbeat word has not moved for
 // ring_idle_limit_s seconds (the host is gone).
-template <bool SIPP, int KIND>
+// A finished job becomes visible to the host: its done word, then its entry in the completion queue.
+template <bool SIPP>
+DEVI void publishDone(const LaunchParams& P, uint32_t slot, uint32_t doneVal) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t compSize = P.n_slots;
+#ifdef MRP_LL_SESSION_FENCES
+  __threadfence_system();
+  __hip_atomic_store(P.ring_done + slot, doneVal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring
+  uint32_t cidx = atomicAdd(P.comp_count, lane == 0 ? 1u : 0u);
+  cidx = rfl(cidx);
+  __hip_atomic_store(P.comp_ring + (cidx % compSize), ((cidx / compSize + 1) << kRingSlotBits) | slot, __ATOMIC_RELEASE,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+  // Publication without a cache write-back.  What the host reads (result record, path, done word, completion entry)
+  // was written with system-scope stores (processJob: hostStore32) that go through the L2 to host memory, and they
+  // are complete — in order for the host — once vmcnt says so.  What other workgroups read (the path-store slot) was
+  // written with agent-scope stores that go through to memory (processJob).  A system-scope release would add a
+  // buffer_wbl2 sc0 sc1: a write-back of EVERY dirty line of this XCD's L2 (the bitmaps, cameFrom bytes, arena nodes and
+  // heaps of every search on the XCD), per job.
+  // The rule this relies on (LLVM AMDGPU memory model, gfx942 / gfx950): a system-scope (sc0 sc1) store is a write-through
+  // store — it is performed at the system coherence point, not held in this XCD's L2 — and `s_waitcnt vmcnt(0)` returns only
+  // when every earlier vector-memory operation of the wave, stores included (gfx9 counts them in vmcnt), has been
+  // acknowledged there.  Stores of ONE wave that have all been acknowledged before a later store is issued cannot be
+  // observed out of order by any agent.  That is the release half of the model's store-release code sequence
+  // (`buffer_wbl2 sc0 sc1; s_waitcnt vmcnt(0); store sc0 sc1`) minus the write-back, which exists for data written with
+  // weaker scopes — of which the host reads none.
+  if (SIPP && !P.sipp_tables_uncached) __threadfence_system();  // (cached tables: the commits are plain stores)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(P.ring_done + slot, doneVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring; it looks at the done
+  // word of the slot an entry names, so the done word goes first
+  uint32_t cidx = atomicAdd(P.comp_count, lane == 0 ? 1u : 0u);
+  cidx = rfl(cidx);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(P.comp_ring + (cidx % compSize), ((cidx / compSize + 1) << kRingSlotBits) | slot, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+
+template <bool SIPP, int KIND, int TIERS = kTiersAll>
 DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevResult& resS) {
   const uint32_t lane = threadIdx.x;
   uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
@@ -2511,7 +2593,6 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
   uint32_t* const tickets0 = P.queue_head;        // device counters, 64 bytes apart
   uint32_t* const head0 = P.ring_head;            // host words, 64 bytes apart
   uint32_t* const mirror = P.queue_head + 32;     // device: [0] copy of *head0, [16] copy of *ring_stop (zeroed with the tickets)
-  const uint32_t compSize = P.n_slots;
   bool haveBulk = false;                          // a bulk ticket is held and not yet served
   uint32_t bulkT = 0;
   uint32_t lastBeat = 0;                          // host heartbeat value seen at the last idle-limit check
@@ -2607,37 +2688,22 @@ DEVI void residentLoop(const LaunchParams& P, uint8_t* smem, DevJob& jobS, DevRe
     const uint64_t t1c = __builtin_amdgcn_s_memrealtime();
     idleTicks += t1c - t0;
     if (stop) break;
-    if (SIPP)
+    bool handOver = false;
+    if constexpr (SIPP)
       processSippJob(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_host_stride, arenaSlot, smem, jobS,
                      resS);
     else
-      processJob<KIND>(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_host_stride, smem, arenaSlot,
-                       jobS, resS);
-#ifdef MRP_LL_SESSION_FENCES
-    __threadfence_system();
-    __hip_atomic_store(P.ring_done + slot, doneVal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring
-    uint32_t cidx = atomicAdd(P.comp_count, lane == 0 ? 1u : 0u);
-    cidx = rfl(cidx);
-    __hip_atomic_store(P.comp_ring + (cidx % compSize), ((cidx / compSize + 1) << kRingSlotBits) | slot, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-#else
-    // Publication without a cache write-back.  What the host reads (result record, path, done word, completion entry)
-    // was written with system-scope stores (processJob: hostStore32) that go through the L2 to host memory, and they
-    // are complete — in order for the host — once vmcnt says so.  What other workgroups read (the path-store slot) was written with agent-scope stores that go
-    // through to memory (processJob).  A system-scope release would add a buffer_wbl2 sc0 sc1: a write-back of EVERY
-    // dirty line of this XCD's L2 (the bitmaps, cameFrom bytes, arena nodes and heaps of every search on the XCD), per job.
-    if (SIPP && !P.sipp_tables_uncached) __threadfence_system();  // (cached tables: the commits are plain stores)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(P.ring_done + slot, doneVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring; it looks at the done
-    // word of the slot an entry names, so the done word goes first
-    uint32_t cidx = atomicAdd(P.comp_count, lane == 0 ? 1u : 0u);
-    cidx = rfl(cidx);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(P.comp_ring + (cidx % compSize), ((cidx / compSize + 1) << kRingSlotBits) | slot, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
+      handOver = processJob<KIND, TIERS>(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_host_stride, smem,
+                                         arenaSlot, jobS, resS);
+    if (TIERS == kTiersFront && handOver) {
+      // The search does not fit the narrow tier: the heavy workgroups take it over (ll_device.h heavy_q).  One 8-byte store
+      // carries everything they need — the job slot (whose descriptor still sits in host memory) and the done value.
+      const uint32_t ht = rfl(atomicAdd(P.heavy_ctr, lane == 0 ? 1u : 0u));
+      const unsigned long long he = ((unsigned long long)doneVal << 32) | (unsigned long long)(((ht / kRingSlots + 1u) << kRingSlotBits) | slot);
+      __hip_atomic_store(P.heavy_q + (ht % kRingSlots), he, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      publishDone<SIPP>(P, slot, doneVal);
+    }
     busyTicks += __builtin_amdgcn_s_memrealtime() - t1c;
   }
   atomicAdd(P.sess_ticks + 0, lane == 0 ? (unsigned long long)busyTicks : 0ull);
@@ -2657,6 +2723,76 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_persistent_kernel(L
   const LaunchParams& P = Parg;
   residentLoop<false, 1>(P, smem, jobS, resS);
 }
+// The front / heavy pair of an A*-epsilon session (ll_device.h heavy_q).  Front workgroups are the resident loop above
+// with the narrow compact tier alone — no arena-tier code, hence a smaller register allocation; heavy workgroups wait on
+// the device-side queue the front ones fill, run each search in the WIDE compact geometry (41.6 KB of LDS: open and focal
+// lists of 4095 entries, walk queue) and, beyond even that, in the arena tier.
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_front_kernel(LaunchParams Parg) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  MRP_LL_WINDOW_BLOCKS(smem, jobS, resS);
+  const LaunchParams& P = Parg;
+  // "the front launch runs" (the host turns a launch that never starts — streams sharing a hardware queue with a resident
+  // kernel — into an error instead of a hang): the last alive word
+  if (blockIdx.x == 0) hostStore32(P.heavy_alive + (kRingSlots - 1u), 1u);
+  residentLoop<false, 1, kTiersFront>(P, smem, jobS, resS);
+}
+
+// Exit conditions every wave reaches: the stop flag (its device mirror, written by the front workgroup that polls the
+// host, or the host word itself, looked at every ~0.5 ms), or a host heartbeat that stood still for ring_idle_limit_s.
+extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_heavy_kernel(LaunchParams Parg) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  MRP_LL_WINDOW_BLOCKS(smem, jobS, resS);
+  const LaunchParams& P = Parg;
+  const uint32_t lane = threadIdx.x;
+  uint8_t* arenaSlot = P.arena + (size_t)blockIdx.x * P.arena_stride;
+  uint32_t* const mirror = P.queue_head + 32;
+  const uint64_t idleLimit = (uint64_t)P.ring_idle_limit_s * 100000000ull;
+  uint64_t busyTicks = 0, idleTicks = 0;
+  hostStore32(P.heavy_alive + blockIdx.x, 1u);  // "this workgroup is resident" (the host checks before it relies on us)
+  uint32_t lastBeat = 0;
+  for (;;) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t tBeat = t0;
+    const uint32_t ht = rfl(atomicAdd(P.heavy_ctr + 16, lane == 0 ? 1u : 0u));
+    const uint32_t gen = ht / kRingSlots + 1u;
+    unsigned long long e = 0;
+    bool stop = false;
+    uint32_t naps = 1, looks = 0;
+    for (;;) {
+      e = rfl64(__hip_atomic_load(P.heavy_q + (ht % kRingSlots), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if ((((uint32_t)e) >> kRingSlotBits) == gen) break;
+      uint32_t sp = rfl(__hip_atomic_load(mirror + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (sp == 0 && (++looks & 31u) == 0u) sp = rfl(__hip_atomic_load(P.ring_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      if (sp != 0) {
+        stop = true;
+        break;
+      }
+      if (__builtin_amdgcn_s_memrealtime() - tBeat > idleLimit) {
+        const uint32_t hb = rfl(__hip_atomic_load(P.ring_head + kHeartbeatWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (hb == lastBeat) {
+          stop = true;
+          break;
+        }
+        lastBeat = hb;
+        tBeat = __builtin_amdgcn_s_memrealtime();
+      }
+      for (uint32_t q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(64);  // ~2 us, doubling to ~16 us
+      if (naps < 8) naps *= 2;
+    }
+    const uint64_t t1c = __builtin_amdgcn_s_memrealtime();
+    idleTicks += t1c - t0;
+    if (stop) break;
+    const uint32_t slot = (uint32_t)e & kRingSlotMask, doneVal = (uint32_t)(e >> 32);
+    (void)processJob<1, kTiersHeavy>(P, P.jobs + slot, P.results + slot, P.out_paths + (size_t)slot * P.out_host_stride, smem,
+                                     arenaSlot, jobS, resS);
+    publishDone<false>(P, slot, doneVal);
+    busyTicks += __builtin_amdgcn_s_memrealtime() - t1c;
+  }
+  atomicAdd(P.sess_ticks + 4, lane == 0 ? (unsigned long long)busyTicks : 0ull);
+  atomicAdd(P.sess_ticks + 5, lane == 0 ? (unsigned long long)idleTicks : 0ull);
+  atomicAdd(P.sess_ticks + 6, (lane == 0 && busyTicks != 0) ? 1ull : 0ull);
+}
+
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_cbs_persistent_kernel(LaunchParams Parg) {  // A* only
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   MRP_LL_WINDOW_BLOCKS(smem, jobS, resS);
@@ -2721,6 +2857,32 @@ extern "C" int mrp_ll_persistent_occupancy(int kind, uint32_t ldsBytes) {
   if (mrp::allowFullLds(reinterpret_cast<const void*>(k), 3 + kind) != hipSuccess) return 0;
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), 64, ldsBytes) != hipSuccess) return 0;
+  return n;
+}
+
+// The front / heavy pair (kind 1 sessions with heavy workgroups): `heavy` = false launches the front workgroups with the
+// narrow window of `ldsBytes`, true the heavy ones with the wide window.
+extern "C" uint32_t mrp_ll_heavy_lds_bytes(void) { return mrp::ct::Wide::windowBytes(true); }
+extern "C" hipError_t mrp_ll_launch_front_heavy(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, int heavy,
+                                                hipStream_t stream) {
+  typedef void (*Kern)(mrp::LaunchParams);
+  const Kern k = heavy ? mrp::mrp_ll_ecbs_heavy_kernel : mrp::mrp_ll_ecbs_front_kernel;
+  {
+    hipError_t e = mrp::allowFullLds(reinterpret_cast<const void*>(k), 6 + (heavy ? 1 : 0));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), heavy ? mrp::ct::Wide::windowBytes(true) : ldsBytes, stream, *P);
+  return hipGetLastError();
+}
+// Resident workgroups per CU of the front kernel (`heavy` = 0) / the heavy kernel alone (0 on error).
+extern "C" int mrp_ll_front_heavy_occupancy(int heavy, uint32_t ldsBytes) {
+  typedef void (*Kern)(mrp::LaunchParams);
+  const Kern k = heavy ? mrp::mrp_ll_ecbs_heavy_kernel : mrp::mrp_ll_ecbs_front_kernel;
+  if (mrp::allowFullLds(reinterpret_cast<const void*>(k), 6 + (heavy ? 1 : 0)) != hipSuccess) return 0;
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), 64,
+                                                   heavy ? mrp::ct::Wide::windowBytes(true) : ldsBytes) != hipSuccess)
+    return 0;
   return n;
 }
 

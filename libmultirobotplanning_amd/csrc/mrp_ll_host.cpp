@@ -23,6 +23,10 @@ extern "C" hipError_t mrp_ll_launch_sipp(const mrp::LaunchParams* P, uint32_t gr
 extern "C" hipError_t mrp_ll_launch_sipp_persistent(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t mrp_ll_launch_persistent(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, int kind,
                                                hipStream_t stream);
+extern "C" uint32_t mrp_ll_heavy_lds_bytes(void);
+extern "C" hipError_t mrp_ll_launch_front_heavy(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, int heavy,
+                                                hipStream_t stream);
+extern "C" int mrp_ll_front_heavy_occupancy(int heavy, uint32_t ldsBytes);
 
 namespace mrp {
 struct ConflictOut {
@@ -176,6 +180,12 @@ struct Ring {
   uint32_t grid2 = 0;
   hipStream_t stream2 = nullptr;
   hipEvent_t ev2 = nullptr;
+  // The heavy workgroups of an A*-epsilon session (mrp_ll_session_begin_tiers; ll_device.h heavy_q): the second launch is
+  // then the heavy kernel, the first one the front kernel.
+  bool heavy = false;
+  unsigned long long* heavyQ = nullptr;   // device: kRingSlots entries
+  uint32_t* heavyCtr = nullptr;           // device: [0] written, [16] taken
+  uint32_t* heavyAlive = nullptr;         // pinned host: one word per heavy workgroup
   // SIPP sessions (mrp_ll_session_begin_sipp): the jobs' safe-interval tables are far larger than a slot's constraint
   // area, so they get their own pinned buffer, and only the first kSippSlots job slots are used
   static constexpr uint32_t kSippSlots = 512;
@@ -826,6 +836,7 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   d.n_agents_pad = 0;
   d.t_pad = 0;
   d.path_off = 0;
+  if ((j.flags & MRP_LL_JOB_HEAVY) && j.algo == MRP_LL_ASTAR_EPS) d.ctx_flags |= mrp::kCtxHeavy;
   // the result path also goes to a path-store slot only when the caller says so (a zero-initialised job names no slot)
   const bool storeResult = (j.flags & MRP_LL_JOB_STORE_RESULT) != 0;
   d.store_out_id = (storeResult && j.result_path_id >= 0 && static_cast<uint32_t>(j.result_path_id) < ctx->pathStoreSlots)
@@ -851,7 +862,7 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
       for (int a = 0; a < j.n_agents; ++a)
         cs.push(a != j.agent_idx && j.path_len[a] > 0 ? static_cast<uint32_t>(j.path_ids[a]) : mrp::kNoStoreSlot);
       if (cs.failed) return false;
-      d.ctx_flags = mrp::kCtxById;
+      d.ctx_flags |= mrp::kCtxById;
       d.n_ctx = static_cast<uint32_t>(j.n_agents);
       d.n_agents_pad = (static_cast<uint32_t>(j.n_agents) + 15u) & ~15u;
       d.t_pad = static_cast<uint32_t>(tpad);
@@ -1181,6 +1192,9 @@ void mrp_ll_destroy(mrp_ll_ctx* ctx) {
   if (ctx->ring.push) (void)(ctx->ring.pushInDevice ? hipFree(ctx->ring.push) : hipHostFree(ctx->ring.push));
   if (ctx->ring.sippCons) (void)hipHostFree(ctx->ring.sippCons);
   if (ctx->ring.compCountDev) (void)hipFree(ctx->ring.compCountDev);
+  if (ctx->ring.heavyQ) (void)hipFree(ctx->ring.heavyQ);
+  if (ctx->ring.heavyCtr) (void)hipFree(ctx->ring.heavyCtr);
+  if (ctx->ring.heavyAlive) (void)hipHostFree(ctx->ring.heavyAlive);
   if (ctx->ring.ticksDev) (void)hipFree(ctx->ring.ticksDev);
   delete static_cast<SippScratch*>(ctx->sippScratch);
   for (auto& t : ctx->tickets) {
@@ -1317,10 +1331,17 @@ int mrp_ll_session_occupancy(mrp_ll_ctx* ctx, int32_t algo, int32_t* occOut) {
 
 // ---- session mode ---------------------------------------------------------------------------------------------
 // kind (A* sessions): 0 = jobs of both A* algorithms, 1 = MRP_LL_ASTAR_EPS only, 2 = MRP_LL_ASTAR only
-static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind = 0) {
+static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind = 0, int32_t heavyWgs = 0,
+                        int32_t* gate = nullptr, int32_t parties = 0) {
   if (!ctx) return MRP_LL_E_INVALID;
   Ring& g = ctx->ring;
   if (g.active) return MRP_LL_E_INVALID;
+  if (heavyWgs > 0 && (sipp || kind != 1)) return MRP_LL_E_INVALID;
+  if (const char* e = std::getenv("MRP_LL_HEAVY_WGS")) {  // tuning / A-B knob: overrides the caller's heavy workgroups (kind 1)
+    if (!sipp && kind == 1 && heavyWgs >= 0) heavyWgs = std::max(0, std::atoi(e));
+  }
+  if (heavyWgs < 0) heavyWgs = 0;  // (the fallback below: a single all-tier launch, whatever the knob says)
+  if (heavyWgs > 0 && (ctx->opt.lds_nodes == 0 || heavyWgs >= ctx->opt.slots)) heavyWgs = 0;  // (no compact tier: one launch serves all)
   HIPCHK(ctx, hipSetDevice(ctx->device));
   Ticket& t = ctx->tickets[0];
   if (t.inFlight) {
@@ -1383,6 +1404,10 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
     g.compRing = reinterpret_cast<uint32_t*>(g.block + oComp);
     HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&g.compCountDev), 256));
     HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&g.ticksDev), 256));
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&g.heavyQ), static_cast<size_t>(R) * 8));
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&g.heavyCtr), 256));
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&g.heavyAlive), static_cast<size_t>(R) * 4,
+                              hipHostMallocMapped | hipHostMallocCoherent));
     g.jobs = reinterpret_cast<DevJob*>(g.push + oJobs);
     g.results = reinterpret_cast<DevResult*>(g.block + oRes);
     g.outPaths = reinterpret_cast<uint16_t*>(g.block + oOut);
@@ -1475,18 +1500,88 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
   P.out_host_stride = g.outStride;
   ctx->sessionRowWords = P.lds_row_words;
   ctx->sessionLdsPathBytes = P.lds_paths_bytes;
-  g.grid = static_cast<uint32_t>(workgroups > 0 ? std::min(workgroups, ctx->opt.slots) : ctx->opt.slots);
+  if (P.lds_nodes == 0) heavyWgs = 0;
+  heavyWgs = std::min<int32_t>(heavyWgs, static_cast<int32_t>(Ring::kSlots) - 1);  // (the last alive word is the front launch's)
+  g.grid = static_cast<uint32_t>(workgroups > 0 ? std::min(workgroups, ctx->opt.slots - heavyWgs) : ctx->opt.slots - heavyWgs);
   HIPCHK(ctx, hipMemsetAsync(t.queueHead, 0, 256, t.stream));  // session tickets of both lanes count from 0
   HIPCHK(ctx, hipMemsetAsync(g.compCountDev, 0, 4, t.stream));
-  HIPCHK(ctx, hipMemsetAsync(g.ticksDev, 0, 32, t.stream));
+  HIPCHK(ctx, hipMemsetAsync(g.ticksDev, 0, 64, t.stream));
   t.queueBase = 0;
+  g.heavy = false;
+  g.grid2 = 0;
+  if (heavyWgs > 0) {
+    // The heavy workgroups go first, on their own stream, so that they find room on the device before the many front
+    // workgroups fill it; each reports itself in heavyAlive.  Without at least one of them a search that outgrows the
+    // front tier would never run: in that case this session is ended and begun again as a single all-tier launch.
+    HIPCHK(ctx, hipMemsetAsync(g.heavyQ, 0, static_cast<size_t>(R) * 8, t.stream));
+    HIPCHK(ctx, hipMemsetAsync(g.heavyCtr, 0, 256, t.stream));
+    std::memset(g.heavyAlive, 0, static_cast<size_t>(R) * 4);
+    HIPCHK(ctx, hipEventRecord(g.ev0, t.stream));
+    if (!g.stream2) {
+      HIPCHK(ctx, hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+      HIPCHK(ctx, hipEventCreate(&g.ev2));
+    }
+    void* aliveDev = nullptr;
+    HIPCHK(ctx, hipHostGetDevicePointer(&aliveDev, g.heavyAlive, 0));
+    P.heavy_q = g.heavyQ;
+    P.heavy_ctr = g.heavyCtr;
+    P.heavy_alive = static_cast<uint32_t*>(aliveDev);
+    P.heavy_wgs = static_cast<uint32_t>(heavyWgs);
+    mrp::LaunchParams P2 = P;
+    P2.lds_paths_bytes = 0;  // the wide window holds no path table
+    P2.arena = t.arena + static_cast<uint64_t>(g.grid) * ctx->arenaStride;  // arena slots behind the front workgroups'
+    HIPCHK(ctx, hipStreamWaitEvent(g.stream2, g.ev0, 0));
+    HIPCHK(ctx, mrp_ll_launch_front_heavy(&P2, static_cast<uint32_t>(heavyWgs), 0, 1, g.stream2));
+    HIPCHK(ctx, hipEventRecord(g.ev2, g.stream2));
+    // residency: every heavy workgroup reports itself within microseconds when there is room for it; 200 ms is "never"
+    const auto tw0 = std::chrono::steady_clock::now();
+    int32_t nAlive = 0;
+    for (;;) {
+      nAlive = 0;
+      for (int32_t q = 0; q < heavyWgs; ++q) nAlive += __atomic_load_n(g.heavyAlive + q, __ATOMIC_ACQUIRE) != 0 ? 1 : 0;
+      if (nAlive == heavyWgs || std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count() > 0.2) break;
+    }
+    if (gate) {  // the other contexts' heavy workgroups first, then anybody's front workgroups (mrp_ll.h)
+      __atomic_fetch_add(gate, 1, __ATOMIC_ACQ_REL);
+      const auto tg0 = std::chrono::steady_clock::now();
+      while (__atomic_load_n(gate, __ATOMIC_ACQUIRE) < parties &&
+             std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count() < 2.0) {
+      }
+    }
+    HIPCHK(ctx, mrp_ll_launch_front_heavy(&P, g.grid, ldsBytes, 0, t.stream));
+    HIPCHK(ctx, hipEventRecord(g.ev1, t.stream));
+    ctx->stats.launches += 2;
+    g.kind = 1;
+    g.grid2 = static_cast<uint32_t>(heavyWgs);
+    g.heavy = true;
+    g.active = true;
+    if (nAlive > 0) {
+      // ... and the front launch must really run beside them: two streams of this process that were given the same
+      // hardware queue (GPU_MAX_HW_QUEUES smaller than the number of resident kernels) would wait for each other for ever
+      const auto tf0 = std::chrono::steady_clock::now();
+      while (__atomic_load_n(g.heavyAlive + (R - 1), __ATOMIC_ACQUIRE) == 0) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count() > 5.0) {
+          (void)mrp_ll_session_end(ctx);
+          ctx->err = "mrp_ll_session_begin_tiers: the front workgroups did not start beside the heavy ones (HIP streams share "
+                     "hardware queues: export GPU_MAX_HW_QUEUES >= 2 per context + 4 before the HIP runtime initialises)";
+          return MRP_LL_E_DEVICE;
+        }
+      }
+      return MRP_LL_SUCCESS;
+    }
+    // no heavy workgroup runs: a search that outgrows the front tier would wait for ever — one all-tier launch instead
+    int rcEnd = mrp_ll_session_end(ctx);
+    if (rcEnd != MRP_LL_SUCCESS) return rcEnd;
+    ctx->stats.heavy_fallbacks += 1;
+    return sessionBegin(ctx, workgroups, false, kind, -1);
+  }
+  if (gate) __atomic_fetch_add(gate, 1, __ATOMIC_ACQ_REL);  // (a party without heavy workgroups holds nobody up)
   HIPCHK(ctx, hipEventRecord(g.ev0, t.stream));
   if (sipp)
     HIPCHK(ctx, mrp_ll_launch_sipp_persistent(&P, g.grid, t.stream));
   else
     HIPCHK(ctx, mrp_ll_launch_persistent(&P, g.grid, ldsBytes, kind, t.stream));
   g.kind = sipp ? 0 : kind;
-  g.grid2 = 0;
   if (!sipp && P.lds_nodes != 0) {
     uint32_t extra = ctx->extraHbmWgs;
     if (const char* e = std::getenv("MRP_LL_EXTRA_HBM_WGS")) extra = static_cast<uint32_t>(std::max(0, std::atoi(e)));
@@ -1522,6 +1617,31 @@ int mrp_ll_session_begin_algo(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups)
   return sessionBegin(ctx, workgroups, false, algo == MRP_LL_ASTAR_EPS ? 1 : 2);
 }
 int mrp_ll_session_begin_sipp(mrp_ll_ctx* ctx, int32_t workgroups) { return sessionBegin(ctx, workgroups, true); }
+int mrp_ll_session_begin_tiers_gated(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups, int32_t heavyWorkgroups, int32_t* gate,
+                                     int32_t parties) {
+  if (algo == MRP_LL_SIPP) return MRP_LL_E_INVALID;
+  if (algo != MRP_LL_ASTAR && algo != MRP_LL_ASTAR_EPS) return MRP_LL_E_INVALID;
+  if (algo != MRP_LL_ASTAR_EPS && heavyWorkgroups > 0) return MRP_LL_E_INVALID;
+  return sessionBegin(ctx, workgroups, false, algo == MRP_LL_ASTAR_EPS ? 1 : 2, std::max(heavyWorkgroups, 0), gate, parties);
+}
+int mrp_ll_session_begin_tiers(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups, int32_t heavyWorkgroups) {
+  return mrp_ll_session_begin_tiers_gated(ctx, algo, workgroups, heavyWorkgroups, nullptr, 0);
+}
+int mrp_ll_session_tiers_geometry(mrp_ll_ctx* ctx, int32_t* frontOcc, int32_t* frontLds, int32_t* heavyLds) {
+  if (!ctx) return MRP_LL_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
+  const uint32_t bytes = mrp_ll_lds_bytes(1, static_cast<uint32_t>(ctx->opt.lds_nodes), ctx->tierRows, rowWords,
+                                          ctx->opt.lds_nodes ? ctx->tierPathBytes : 0);
+  if (frontOcc) {
+    int occ = mrp_ll_front_heavy_occupancy(0, bytes);
+    if (occ <= 0) occ = static_cast<int>(std::max<uint32_t>(1, std::min<uint32_t>(16, (160u * 1024u) / (bytes + 256u))));
+    *frontOcc = std::min(occ, 16);
+  }
+  if (frontLds) *frontLds = static_cast<int32_t>(bytes);
+  if (heavyLds) *heavyLds = static_cast<int32_t>(mrp_ll_heavy_lds_bytes());
+  return MRP_LL_SUCCESS;
+}
 
 int mrp_ll_session_end(mrp_ll_ctx* ctx) {
   if (!ctx) return MRP_LL_E_INVALID;
@@ -1535,11 +1655,14 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) ctx->stats.kernel_ms += ms;
   {
-    unsigned long long tk[3] = {0, 0, 0};
-    if (hipMemcpy(tk, g.ticksDev, 24, hipMemcpyDeviceToHost) == hipSuccess) {
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpy(tk, g.ticksDev, 64, hipMemcpyDeviceToHost) == hipSuccess) {
       ctx->stats.session_active_wgs += static_cast<int64_t>(tk[2]);
       ctx->stats.session_busy_ms += static_cast<double>(tk[0]) / 1e5;  // 100 MHz ticks
       ctx->stats.session_idle_ms += static_cast<double>(tk[1]) / 1e5;
+      ctx->stats.heavy_active_wgs += static_cast<int64_t>(tk[6]);
+      ctx->stats.heavy_busy_ms += static_cast<double>(tk[4]) / 1e5;
+      ctx->stats.heavy_idle_ms += static_cast<double>(tk[5]) / 1e5;
     }
   }
   g.active = false;

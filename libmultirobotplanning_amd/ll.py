@@ -16,7 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MRP_LL_LIB") or os.path.join(_PKG, "lib", "libmrp_ll.so")
 
 ASTAR, ASTAR_EPS, SIPP, ASTAR_TA = 0, 1, 2, 3
-JOB_STORE_RESULT, JOB_NO_GOAL = 1, 2  # mrp_ll_job.flags (include/mrp_ll.h)
+JOB_STORE_RESULT, JOB_NO_GOAL, JOB_ROOT_CHAIN, JOB_HEAVY = 1, 2, 4, 8  # mrp_ll_job.flags (include/mrp_ll.h)
 OK, NO_SOLUTION, CAP_EXPANSIONS, CAP_NODES, CAP_HORIZON, BAD_JOB, PATH_TRUNCATED, CAP_FOCAL = range(8)
 ACTION_NAMES = ["Up", "Down", "Left", "Right", "Wait"]  # example/ecbs.cpp:49-55
 
@@ -60,7 +60,9 @@ class mrp_ll_stats(ctypes.Structure):
                 ("nodes_created", ctypes.c_int64), ("migrated", ctypes.c_int64), ("kernel_ms", ctypes.c_double),
                 ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("session_busy_ms", ctypes.c_double),
                 ("session_idle_ms", ctypes.c_double), ("session_active_wgs", ctypes.c_int64), ("pack_ms", ctypes.c_double),
-                ("unpack_ms", ctypes.c_double), ("staged_bytes", ctypes.c_int64), ("prof", ctypes.c_int64 * 8)]
+                ("unpack_ms", ctypes.c_double), ("staged_bytes", ctypes.c_int64), ("prof", ctypes.c_int64 * 8),
+                ("heavy_busy_ms", ctypes.c_double), ("heavy_idle_ms", ctypes.c_double), ("heavy_active_wgs", ctypes.c_int64),
+                ("heavy_fallbacks", ctypes.c_int64)]
 
 
 EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_upload_map", "mrp_ll_search_batch",
@@ -68,7 +70,8 @@ EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_uploa
            "mrp_ll_session_begin", "mrp_ll_session_end", "mrp_ll_poll", "mrp_ll_poll_any", "mrp_ll_submit_lane", "mrp_ll_sync_maps",
            "mrp_ll_configure_tiers", "mrp_ll_session_occupancy", "mrp_ll_session_begin_sipp", "mrp_ll_release_maps", "mrp_ll_session_begin_algo", "mrp_ll_conflict_scan",
            "mrp_ll_sipp_table_create", "mrp_ll_sipp_table_add", "mrp_ll_sipp_table_destroy", "mrp_ll_path_store_reserve",
-           "mrp_ll_upload_heuristic"]
+           "mrp_ll_upload_heuristic", "mrp_ll_session_begin_tiers", "mrp_ll_session_tiers_geometry",
+           "mrp_ll_session_begin_tiers_gated"]
 
 _lib = None
 
@@ -109,6 +112,10 @@ def load_library(path: Optional[str] = None):
     lib.mrp_ll_session_begin.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.mrp_ll_session_begin_algo.restype = ctypes.c_int
     lib.mrp_ll_session_begin_algo.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
+    lib.mrp_ll_session_begin_tiers.restype = ctypes.c_int
+    lib.mrp_ll_session_begin_tiers.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    lib.mrp_ll_session_tiers_geometry.restype = ctypes.c_int
+    lib.mrp_ll_session_tiers_geometry.argtypes = [ctypes.c_void_p, I32P, I32P, I32P]
     lib.mrp_ll_session_end.restype = ctypes.c_int
     lib.mrp_ll_session_end.argtypes = [ctypes.c_void_p]
     lib.mrp_ll_poll.restype = ctypes.c_int
@@ -159,6 +166,7 @@ class LLJob:
     path_ids: Optional[Sequence[int]] = None  # f2: path-store slots of ctx_paths (-1 = none); lengths come from ctx_paths
     result_path_id: int = -1                  # f2: path-store slot that also receives the result path
     heuristic_id: int = -1                    # ASTAR_TA: LowLevelEngine.upload_heuristic of the goal cell
+    heavy: bool = False                       # MRP_LL_JOB_HEAVY: the search is known to outgrow the LDS tier (a hint)
 
 
 @dataclass
@@ -239,7 +247,8 @@ class LowLevelEngine:
                 cj.sipp_table = j.sipp_table
                 cj.sipp_commit = 1 if j.sipp_commit else 0
             cj.result_path_id = j.result_path_id
-            cj.flags = (JOB_STORE_RESULT if j.result_path_id >= 0 else 0) | (JOB_NO_GOAL if j.goal is None else 0)
+            cj.flags = (JOB_STORE_RESULT if j.result_path_id >= 0 else 0) | (JOB_NO_GOAL if j.goal is None else 0) | \
+                (JOB_HEAVY if j.heavy else 0)
             cj.heuristic_id = j.heuristic_id
             if j.path_ids is not None:
                 ids = np.ascontiguousarray(np.asarray(j.path_ids, dtype=np.int32))
@@ -346,6 +355,12 @@ class LowLevelEngine:
     def session_begin_algo(self, algo: int, workgroups: int = 0):
         """A session for jobs of one algorithm only (the specialised resident kernel)."""
         self._check(self._lib.mrp_ll_session_begin_algo(self._h, algo, workgroups), "mrp_ll_session_begin_algo")
+
+    def session_begin_tiers(self, workgroups: int, heavy_workgroups: int):
+        """An A*-epsilon session as a pair of resident launches: front workgroups (LDS tier only) + heavy workgroups (wide
+        LDS tier, arena tier) that take over the searches that outgrow the front tier (include/mrp_ll.h)."""
+        self._check(self._lib.mrp_ll_session_begin_tiers(self._h, ASTAR_EPS, workgroups, heavy_workgroups),
+                    "mrp_ll_session_begin_tiers")
 
     def session_begin_sipp(self, workgroups: int = 0):
         """A session for MRP_LL_SIPP jobs (resident SIPP kernel); other jobs come back as BAD_JOB."""

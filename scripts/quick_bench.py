@@ -38,12 +38,14 @@ for rep in range(int(os.environ.get('MRP_REPS', '3'))):
     import collections
     print("   statuses: " + str(dict(collections.Counter(r["status"] for r in res))), flush=True)
     pf = ls["prof"]
-    print("   kernel tiers: LDS %.2f us/expansion over %.4g expansions; arena %.2f us/expansion over %.4g expansions" % (
+    print("   kernel tiers: LDS %.2f us/expansion over %.4g expansions; beyond it (wide LDS tier / arena) %.2f us/expansion over %.4g expansions" % (
         pf[0] / 100.0 / max(pf[1], 1), pf[1], pf[2] / 100.0 / max(pf[3], 1), pf[3]), flush=True)
     print("   whole job on the device: %.1f us over %d jobs" % (pf[4] / 100.0 / max(pf[5], 1), pf[5]), flush=True)
     print("   resident workgroups: busy %.3f s, waiting %.3f s (sum over workgroups) -> busy fraction %.2f" % (
         ls["session_busy_ms"] / 1e3, ls["session_idle_ms"] / 1e3,
         ls["session_busy_ms"] / max(ls["session_busy_ms"] + ls["session_idle_ms"], 1e-9)), flush=True)
+    print("   heavy workgroups: %d active, busy %.3f s, waiting %.3f s; fallbacks to one launch %d" % (
+        ls["heavy_active_wgs"], ls["heavy_busy_ms"] / 1e3, ls["heavy_idle_ms"] / 1e3, ls["heavy_fallbacks"]), flush=True)
 
 if cpu_n:
     import oracle

@@ -2,7 +2,7 @@
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "64")
 import oracle
 from libmultirobotplanning_amd import hl
 agents = int(sys.argv[1]) if len(sys.argv) > 1 else 50

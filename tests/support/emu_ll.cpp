@@ -24,7 +24,8 @@ int neighborIndexFromDelta(int dx, int dy) {  // Wait, Left, Right, Up, Down (ec
 extern "C" {
 
 // One low-level search through the compact tier (eps: 0 = A*, 1 = A*-epsilon, 2 = A*-epsilon with the bitmap in device
-// memory, ll_compact.h BG).  Inputs as in include/mrp_ll.h's mrp_ll_job (constraints [n][3] / [n][5],
+// memory, ll_compact.h BG; 3 = the same in the WIDE geometry — 4095 open entries, t <= 125 — with the path table in
+// "device memory" too: what the heavy workgroups run).  Inputs as in include/mrp_ll.h's mrp_ll_job (constraints [n][3] / [n][5],
 // context paths flattened: path_len[n_agents], path_xy = all states back to back); lds_path_bytes = room for the focal
 // path table in the LDS window (a larger table is read from "global" memory, as on the device); open_cap / max_t > 0:
 // tighter limits of the tier for this job (what mrp_ll_configure_tiers' lds_nodes / lds_rows set on the device).
@@ -91,13 +92,15 @@ int emu_compact_search(int eps, int dimx, int dimy, int n_obst, const int32_t* o
   }
   if (npad > 128) return -2;  // (the kernel starts such a job in the arena tier)
   const uint32_t tableBytes = tpad * npad * 2u;
-  const bool tableInLds = tableBytes != 0 && tableBytes <= (uint32_t)lds_path_bytes;
-  const bool bg = eps == 2;  // the A*-epsilon-only kernels' form: (time, cell) bitmap in "device memory", smaller window
-  std::vector<uint8_t> ldsMem(windowBytes(bg) + (uint32_t)std::max(lds_path_bytes, 0), 0xA5);  // garbage from "the previous job"
+  const bool tableInLds = eps != 3 && tableBytes != 0 && tableBytes <= (uint32_t)lds_path_bytes;
+  const bool wide = eps == 3;
+  const bool bg = eps >= 2;  // the A*-epsilon-only kernels' form: (time, cell) bitmap in "device memory", smaller window
+  if (wide) lds_path_bytes = 0;
+  std::vector<uint8_t> ldsMem((wide ? Wide::windowBytes(true) : windowBytes(bg)) + (uint32_t)std::max(lds_path_bytes, 0), 0xA5);  // garbage from "the previous job"
   wv::LdsWindow win{ldsMem.data(), (uint32_t)ldsMem.size(), 0, 0};
   if (tableInLds) std::memcpy(ldsMem.data() + pathsOff(bg), table.data(), tableBytes);
-  std::vector<uint8_t> parentTab(kParentBytes, 0xEE);
-  std::vector<uint32_t> bitsG(kBitsBytes / 4u, 0xA5A5A5A5u);
+  std::vector<uint8_t> parentTab(wide ? Wide::kParentBytes : kParentBytes, 0xEE);
+  std::vector<uint32_t> bitsG((wide ? Wide::kBitsBytes : kBitsBytes) / 4u, 0xA5A5A5A5u);
   std::vector<uint16_t> outPath(1024, 0);
   table.resize(table.size() + 256, 0xFFFFu);  // (lanes beyond a row's end are masked, but keep reads in bounds)
   CJob J;
@@ -111,14 +114,16 @@ int emu_compact_search(int eps, int dimx, int dimy, int n_obst, const int32_t* o
   J.nAgentsPad = npad; J.tPad = tpad;
   J.pathsG = (uint64_t)(uintptr_t)table.data();
   J.maxExp = max_exp < 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(max_exp, 0xFFFFFFFEll);
-  J.openCap = open_cap > 0 ? std::min<uint32_t>((uint32_t)open_cap, kCap) : kCap;
-  J.maxT = max_t > 0 ? std::min<uint32_t>((uint32_t)max_t, kMaxT) : kMaxT;
+  const uint32_t capT = wide ? Wide::kCap : kCap, maxTT = wide ? Wide::kMaxT : kMaxT;
+  J.openCap = open_cap > 0 ? std::min<uint32_t>((uint32_t)open_cap, capT) : capT;
+  J.maxT = max_t > 0 ? std::min<uint32_t>((uint32_t)max_t, maxTT) : maxTT;
   J.parentTab = (uint64_t)(uintptr_t)parentTab.data();
   J.outPath = (uint64_t)(uintptr_t)outPath.data();
   J.bitsG = (uint64_t)(uintptr_t)bitsG.data();
   if (J.nEc > 64) return -2;  // (the kernel starts such a job in the arena tier)
   std::memcpy(ldsMem.data() + oJob, &J, sizeof(J));
   const int32_t rc = !eps                ? compactSearch<false, true>(&win)
+                     : wide              ? compactSearch<true, false, true, Wide>(&win)
                      : bg && tableInLds  ? compactSearch<true, true, true>(&win)
                      : bg                ? compactSearch<true, false, true>(&win)
                      : tableInLds        ? compactSearch<true, true>(&win)
@@ -192,8 +197,9 @@ int emu_compact_search_ta(int dimx, int dimy, int n_obst, const int32_t* obst_xy
   J.pathsG = (uint64_t)(uintptr_t)table.data();
   J.taNoGoal = has_goal ? 0u : 1u;
   J.maxExp = max_exp < 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(max_exp, 0xFFFFFFFEll);
-  J.openCap = open_cap > 0 ? std::min<uint32_t>((uint32_t)open_cap, kCap) : kCap;
-  J.maxT = max_t > 0 ? std::min<uint32_t>((uint32_t)max_t, kMaxT) : kMaxT;
+  const uint32_t capT = kCap, maxTT = kMaxT;
+  J.openCap = open_cap > 0 ? std::min<uint32_t>((uint32_t)open_cap, capT) : capT;
+  J.maxT = max_t > 0 ? std::min<uint32_t>((uint32_t)max_t, maxTT) : maxTT;
   J.parentTab = (uint64_t)(uintptr_t)parentTab.data();
   J.outPath = (uint64_t)(uintptr_t)outPath.data();
   std::memcpy(ldsMem.data() + oJob, &J, sizeof(J));

@@ -229,6 +229,17 @@ int mrp_ll_session_occupancy(mrp_ll_ctx*, int32_t, int32_t* occ) {
 int mrp_ll_session_begin(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
 int mrp_ll_session_begin_sipp(mrp_ll_ctx*, int32_t) { return MRP_LL_SUCCESS; }
 int mrp_ll_session_begin_algo(mrp_ll_ctx*, int32_t, int32_t) { return MRP_LL_SUCCESS; }
+int mrp_ll_session_begin_tiers(mrp_ll_ctx*, int32_t, int32_t, int32_t) { return MRP_LL_SUCCESS; }
+int mrp_ll_session_begin_tiers_gated(mrp_ll_ctx*, int32_t, int32_t, int32_t, int32_t* gate, int32_t) {
+  if (gate) __atomic_fetch_add(gate, 1, __ATOMIC_ACQ_REL);
+  return MRP_LL_SUCCESS;
+}
+int mrp_ll_session_tiers_geometry(mrp_ll_ctx*, int32_t* occ, int32_t* front, int32_t* heavy) {
+  if (occ) *occ = 12;
+  if (front) *front = 12928;
+  if (heavy) *heavy = 41600;
+  return MRP_LL_SUCCESS;
+}
 int mrp_ll_session_end(mrp_ll_ctx*) { return MRP_LL_SUCCESS; }
 int mrp_ll_poll(mrp_ll_ctx*, int32_t, int32_t* done) {
   *done = 1;  // the mock runs every job synchronously inside mrp_ll_submit

@@ -54,7 +54,7 @@ def emu_search(L, eps, inst, agent, start, goal, vc, ec, ctx_paths, w, max_exp=-
     pxy, pxy_p = _arr([xy for p in ctx_paths for xy in p], (-1, 2))
     out = np.zeros(8, dtype=np.int64)
     states = np.zeros((1024, 2), dtype=np.int32)
-    rc = L.emu_compact_search((2 if getattr(L, "_bg", False) else 1) if eps else 0, inst["dimx"], inst["dimy"], len(obst), obst_p, start[0], start[1], goal[0],
+    rc = L.emu_compact_search((3 if getattr(L, "_wide", False) else 2 if getattr(L, "_bg", False) else 1) if eps else 0, inst["dimx"], inst["dimy"], len(obst), obst_p, start[0], start[1], goal[0],
                               goal[1], w, len(vca), vc_p, len(eca), ec_p, len(plen), agent, plen_p, pxy_p, max_exp,
                               lds_path_bytes, open_cap, max_t, out.ctypes.data_as(I64P), states.ctypes.data_as(I32P), 1024)
     if rc == -2:  # not a job of the compact tier (more than 64 edge constraints, more than 128 agents)
@@ -86,12 +86,14 @@ def _replay(L, oracle_mod, inst, algo, w, lds_path_bytes=2048, cap_total=-1, ope
     return done, over
 
 
-@pytest.fixture(scope="module", params=[False, True], ids=["bitmap_in_lds", "bitmap_in_memory"])
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["bitmap_in_lds", "bitmap_in_memory", "wide"])
 def emu(request):
-    """Both forms of the tier: the (time, cell) bitmap in the LDS window (CBS / mixed kernels) and in device memory
-    (ll_compact.h BG: the A*-epsilon-only kernels, whose window is 8 KB smaller)."""
+    """The forms of the tier: the (time, cell) bitmap in the LDS window (CBS / mixed kernels), in device memory
+    (ll_compact.h BG: the A*-epsilon-only kernels, whose window is 8 KB smaller), and the wide geometry of the heavy
+    workgroups (4095 open entries, t <= 125, other field widths; A*-epsilon only — its A* searches run the narrow form)."""
     L = _emu_lib()
-    L._bg = request.param
+    L._bg = request.param >= 1
+    L._wide = request.param == 2
     return L
 
 
@@ -110,8 +112,9 @@ def test_skipping_walks_with_an_empty_band_is_unobservable(oracle_mod, bench_ins
     (-DMRP_CT_FORCE_WALK): every output word equal."""
     skip, walk = _emu_lib(), _emu_lib(force_walk=True)
     n = 0
-    for bg in (False, True):
-        skip._bg = walk._bg = bg
+    for form in (0, 1, 2):
+        skip._bg = walk._bg = form >= 1
+        skip._wide = walk._wide = form == 2
         for name in ["map_32by32_obst204_agents10_ex%d" % k for k in (1, 5, 9, 13)] + ["map_32by32_obst204_agents50_ex3"]:
             inst = bench_instances[name]
             _, calls = oracle_mod.mapf_record(oracle_mod.ECBS, inst, w=1.3)
@@ -133,6 +136,8 @@ def test_ecbs_denser_instances_tables_in_lds_and_in_memory(emu, oracle_mod, benc
         done += d
         over += o
     assert done > 450, (done, over)
+    if emu._wide:  # the searches that outgrow the narrow geometry (open lists beyond 1023 entries) finish in the wide one
+        assert over == 0, over
 
 
 def test_ecbs_w1_and_cbs_small_maps(emu, oracle_mod, bench_instances, ref_tests):

@@ -46,4 +46,4 @@ def test_struct_layouts_match_header(built):
     assert ctypes.sizeof(ll.mrp_ll_options) == 32
     assert ctypes.sizeof(ll.mrp_ll_job) == 176
     assert ctypes.sizeof(ll.mrp_ll_result) == 64
-    assert ctypes.sizeof(ll.mrp_ll_stats) == 176
+    assert ctypes.sizeof(ll.mrp_ll_stats) == 208

@@ -267,6 +267,56 @@ def test_session_mode_matches_oracle(oracle_mod, bench_instances):
         eng.close()
 
 
+def test_front_and_heavy_workgroups(oracle_mod, bench_instances):
+    """mrp_ll_session_begin_tiers: front workgroups (LDS tier only) hand the searches that outgrow their tier to heavy
+    workgroups (wide LDS tier: 4095 open entries, 128 time steps; arena tier behind it) through a device-side queue.
+    Same bits as the oracle whichever workgroup ran a search; the wide tier really takes the big ones; a search beyond
+    even that (a 190-step path through a serpentine) ends in the arena tier; the MRP_LL_JOB_HEAVY hint changes nothing."""
+    from libmultirobotplanning_amd import ll
+    cases = _harvest(oracle_mod, bench_instances, ["map_32by32_obst204_agents10_ex%d" % k for k in range(4)] +
+                     ["map_32by32_obst204_agents100_ex2", "map_32by32_obst204_agents100_ex5"], oracle_mod.ECBS, 1.3, 3_000_000)
+    # a serpentine: walls on every second row with a gap at alternating ends
+    obst = [[x, y] for y in range(1, 12, 2) for x in range(32) if x != (31 if (y // 2) % 2 == 0 else 0)]
+    snake = dict(dimx=32, dimy=32, obstacles=obst, starts=[[0, 0]], goals=[[31 if 6 % 2 else 0, 12]])
+    o = oracle_mod.ll_search(oracle_mod.ASTAR_EPS, snake, 0, snake["starts"][0], snake["goals"][0], [], [], [], w=1.3)
+    assert o["success"] and o["cost"] > 130
+    eng = ll.LowLevelEngine(device=0, n_tickets=1, slots=256)
+    try:
+        map_ids = {}
+        for name, inst, _ in cases:
+            if name not in map_ids:
+                map_ids[name] = eng.upload_map(inst["dimx"], inst["dimy"], inst["obstacles"])
+        snake_id = eng.upload_map(32, 32, obst)
+        eng.session_begin_tiers(96, 12)
+        try:
+            tiers = []
+            for lo in range(0, len(cases), 400):
+                res = _run_and_compare(eng, cases[lo:lo + 400], ll.ASTAR_EPS, 1.3, map_ids)
+                tiers += [r.tier for r in res]
+            assert tiers.count(0) > 100 and tiers.count(2) >= 5, (tiers.count(0), tiers.count(1), tiers.count(2))
+            r = eng.search_batch([ll.LLJob(map_id=snake_id, algo=ll.ASTAR_EPS, start=snake["starts"][0], goal=snake["goals"][0],
+                                           w=1.3)])[0]
+            assert (r.status, r.cost, r.fmin, r.expanded, r.tier) == (ll.OK, o["cost"], o["fmin"], o["expanded"], 1)
+            assert [s[1:] for s in r.states] == [s[1:] for s in o["states"]]
+            # the hint: every search starts with the heavy workgroups
+            hinted = []
+            for name, inst, c in cases[:120]:
+                a = c["agent"]
+                hinted.append(ll.LLJob(map_id=map_ids[name], algo=ll.ASTAR_EPS, start=inst["starts"][a], goal=inst["goals"][a],
+                                       agent_idx=a, w=1.3, vertex_constraints=c["vertex_constraints"],
+                                       edge_constraints=c["edge_constraints"], ctx_paths=c["ctx_paths"], heavy=True))
+            for (name, inst, c), r in zip(cases[:120], eng.search_batch(hinted)):
+                assert (r.success, r.expanded, r.tier) == (c["success"], c["expanded"], 2), name
+                if c["success"]:
+                    assert (r.cost, r.fmin, [s[1:] for s in r.states]) == (c["cost"], c["fmin"], c["states"])
+        finally:
+            eng.session_end()
+        st = eng.stats()
+        assert st["heavy_active_wgs"] >= 1 and st["heavy_fallbacks"] == 0
+    finally:
+        eng.close()
+
+
 def test_small_maps_uploaded_during_a_session(oracle_mod, bench_instances):
     """Maps smaller than a cache line uploaded while the resident kernel runs, each right after its predecessor has been
     searched: every bitmap has its own 128-byte line in the device buffer, so no XCD's L2 can serve a stale copy of the
