@@ -849,7 +849,9 @@ int mrp_hl_solver_create(int32_t device, int32_t nThreads, const mrp_ll_options*
   *out = nullptr;
   if (nThreads <= 0) {
     unsigned hc = std::thread::hardware_concurrency();
-    nThreads = static_cast<int32_t>(hc ? std::min<unsigned>(hc, 16) : 8);
+    // eight: an ECBS worker keeps two resident kernels, and the device time-slices a process's hardware queues — idle
+    // ones included — beyond about twenty (solve_preloaded); eight workers feed 0.96 of what sixteen do
+    nThreads = static_cast<int32_t>(hc ? std::min<unsigned>(hc, 8) : 8);
   }
   // One HIP stream (= one resident kernel) per worker: each needs its own hardware queue, the ROCm default is 4.  Only
   // effective if the HIP runtime has not been initialised yet in this process; never overrides the caller.
@@ -1033,26 +1035,43 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   int32_t sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, (256 * occupancy) / nThreads));
   // ECBS: some of the device's LDS goes to heavy workgroups (wide LDS tier + arena tier: the searches that outgrow the
   // front tier — 6 % of the expansions at ten agents, 17 % at a hundred, scripts/search_stats.py).  One takes the LDS of
-  // `displaced` front workgroups; about a quarter / half / three quarters of the CUs get one.
+  // `displaced` front workgroups; five eighths / three quarters / all of the CUs get one.
   int32_t heavyPer = 0;
+  // Workers that run: each keeps TWO resident kernels then, and beyond ~16 resident kernels of one process the device
+  // time-slices its hardware queues (measured: the LDS tier's 2.0 us per expansion becomes 2.5 with 24 kernels, 3.1 with
+  // 32) — so at most eight workers drive such a batch (MRP_HL_PAIR_THREADS); eight feed 0.96 of what sixteen do.
+  int32_t nRun = nThreads;
+  const bool sharedPoolMode = std::getenv("MRP_HL_STATIC_SPLIT") == nullptr;
   if (opt.algo == MRP_HL_ECBS && opt.mode != 1 && !s->engines.empty() && s->llOpt.lds_nodes >= 0) {
+    int32_t pairThreads = 8;
+    if (const char* e = std::getenv("MRP_HL_PAIR_THREADS")) pairThreads = std::max(1, std::atoi(e));
+    const bool wantHeavy = !(std::getenv("MRP_HL_HEAVY_WGS") && std::atoi(std::getenv("MRP_HL_HEAVY_WGS")) == 0);
+    if (wantHeavy && sharedPoolMode) nRun = std::min(nThreads, pairThreads);
+  }
+  if (opt.algo == MRP_HL_ECBS && opt.mode != 1 && !s->engines.empty() && s->llOpt.lds_nodes >= 0 &&
+      (sharedPoolMode || nThreads <= 8)) {
     int32_t frontOcc = 0, frontLds = 0, heavyLds = 0;
     if (mrp_ll_session_tiers_geometry(s->engines[0], &frontOcc, &frontLds, &heavyLds) == MRP_LL_SUCCESS && frontOcc > 0 &&
         frontLds > 0) {
-      int32_t heavyTotal = maxAgents <= 16 ? 64 : maxAgents <= 64 ? 128 : 192;
+      // (measured, eight workers: ten agents 160 > 192 > 128 > 256; fifty 192 > 256 > 128; a hundred 256)
+      int32_t heavyTotal = maxAgents <= 16 ? 160 : maxAgents <= 64 ? 192 : 256;
       if (const char* e = std::getenv("MRP_HL_HEAVY_WGS")) heavyTotal = std::max(0, std::atoi(e));  // tuning knob (0: one launch)
-      heavyPer = heavyTotal / nThreads + (heavyTotal % nThreads ? 1 : 0);
+      heavyPer = heavyTotal / nRun + (heavyTotal % nRun ? 1 : 0);
       if (heavyPer > 0) {
         const int32_t granule = 512;  // LDS allocation granularity
         const int32_t fl = (frontLds + granule - 1) / granule * granule, hl = (heavyLds + granule - 1) / granule * granule;
         const int32_t cuLds = 160 * 1024;
         const int32_t frontBeside = std::max(0, (cuLds - hl) / fl);          // front workgroups on a CU that hosts a heavy one
         const int32_t displaced = std::max(0, std::min(frontOcc, cuLds / fl) - frontBeside);
-        const int32_t frontTotal = 256 * std::min(frontOcc, cuLds / fl) - displaced * heavyPer * nThreads;
-        sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots - heavyPer, frontTotal / nThreads));
+        const int32_t frontTotal = 256 * std::min(frontOcc, cuLds / fl) - displaced * heavyPer * nRun;
+        sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots - heavyPer, frontTotal / nRun));
         if (sessionWgs + heavyPer > s->llOpt.slots || frontTotal <= 0) heavyPer = 0;  // (tiny engines: one launch serves all)
       }
     }
+  }
+  if (heavyPer == 0 && nRun != nThreads) {  // no pair after all: every worker runs, with the single launch's share
+    nRun = nThreads;
+    sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, (256 * occupancy) / nThreads));
   }
   if (const char* e = std::getenv("MRP_HL_SESSION_WGS")) sessionWgs = std::max(1, std::atoi(e));  // tuning knob
   // f2: the engines' device-resident path stores (ECBS only: CBS's low level has no focal context).  A search leaves its
@@ -1081,22 +1100,22 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   // one pool of instances for all workers (MRP_HL_STATIC_SPLIT=1 restores the fixed interleaved split)
   std::atomic<int32_t> nextInstance(0);
   int32_t sessionGate = 0;  // mrp_ll_session_begin_tiers_gated: every worker's heavy launch before anybody's front launch
-  const bool sharedPool = std::getenv("MRP_HL_STATIC_SPLIT") == nullptr;
+  const bool sharedPool = sharedPoolMode;
   auto t0 = std::chrono::steady_clock::now();
   batchEpoch() = t0;
   {
     std::vector<std::thread> th;
-    for (int32_t t = 0; t < nThreads; ++t)
+    for (int32_t t = 0; t < (opt.mode == 1 ? nThreads : nRun); ++t)
       th.emplace_back([&, t]() {
         pinWorker(t);
         if (opt.mode == 1)
           runGroup(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, gr[t]);
         else if (sharedPool)
           runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, pathSlots,
-                          gr[t], &nextInstance, nInst, pre->mapBase[t], nThreads, heavyPer, &sessionGate);
+                          gr[t], &nextInstance, nInst, pre->mapBase[t], nRun, heavyPer, &sessionGate);
         else
           runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, pathSlots,
-                          gr[t], nullptr, 0, 0, nThreads, heavyPer, &sessionGate);
+                          gr[t], nullptr, 0, 0, nRun, heavyPer, &sessionGate);
       });
     for (auto& x : th) x.join();
   }

@@ -47,15 +47,20 @@ using namespace wv;
 //   Narrow — the tier every search starts in: 1023 open entries, t <= 61, 12.9 KB of LDS with ten agents (12 searches per CU);
 //            entry  [31:23] 511 - focalH   [22:16] 127 - f   [15:10] g   [9:0] cell
 //   Wide   — the tier of the searches that outgrow it (the "heavy" resident workgroups, ll_kernel.hip): 4095 open entries,
-//            t <= 125, 41.6 KB;  entry  [31:25] 127 - focalH   [24:17] 255 - f   [16:10] g   [9:0] cell
+//            41.6 KB, and as many time steps as the job's arena slot has room for (CJob::rows, up to 958): its entry
+//            carries h instead of g —  [31:26] 63 - focalH   [25:16] 1023 - f   [15:10] 63 - h   [9:0] cell  — which orders
+//            the same way (equal f: g desc <=> h asc, f = g + h) and lets f span 10 bits; g = f - h, a state is named by
+//            (f, cell).  Its (time, cell) bitmap lives in device memory and is built 64 rows at a time, as t grows.
 constexpr uint32_t kRowBytes = 128;               // (time, cell) bitmap: 32 words (one per y) of 32 bits (x) per time step
 constexpr uint32_t oCtl = 0;                      // 256 bytes for the kernel that hosts the tier (job descriptor, result)
 constexpr uint32_t oJob = 256;                    // CJob
 constexpr uint32_t oRes = 384;                    // CRes (+ eight profile words in the diagnostic build)
 constexpr uint32_t oOpen = 448;
 constexpr uint32_t kFront = 0xFFFFFFFFu;          // the word in front of element 0: above every key, names no state
-template <uint32_t GROUPS, uint32_t FH_BITS, uint32_t F_BITS, uint32_t G_BITS>
+// L_BITS: width of the field below f — g (LONGT = false) or 63 - h (LONGT = true, 6 bits)
+template <uint32_t GROUPS, uint32_t FH_BITS, uint32_t F_BITS, uint32_t L_BITS, bool LONGT = false>
 struct TierCfg {
+  static constexpr bool kLongT = LONGT;
   static constexpr uint32_t kGroups = GROUPS;                  // 256-entry groups of the open / focal arrays (one scan instruction each)
   static constexpr uint32_t kCap = 256u * GROUPS - 1u;         // entries of the open / focal list
   static constexpr uint32_t kHeapBytes = 1024u * GROUPS + 16u;
@@ -63,16 +68,19 @@ struct TierCfg {
   static constexpr uint32_t kAuxCap = 128u * GROUPS + 2u;      // walk queue of the ordered walk: at most (n + 1) / 2 + 1 entries
   static constexpr uint32_t kAuxBytes = 512u * GROUPS + 32u;
   static constexpr uint32_t kAuxClamp = kAuxCap + 1u;          // odd; elements kAuxCap .. kAuxCap + 4 always hold kEmpty
-  static constexpr uint32_t kRows = 1u << G_BITS;              // time steps of the (time, cell) bitmap and of the cameFrom table
-  static constexpr uint32_t kFShift = 10u + G_BITS, kFhShift = 10u + G_BITS + F_BITS;
-  static constexpr uint32_t kGMax = (1u << G_BITS) - 1u, kFMax = (1u << F_BITS) - 1u, kFhMax = (1u << FH_BITS) - 1u;
-  static constexpr uint32_t kMO = ((1u << (F_BITS + G_BITS)) - 1u) << 10;  // open key:  f, g
-  static constexpr uint32_t kMF = 0xFFFFFC00u;                             // focal key: focalH, f, g
-  static constexpr uint32_t kStateMask = (1u << kFShift) - 1u;             // g (== time), cell: what names a state
+  // time steps of the (time, cell) bitmap and of the cameFrom table; LONGT: of one chunk of rows (the job says how many rows)
+  static constexpr uint32_t kRows = LONGT ? 64u : (1u << L_BITS);
+  static constexpr uint32_t kFShift = 10u + L_BITS, kFhShift = 10u + L_BITS + F_BITS;
+  static constexpr uint32_t kGMax = (1u << L_BITS) - 1u, kFMax = (1u << F_BITS) - 1u, kFhMax = (1u << FH_BITS) - 1u;
+  static constexpr uint32_t kMO = ((1u << (F_BITS + L_BITS)) - 1u) << 10;  // open key:  f, g (or h)
+  static constexpr uint32_t kMF = 0xFFFFFC00u;                             // focal key: focalH, f, g (or h)
+  // what names a state: g (== time) and cell; LONGT: f and cell
+  static constexpr uint32_t kStateMask = LONGT ? ((kFMax << kFShift) | 1023u) : ((1u << kFShift) - 1u);
   // "no element": its key is below every real key (f <= kFMax - 3 in a tier) and its state bits never name a state
-  // (g = kGMax is never pushed: kMaxT)
-  static constexpr uint32_t kEmpty = kStateMask;
-  static constexpr uint32_t kMaxT = kGMax - 2u;                // the last time step whose nodes are expanded here
+  // (g = kGMax is never pushed: kMaxT; LONGT: nor is f = kFMax)
+  static constexpr uint32_t kEmpty = (1u << kFShift) - 1u;
+  // the last time step whose nodes are expanded here (LONGT: as far as f = g + h <= kFMax - 3 reaches; the job's rows cut it)
+  static constexpr uint32_t kMaxT = LONGT ? kFMax - 3u - 63u : kGMax - 2u;
   // walk-queue entries: the open key of an element above its index in the open array (10 bits, 12 beyond 1023 entries)
   static constexpr uint32_t kAuxShift = GROUPS > 4u ? 2u : 0u;
   static constexpr uint32_t kAuxIdxMask = (1u << (10u + kAuxShift)) - 1u;
@@ -85,21 +93,26 @@ struct TierCfg {
   static constexpr uint32_t oPaths = oObst + kRowBytes;        // the focal path table follows (size chosen by the launcher)
   static constexpr uint32_t kBitsBytes = kRows * kRowBytes;
   static constexpr uint32_t kParentBytes = kRows * 1024u;      // cameFrom table in the arena slot
+  // bytes of device memory a search of `rows` time steps needs behind CJob::parentTab / CJob::bitsG
+  static constexpr uint32_t parentBytes(uint32_t rows) { return (LONGT ? rows : kRows) * 1024u; }
+  static constexpr uint32_t bitsBytes(uint32_t rows) { return (LONGT ? rows : kRows) * kRowBytes; }
   // BG ("bitmap in global memory", the A*-epsilon-only kernels): the (time, cell) bitmap lives in the search's arena slot
   // (CJob::bitsG) instead of the window, which then ends right behind the walk queue: obstacle row, path table.
   static constexpr uint32_t obstOff(bool bg) { return bg ? oBits : oObst; }
   static constexpr uint32_t pathsOff(bool bg) { return obstOff(bg) + kRowBytes; }
   static constexpr uint32_t windowBytes(bool bg) { return pathsOff(bg); }
   static_assert(kFhShift + FH_BITS == 32u, "an entry is 32 bits");
+  static_assert(!LONGT || L_BITS == 6u, "h <= 62 on a 32 x 32 map");
   static_assert(2u * kHeapBytes >= kBitsBytes, "BG builds the bitmap in the (not yet initialised) open + focal areas");
+  static_assert(!LONGT || kAuxBytes >= kBitsBytes, "LONGT builds a chunk of bitmap rows in the walk queue's area");
   static_assert(oFocal % 16 == 0 && oAux % 16 == 0 && oBits % 16 == 0 && oObst % 16 == 0 && oPaths % 16 == 0, "16-byte aligned areas");
   static_assert((kHeapClamp & 1u) == 1u && 4u * (kHeapClamp + 3u) <= kHeapBytes, "clamped child pair stays inside the heap area");
   static_assert((kAuxClamp & 1u) == 1u && 4u * (kAuxClamp + 3u) <= kAuxBytes, "clamped child pair stays inside the walk queue");
-  static_assert(256u * GROUPS <= kAuxIdxMask + 1u && 10u + F_BITS + G_BITS + kAuxShift <= 32u, "walk-queue entry: key above index");
+  static_assert(256u * GROUPS <= kAuxIdxMask + 1u && 10u + F_BITS + L_BITS + kAuxShift <= 32u, "walk-queue entry: key above index");
   static_assert(kMaxT + 1u + 62u <= kFMax - 3u, "f = g + h (h <= 62 on a 32 x 32 map) fits its field");
 };
 typedef TierCfg<4, 9, 7, 6> Narrow;
-typedef TierCfg<16, 7, 8, 7> Wide;
+typedef TierCfg<16, 6, 10, 6, true> Wide;
 // (names the hosting kernels and the host tests use: the narrow geometry)
 constexpr uint32_t kGroups = Narrow::kGroups, kCap = Narrow::kCap, kHeapBytes = Narrow::kHeapBytes, kAuxBytes = Narrow::kAuxBytes;
 constexpr uint32_t kRows = Narrow::kRows;
@@ -125,6 +138,7 @@ struct CJob {              // at oJob of the window; pointers as two words
   uint32_t maxExp;         // 0xFFFFFFFF = unlimited
   uint32_t openCap, maxT;  // limits of this job inside the tier: <= kCap open entries, expanded nodes at t <= maxT <= kMaxT
   uint32_t taNoGoal;       // compactSearchTA: the agent has no task (cbs_ta.cpp:283-319)
+  uint32_t rows;           // Wide geometry: time steps the device memory behind parentTab / bitsG has room for (maxT <= rows - 2)
   uint64_t vc;             // const uint32_t*: t << 16 | y << 8 | x
   uint64_t ec;             // const uint32_t*: t << 19 | (y * dimx + x) << 3 | k   (k = index in Wait, Left, Right, Up, Down)
   uint64_t obst;           // const uint32_t*: the map's obstacle bitmap, bit y * dimx + x
@@ -373,30 +387,54 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     ldsStore128m(lds, splat(oFocal + kGroups * 1024u), none, lane == 0u);
     for (uint32_t b = 1024u; b < kAuxBytes; b += 1024u) ldsStore128m(lds, splat(oAux + b) + lane * 16u, none, (lane * 16u + b) < kAuxBytes);
   };
-  if (!BG) initHeaps();
+  static_assert(!C::kLongT || BG, "the long-horizon geometry keeps its bitmap in device memory");
+  if (!BG || C::kLongT) initHeaps();
   sync();
-  {  // bitmap rows: row t = obstacles (| vertex constraints at t, below | states discovered, during the search)
+  // Bitmap rows r0 .. r0 + kRows - 1 (row t = obstacles | vertex constraints at t | states discovered, during the search),
+  // put together at `where` in the window.
+  auto buildRows = [&](uint32_t where, uint32_t r0) {
     const V4 chunk = ldsLoad128(lds, splat(oObstX) + (lane & 7u) * 16u);
     for (uint32_t i = 0; i < kRows / 8u; ++i)
-      ldsStore128(lds, splat(oBuild + i * 8u * kRowBytes) + (lane >> 3) * kRowBytes + (lane & 7u) * 16u, chunk);
-  }
-  sync();
-  {  // stateValid's vertex constraints (ecbs.cpp:499-502)
+      ldsStore128(lds, splat(where + i * 8u * kRowBytes) + (lane >> 3) * kRowBytes + (lane & 7u) * 16u, chunk);
+    sync();
+    // stateValid's vertex constraints (ecbs.cpp:499-502)
     const uint32_t nVc = MRP_CT_JOB_U32(lds, nVc);
     const uint32_t* vc = MRP_CT_JOB_PTR(const uint32_t, lds, vc);
     for (uint32_t j0 = 0; j0 < nVc; j0 += 64u) {
       const B in = (lane + j0) < nVc;
       const V v = gLoad32m(vc, lane + j0, in);
-      const V tt = v >> 16, yy = (v >> 8) & 0xFFu, xx = v & 0xFFu;
-      ldsOr32m(lds, splat(oBuild) + tt * kRowBytes + yy * 4u, splat(1u) << xx, in & (tt < kRows) & (yy < 32u) & (xx < 32u));
+      const V tt = (v >> 16) - r0, yy = (v >> 8) & 0xFFu, xx = v & 0xFFu;  // (rows in front of r0: a huge number)
+      ldsOr32m(lds, splat(where) + tt * kRowBytes + yy * 4u, splat(1u) << xx, in & (tt < kRows) & (yy < 32u) & (xx < 32u));
     }
-  }
-  if (BG) {  // the finished rows leave for device memory (8 x 1 KB, coalesced); then the heaps take the area over
+  };
+  // LONGT: the rows exist up to rowsReady (exclusive); the next chunk is put together in the walk queue's area — free
+  // between walks — copied out to device memory, and the area is given back to the walk queue.
+  uint32_t rowsReady = 0;
+  auto moreRows = [&]() {
+    sync();
+    buildRows(oAux, rowsReady);
     sync();
     for (uint32_t i = 0; i < kBitsBytes / 1024u; ++i)
-      gStore128(bitsG, splat(i * 64u) + lane, ldsLoad128(lds, splat(oBuild + i * 1024u) + lane * 16u));
+      gStore128(bitsG, splat(rowsReady * (kRowBytes / 16u) + i * 64u) + lane, ldsLoad128(lds, splat(oAux + i * 1024u) + lane * 16u));
     sync();
-    initHeaps();
+    const V4 none{splat(kEmpty), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
+    const V4 head{sel(lane == 0u, splat(kFront), splat(kEmpty)), splat(kEmpty), splat(kEmpty), splat(kEmpty)};
+    ldsStore128(lds, splat(oAux) + lane * 16u, head);
+    for (uint32_t b = 1024u; b < kAuxBytes; b += 1024u) ldsStore128m(lds, splat(oAux + b) + lane * 16u, none, (lane * 16u + b) < kAuxBytes);
+    sync();
+    rowsReady += kRows;
+  };
+  if (C::kLongT) {
+    moreRows();  // (later chunks: in the loop, as t grows)
+  } else {
+    buildRows(oBuild, 0u);
+    if (BG) {  // the finished rows leave for device memory (8 x 1 KB, coalesced); then the heaps take the area over
+      sync();
+      for (uint32_t i = 0; i < kBitsBytes / 1024u; ++i)
+        gStore128(bitsG, splat(i * 64u) + lane, ldsLoad128(lds, splat(oBuild + i * 1024u) + lane * 16u));
+      sync();
+      initHeaps();
+    }
   }
   // edge-constraint keys, one per lane.  They pass through the window (the walk queue's area, restored afterwards) so that
   // the loop below holds no register a vector-memory load is still writing.
@@ -430,7 +468,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
     const uint32_t sx = MRP_CT_JOB_U32(lds, sx), sy = MRP_CT_JOB_U32(lds, sy);
     const uint32_t h0 = (sx > gx ? sx - gx : gx - sx) + (sy > gy ? sy - gy : gy - sy);
     bestF = (int32_t)h0;
-    const uint32_t e0 = (kFhMax << kFhShift) | ((kFMax - h0) << kFShift) | (0u << 10) | (sx | (sy << 5));
+    const uint32_t e0 = (kFhMax << kFhShift) | ((kFMax - h0) << kFShift) | ((C::kLongT ? 63u - h0 : 0u) << 10) | (sx | (sy << 5));
     ldsStoreS(lds, oOpen + 4u, e0);
     if (EPS) ldsStoreS(lds, oFocal + 4u, e0);
   }
@@ -567,7 +605,9 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       }
     }
     // f, g (== time) and focalH of the popped node are in its entry
-    const uint32_t cell = curE & 1023u, t = (curE >> 10) & kGMax, curFh = kFhMax - (curE >> kFhShift);
+    // (LONGT: the field below f holds 63 - h, and g = f - h)
+    const uint32_t cell = curE & 1023u, curFh = kFhMax - (curE >> kFhShift);
+    const uint32_t t = C::kLongT ? (kFMax - ((curE >> kFShift) & kFMax)) - (63u - ((curE >> 10) & 63u)) : (curE >> 10) & kGMax;
     const uint32_t x = cell & 31u, y = cell >> 5;
     const bool isGoal = cell == goalCell && (int32_t)t > lastGoal;
     if (!isGoal) {
@@ -617,6 +657,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
 
     MRP_CT_PROF_MARK(0);
     const uint32_t t1 = t + 1u;
+    if (C::kLongT && t1 >= rowsReady) moreRows();  // (t1 <= maxT + 1 < the job's rows; the walk queue is empty here)
     // the five successor probes: bounds, then ONE bit of the (time, cell) bitmap = obstacle | vertex constraint | already
     // discovered; requested before the pops so that the latency hides behind them
     const V nx = splat(x) + dx, ny = splat(y) + dy;
@@ -738,7 +779,8 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       cost = 3;
       break;
     }
-    const V eV = ((splat(kFhMax) - fhV) << kFhShift) | ((splat(kFMax) - f) << kFShift) | (t1 << 10) | ncell;
+    const V lowKey = C::kLongT ? (splat(63u + t1) - f) << 10 : splat(t1 << 10);  // g, or 63 - h (h = f - g)
+    const V eV = ((splat(kFhMax) - fhV) << kFhShift) | ((splat(kFMax) - f) << kFShift) | lowKey | ncell;
     uint32_t maskF = 0;
     if (EPS) {
       const float bound = fmulRn((float)bestF, wBound);  // a_star_epsilon.hpp:240, binary32

@@ -1165,9 +1165,16 @@ DEVI bool runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
   // ---- compact tier (ll_compact.h): the whole search in LDS, a state = its 32-bit heap entry.  Maps up to 32 x 32 and
   // up to 128 agents in the focal context; a search that outgrows the tier (open list, time steps, focalH field) comes
   // back as C_OVERFLOW with nothing of it observable, and is run again from the start by the next tier.
+  // the wide geometry: as many time steps as the arena slot's node area has room for (cameFrom table + bitmap), in
+  // chunks of 64, up to the job's horizon
+  uint32_t geoRows = Geo::kRows;
+  if (TIERS == kTiersHeavy) {
+    const uint64_t room = (uint64_t)P.arena_nodes * 16u / (1024u + ct::kRowBytes);
+    geoRows = (uint32_t)(room < P.arena_rows ? room : P.arena_rows) & ~63u;
+  }
   const bool compactOk = !(TIERS == kTiersAll && heavyHint) && P.lds_nodes != 0 && c.dimx <= 32u && c.dimy <= 32u &&
-                         c.nAgentsPad <= 128u && c.nEc <= 64u &&
-                         (uint64_t)P.arena_nodes * 16u >= Geo::kParentBytes + (BG ? Geo::kBitsBytes : 0u);
+                         c.nAgentsPad <= 128u && c.nEc <= 64u && geoRows >= 64u &&
+                         (uint64_t)P.arena_nodes * 16u >= Geo::parentBytes(geoRows) + (BG ? Geo::bitsBytes(geoRows) : 0u);
   bool done = false;
   if (compactOk) {
     // the job goes into its block of the LDS window (every lane stores the same words), the result comes back from there:
@@ -1180,9 +1187,10 @@ DEVI bool runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     cj.obstWords = c.wpr;
     cj.nAgentsPad = EPS ? c.nAgentsPad : 0u; cj.tPad = c.tPad;
     cj.maxExp = c.maxExp < 0 ? 0xFFFFFFFFu : (c.maxExp > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)c.maxExp);
+    cj.rows = geoRows;
     if (TIERS == kTiersHeavy) {  // the wide geometry at its full size
       cj.openCap = Geo::kCap;
-      cj.maxT = Geo::kMaxT;
+      cj.maxT = Geo::kMaxT < geoRows - 2u ? Geo::kMaxT : geoRows - 2u;
     } else {
       // mrp_ll_configure_tiers: lds_nodes / 2 = open-list entries, lds_rows = time steps a search may use inside the tier
       cj.openCap = P.lds_nodes / 2u < Geo::kCap ? P.lds_nodes / 2u : Geo::kCap;
@@ -1194,7 +1202,7 @@ DEVI bool runJob(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t*
     cj.pathsG = (uint64_t)c.paths;
     cj.parentTab = (uint64_t)arenaSlot;  // the arena's node area: unused while the search is in this tier
     cj.outPath = (uint64_t)outPath;
-    cj.bitsG = (uint64_t)(arenaSlot + Geo::kParentBytes);  // (BG) ... and its (time, cell) bitmap behind it
+    cj.bitsG = (uint64_t)(arenaSlot + Geo::parentBytes(geoRows));  // (BG) ... and its (time, cell) bitmap behind it
     {
       auto w32 = (__attribute__((address_space(3))) uint32_t*)((wv::Lds)smem + ct::oJob);
       const uint32_t* src = (const uint32_t*)&cj;
@@ -1377,6 +1385,7 @@ DEVI void runChain(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_
     cj.openCap = P.lds_nodes / 2u < ct::kCap ? P.lds_nodes / 2u : ct::kCap;
     cj.maxT = P.lds_rows >= 3u && P.lds_rows - 2u < ct::kMaxT ? P.lds_rows - 2u : ct::kMaxT;
     cj.taNoGoal = 0;
+    cj.rows = 0;
     cj.vc = 0; cj.ec = 0;
     cj.obst = (uint64_t)(P.maps + J.map_word_off);
     cj.pathsG = 0;
@@ -1462,6 +1471,7 @@ DEVI void runJobTA(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_
   cj.openCap = P.lds_nodes / 2u < ct::kCap ? P.lds_nodes / 2u : ct::kCap;
   cj.maxT = P.lds_rows >= 3u && P.lds_rows - 2u < ct::kMaxT ? P.lds_rows - 2u : ct::kMaxT;
   cj.taNoGoal = (J.ctx_flags & kTaNoGoal) ? 1u : 0u;
+  cj.rows = 0;
   {  // the constraint words leave host memory in one pass (at most 64 + 64 of them)
     uint32_t* consLocal = (uint32_t*)(arenaSlot + P.arena_scratch_off + (size_t)P.out_stride * 2);
     const uint32_t lane = threadIdx.x;

@@ -24,7 +24,7 @@ int neighborIndexFromDelta(int dx, int dy) {  // Wait, Left, Right, Up, Down (ec
 extern "C" {
 
 // One low-level search through the compact tier (eps: 0 = A*, 1 = A*-epsilon, 2 = A*-epsilon with the bitmap in device
-// memory, ll_compact.h BG; 3 = the same in the WIDE geometry — 4095 open entries, t <= 125 — with the path table in
+// memory, ll_compact.h BG; 3 = the same in the WIDE geometry — 4095 open entries, t <= 510 — with the path table in
 // "device memory" too: what the heavy workgroups run).  Inputs as in include/mrp_ll.h's mrp_ll_job (constraints [n][3] / [n][5],
 // context paths flattened: path_len[n_agents], path_xy = all states back to back); lds_path_bytes = room for the focal
 // path table in the LDS window (a larger table is read from "global" memory, as on the device); open_cap / max_t > 0:
@@ -99,8 +99,9 @@ int emu_compact_search(int eps, int dimx, int dimy, int n_obst, const int32_t* o
   std::vector<uint8_t> ldsMem((wide ? Wide::windowBytes(true) : windowBytes(bg)) + (uint32_t)std::max(lds_path_bytes, 0), 0xA5);  // garbage from "the previous job"
   wv::LdsWindow win{ldsMem.data(), (uint32_t)ldsMem.size(), 0, 0};
   if (tableInLds) std::memcpy(ldsMem.data() + pathsOff(bg), table.data(), tableBytes);
-  std::vector<uint8_t> parentTab(wide ? Wide::kParentBytes : kParentBytes, 0xEE);
-  std::vector<uint32_t> bitsG((wide ? Wide::kBitsBytes : kBitsBytes) / 4u, 0xA5A5A5A5u);
+  const uint32_t wideRows = 512;  // time steps the "arena slot" of a heavy workgroup has room for (mrp_ll_options.max_horizon)
+  std::vector<uint8_t> parentTab(wide ? Wide::parentBytes(wideRows) : kParentBytes, 0xEE);
+  std::vector<uint32_t> bitsG((wide ? Wide::bitsBytes(wideRows) : kBitsBytes) / 4u, 0xA5A5A5A5u);
   std::vector<uint16_t> outPath(1024, 0);
   table.resize(table.size() + 256, 0xFFFFu);  // (lanes beyond a row's end are masked, but keep reads in bounds)
   CJob J;
@@ -114,7 +115,8 @@ int emu_compact_search(int eps, int dimx, int dimy, int n_obst, const int32_t* o
   J.nAgentsPad = npad; J.tPad = tpad;
   J.pathsG = (uint64_t)(uintptr_t)table.data();
   J.maxExp = max_exp < 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(max_exp, 0xFFFFFFFEll);
-  const uint32_t capT = wide ? Wide::kCap : kCap, maxTT = wide ? Wide::kMaxT : kMaxT;
+  const uint32_t capT = wide ? Wide::kCap : kCap, maxTT = wide ? std::min(Wide::kMaxT, wideRows - 2u) : kMaxT;
+  J.rows = wide ? wideRows : 0u;
   J.openCap = open_cap > 0 ? std::min<uint32_t>((uint32_t)open_cap, capT) : capT;
   J.maxT = max_t > 0 ? std::min<uint32_t>((uint32_t)max_t, maxTT) : maxTT;
   J.parentTab = (uint64_t)(uintptr_t)parentTab.data();

@@ -190,6 +190,35 @@ def test_random_constraint_sets_and_caps(emu, oracle_mod, bench_instances):
     assert n > 60
 
 
+def test_long_horizons(emu, oracle_mod):
+    """Paths far beyond 61 time steps (a 198-step serpentine, with vertex / edge / goal constraints late on the way): the
+    narrow forms hand them over, the wide geometry — entries that carry h instead of g, bitmap rows built 64 at a time as t
+    grows — finishes them bit for bit."""
+    obst = [[x, y] for y in range(1, 12, 2) for x in range(32) if x != (31 if (y // 2) % 2 == 0 else 0)]
+    m = dict(dimx=32, dimy=32, obstacles=obst)
+    s, g = [0, 0], [0, 12]
+    free = oracle_mod.ll_search(oracle_mod.ASTAR_EPS, m, 0, s, g, [], [], [], w=1.3)
+    assert free["success"] and free["cost"] == 198
+    on_path = [st[1:] for st in free["states"]]
+    cases = [([], [])]
+    cases.append(([[150, on_path[150][0], on_path[150][1]], [70, on_path[70][0], on_path[70][1]]], []))   # forces waits
+    cases.append(([[230, g[0], g[1]]], [[100, on_path[100][0], on_path[100][1], on_path[101][0], on_path[101][1]]]))  # late goal constraint
+    other = [[[31, 20]] * 5 + on_path[5:60]]  # another agent walking the same corridor: focal conflicts
+    n = 0
+    for vc, ec in cases:
+        for ctx in ([], [[], other[0]]):
+            o = oracle_mod.ll_search(oracle_mod.ASTAR_EPS, m, 0, s, g, vc, ec, ctx, w=1.3)
+            r = emu_search(emu, True, dict(m, starts=[s], goals=[g]), 0, s, g, vc, ec, ctx, 1.3)
+            assert r["oob_reads"] == 0 and r["oob_writes"] == 0
+            if not emu._wide:
+                assert r["status"] == -1  # handed over
+                continue
+            assert (r["status"] == 0, r["expanded"]) == (o["success"], o["expanded"]), (vc, ec, r["status"], r["expanded"], o["expanded"])
+            assert (r["cost"], r["fmin"], r["states"]) == (o["cost"], o["fmin"], [st[1:] for st in o["states"]])
+            n += 1
+    assert n == (6 if emu._wide else 0)
+
+
 def test_tight_limits_hand_over_cleanly(emu, oracle_mod, bench_instances):
     """Small open-list / time-step limits (mrp_ll_configure_tiers): what still finishes inside the tier is exact, the rest
     is handed over."""

@@ -270,8 +270,8 @@ def test_session_mode_matches_oracle(oracle_mod, bench_instances):
 def test_front_and_heavy_workgroups(oracle_mod, bench_instances):
     """mrp_ll_session_begin_tiers: front workgroups (LDS tier only) hand the searches that outgrow their tier to heavy
     workgroups (wide LDS tier: 4095 open entries, 128 time steps; arena tier behind it) through a device-side queue.
-    Same bits as the oracle whichever workgroup ran a search; the wide tier really takes the big ones; a search beyond
-    even that (a 190-step path through a serpentine) ends in the arena tier; the MRP_LL_JOB_HEAVY hint changes nothing."""
+    Same bits as the oracle whichever workgroup ran a search; the wide tier really takes the big ones, and the long ones (a
+    198-step path through a serpentine: its entries carry h instead of g); the MRP_LL_JOB_HEAVY hint changes nothing."""
     from libmultirobotplanning_amd import ll
     cases = _harvest(oracle_mod, bench_instances, ["map_32by32_obst204_agents10_ex%d" % k for k in range(4)] +
                      ["map_32by32_obst204_agents100_ex2", "map_32by32_obst204_agents100_ex5"], oracle_mod.ECBS, 1.3, 3_000_000)
@@ -296,7 +296,7 @@ def test_front_and_heavy_workgroups(oracle_mod, bench_instances):
             assert tiers.count(0) > 100 and tiers.count(2) >= 5, (tiers.count(0), tiers.count(1), tiers.count(2))
             r = eng.search_batch([ll.LLJob(map_id=snake_id, algo=ll.ASTAR_EPS, start=snake["starts"][0], goal=snake["goals"][0],
                                            w=1.3)])[0]
-            assert (r.status, r.cost, r.fmin, r.expanded, r.tier) == (ll.OK, o["cost"], o["fmin"], o["expanded"], 1)
+            assert (r.status, r.cost, r.fmin, r.expanded, r.tier) == (ll.OK, o["cost"], o["fmin"], o["expanded"], 2)
             assert [s[1:] for s in r.states] == [s[1:] for s in o["states"]]
             # the hint: every search starts with the heavy workgroups
             hinted = []
@@ -313,6 +313,21 @@ def test_front_and_heavy_workgroups(oracle_mod, bench_instances):
             eng.session_end()
         st = eng.stats()
         assert st["heavy_active_wgs"] >= 1 and st["heavy_fallbacks"] == 0
+    finally:
+        eng.close()
+    # a horizon of 200 time steps gives the wide tier three chunks of 64 rows: the serpentine (198 steps) leaves it too and
+    # ends in the arena tier
+    eng = ll.LowLevelEngine(device=0, n_tickets=1, slots=64, max_horizon=200)
+    try:
+        snake_id = eng.upload_map(32, 32, obst)
+        eng.session_begin_tiers(32, 4)
+        try:
+            r = eng.search_batch([ll.LLJob(map_id=snake_id, algo=ll.ASTAR_EPS, start=snake["starts"][0], goal=snake["goals"][0],
+                                           w=1.3)])[0]
+            assert (r.status, r.cost, r.fmin, r.expanded, r.tier) == (ll.OK, o["cost"], o["fmin"], o["expanded"], 1)
+            assert [s[1:] for s in r.states] == [s[1:] for s in o["states"]]
+        finally:
+            eng.session_end()
     finally:
         eng.close()
 
