@@ -54,6 +54,10 @@ typedef struct mrp_hl_solution {
   int32_t* paths_xy;              /* caller buffer [n_agents][path_cap][2] or NULL                              */
   int32_t path_cap;
   int32_t reserved;
+  /* FNV-1a (64 bit) of the schedule of a SOLVED instance — for every agent in order: the bytes x, y of every state of its
+   * path, then the byte 0xFF — computed from the full paths whether or not paths_xy holds (all of) them: a caller that
+   * checks a million schedules compares eight bytes each.  0 when status != MRP_HL_SOLVED. */
+  uint64_t schedule_digest;
 } mrp_hl_solution;
 
 typedef struct mrp_hl_options {

@@ -136,8 +136,20 @@ void writeSolution(const Instance& I, mrp_hl_solution& s) {
   s.low_level_expanded = I.llExpanded();
   s.cost = 0;
   s.makespan = 0;
+  s.schedule_digest = 0;
   if (I.status() == MRP_HL_SOLVED) {
     const auto& sol = I.finalSolution();
+    uint64_t h = 14695981039346656037ull;
+    auto mix = [&h](uint32_t byte) { h = (h ^ (byte & 0xFFu)) * 1099511628211ull; };
+    for (int32_t a = 0; a < I.nAgents(); ++a) {
+      const int32_t* q = sol[a]->xy.data();
+      for (int32_t k = 0, n = sol[a]->len(); k < n; ++k) {
+        mix(static_cast<uint32_t>(q[2 * k]));
+        mix(static_cast<uint32_t>(q[2 * k + 1]));
+      }
+      mix(0xFFu);
+    }
+    s.schedule_digest = h;
     for (int32_t a = 0; a < I.nAgents(); ++a) {
       s.cost += sol[a]->cost;
       s.makespan = std::max<int64_t>(s.makespan, sol[a]->cost);
@@ -1334,7 +1346,7 @@ void runSippGroup(mrp_ll_ctx* ctx, int32_t horizon, int32_t nTickets, const mrp_
 
 // The same loop in session mode: the SIPP kernel stays resident and every instance publishes its next agent's search the
 // moment the previous one has come back — no round barrier, so an instance never waits for another instance's search.
-void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const mrp_hl_instance* instances,
+void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, int32_t nWorkers, const mrp_hl_instance* instances,
                          mrp_hl_sipp_solution* sols, const std::vector<int32_t>& idx, GroupResult& out) {
   struct Iv { int32_t s, e; };
   struct Prio {
@@ -1374,7 +1386,9 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, const 
   // at most one wavefront per instance, and about two per SIMD over all workers: the SIPP kernel waits on HBM for most
   // of an expansion, more resident wavefronts only slow each other down (round 2, 2048 instances x 100 agents, 64 / 96 /
   // 128 / 192 / 256 per worker: 0.43 / 0.38 / 0.42 / 0.51 / 0.61 s)
-  int32_t wgs = static_cast<int32_t>(std::min<size_t>(std::min<size_t>(std::max<size_t>(n, 16), slots), 96));
+  // (that was with sixteen workers: 1536 wavefronts on the device, whatever the number of workers)
+  const size_t perWorker = static_cast<size_t>(std::max(96, 1536 / std::max(nWorkers, 1)));
+  int32_t wgs = static_cast<int32_t>(std::min<size_t>(std::min<size_t>(std::max<size_t>(n, 16), slots), perWorker));
   if (const char* e = std::getenv("MRP_HL_SIPP_WGS")) wgs = std::max(1, std::atoi(e));          // tuning knob
   if (mrp_ll_session_begin_sipp(ctx, wgs) != MRP_LL_SUCCESS) {
     out.err = std::string("mrp_ll_session_begin_sipp: ") + mrp_ll_last_error(ctx);
@@ -1552,7 +1566,7 @@ int mrp_hl_solver_prioritized_sipp(mrp_hl_solver* s, int32_t nInst, const mrp_hl
         if (batchMode)
           runSippGroup(s->engines[t], horizon, s->llOpt.n_tickets, instances, sols, idx[t], gr[t]);
         else
-          runSippGroupSession(s->engines[t], horizon, s->llOpt.slots, instances, sols, idx[t], gr[t]);
+          runSippGroupSession(s->engines[t], horizon, s->llOpt.slots, nThreads, instances, sols, idx[t], gr[t]);
       });
     for (auto& x : th) x.join();
   }

@@ -29,7 +29,13 @@ class mrp_hl_solution(ctypes.Structure):
     _fields_ = [("status", ctypes.c_int32), ("n_ll_searches", ctypes.c_int32), ("cost", ctypes.c_int64),
                 ("makespan", ctypes.c_int64), ("high_level_expanded", ctypes.c_int64),
                 ("low_level_expanded", ctypes.c_int64), ("path_len", I32P), ("paths_xy", I32P),
-                ("path_cap", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("path_cap", ctypes.c_int32), ("reserved", ctypes.c_int32), ("schedule_digest", ctypes.c_uint64)]
+
+
+# the same record as a numpy dtype (bulk access to arrays of results)
+_SOLUTION_DTYPE = np.dtype([("status", "<i4"), ("n_ll_searches", "<i4"), ("cost", "<i8"), ("makespan", "<i8"),
+                            ("high_level_expanded", "<i8"), ("low_level_expanded", "<i8"), ("path_len", "<u8"),
+                            ("paths_xy", "<u8"), ("path_cap", "<i4"), ("reserved", "<i4"), ("schedule_digest", "<u8")])
 
 
 class mrp_hl_options(ctypes.Structure):
@@ -239,7 +245,7 @@ class BatchSolver:
         keep = []
         plen: List[Optional[np.ndarray]] = []
         pxy: List[Optional[np.ndarray]] = []
-        if isinstance(instances, InstanceArrays) and not want_paths:
+        if isinstance(instances, InstanceArrays):
             # bulk form: fill the descriptor array through one numpy view instead of n x 7 ctypes attribute stores
             ob, st, go = (np.ascontiguousarray(a) for a in (instances.obstacles, instances.starts, instances.goals))
             keep.append((ob, st, go))
@@ -253,6 +259,18 @@ class BatchSolver:
             view["obstacles_xy"] = ob.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(ob.shape[1] * 8)
             view["starts_xy"] = st.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(st.shape[1] * 8)
             view["goals_xy"] = go.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(go.shape[1] * 8)
+            if want_paths:  # one block for all schedules: [n][agents][path_cap][2] int32 + [n][agents] lengths
+                na = st.shape[1]
+                lens = np.zeros((n, na), dtype=np.int32)
+                paths = np.empty((n, na, path_cap, 2), dtype=np.int32)
+                keep.append((lens, paths))
+                assert _SOLUTION_DTYPE.itemsize == ctypes.sizeof(mrp_hl_solution)
+                sv = np.frombuffer(csol, dtype=_SOLUTION_DTYPE, count=n)
+                sv["path_len"] = lens.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(na * 4)
+                sv["paths_xy"] = paths.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(na * path_cap * 8)
+                sv["path_cap"] = path_cap
+                plen = [lens[i] for i in range(n)] if n <= 4096 else lens
+                pxy = [paths[i] for i in range(n)] if n <= 4096 else paths
             instances = ()
         for i, inst in enumerate(instances):
             ob = np.ascontiguousarray(np.asarray(inst["obstacles"], dtype=np.int32).reshape(-1, 2))
@@ -300,13 +318,24 @@ class BatchSolver:
                      speculative_searches=st.speculative_searches, wasted_ll_expansions=st.wasted_ll_expansions)
         return (None if raw else self.results_of(prep)), stats
 
+    def result_arrays(self, prep) -> Dict[str, np.ndarray]:
+        """The results of a prepared batch as numpy arrays (status, cost, makespan, hl_expanded, ll_expanded, ll_searches,
+        schedule_digest; path_len [n][agents] when the batch delivers schedules through the bulk form)."""
+        sv = np.frombuffer(prep["csol"], dtype=_SOLUTION_DTYPE, count=prep["n"])
+        out = dict(status=sv["status"].copy(), cost=sv["cost"].copy(), makespan=sv["makespan"].copy(),
+                   hl_expanded=sv["high_level_expanded"].copy(), ll_expanded=sv["low_level_expanded"].copy(),
+                   ll_searches=sv["n_ll_searches"].copy(), schedule_digest=sv["schedule_digest"].copy())
+        if prep["want_paths"] and isinstance(prep["plen"], np.ndarray):
+            out["path_len"] = prep["plen"]
+        return out
+
     def results_of(self, prep) -> List[Dict]:
         out = []
         csol, plen, pxy = prep["csol"], prep["plen"], prep["pxy"]
         for i in range(prep["n"]):
             s = csol[i]
             rec = dict(status=s.status, cost=s.cost, makespan=s.makespan, hl_expanded=s.high_level_expanded,
-                       ll_expanded=s.low_level_expanded, ll_searches=s.n_ll_searches)
+                       ll_expanded=s.low_level_expanded, ll_searches=s.n_ll_searches, schedule_digest=s.schedule_digest)
             if prep["want_paths"] and s.status == SOLVED:
                 assert int(plen[i].max(initial=0)) <= prep["path_cap"]
                 rec["paths"] = [pxy[i][a, :plen[i][a]].tolist() for a in range(len(plen[i]))]

@@ -48,6 +48,8 @@ def lib():
         _LIB.oracle_mapf_solve_batch.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_int, I32P, ctypes.c_int, I32P, I32P, ctypes.c_int64,
                                                  ctypes.c_int, I64P]
+        _LIB.oracle_mapf_solve_batch_digest.restype = ctypes.c_int64
+        _LIB.oracle_mapf_solve_batch_digest.argtypes = _LIB.oracle_mapf_solve_batch.argtypes
         _LIB.oracle_conflict_scan.restype = None
         _LIB.oracle_conflict_scan.argtypes = [ctypes.c_int, I32P, I32P, I32P]
         _LIB.oracle_prioritized_sipp_batch.restype = ctypes.c_int64
@@ -294,6 +296,20 @@ def mapf_solve_batch(algo, dimx, dimy, obstacles, starts, goals, w=1.0, cap_tota
                                          st.ctypes.data_as(I32P), go.ctypes.data_as(I32P), cap_total, n_threads,
                                          out.ctypes.data_as(I64P))
     return out, wall / 1e9
+
+
+def mapf_solve_batch_digest(algo, dimx, dimy, obstacles, starts, goals, w=1.0, cap_total=-1, n_threads=1):
+    """mapf_solve_batch with a seventh word per instance: the FNV-1a (64 bit) digest of the schedule as
+    include/mrp_hl.h mrp_hl_solution::schedule_digest defines it (as uint64 in the returned second array)."""
+    ob = np.ascontiguousarray(obstacles, dtype=np.int32)
+    st = np.ascontiguousarray(starts, dtype=np.int32)
+    go = np.ascontiguousarray(goals, dtype=np.int32)
+    n = len(st)
+    out = np.zeros((n, 7), dtype=np.int64)
+    wall = lib().oracle_mapf_solve_batch_digest(algo, w, n, dimx, dimy, ob.shape[1], ob.ctypes.data_as(I32P), st.shape[1],
+                                                st.ctypes.data_as(I32P), go.ctypes.data_as(I32P), cap_total, n_threads,
+                                                out.ctypes.data_as(I64P))
+    return out[:, :6], out[:, 6].view(np.uint64), wall / 1e9
 
 
 def conflict_scan(paths):

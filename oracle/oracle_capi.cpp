@@ -138,6 +138,60 @@ int64_t oracle_mapf_solve_batch(int algo, float w, int n, int dimx, int dimy, in
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// The same with a digest of every solved instance's schedule: perInst[k][0..6] = the six words above + the FNV-1a (64 bit)
+// of the paths as include/mrp_hl.h mrp_hl_solution::schedule_digest defines it (0 when not solved).  A schedule longer
+// than 1024 states per agent makes the instance's digest 1 (never equal to a real one in practice).
+int64_t oracle_mapf_solve_batch_digest(int algo, float w, int n, int dimx, int dimy, int nObst, const int32_t* obstXY,
+                                       int nAgents, const int32_t* startsXY, const int32_t* goalsXY, int64_t capTotal,
+                                       int nThreads, int64_t* perInst) {
+  std::atomic<int> next(0);
+  auto t0 = std::chrono::steady_clock::now();
+  auto work = [&]() {
+    const int cap = 1024;
+    std::vector<int32_t> len(static_cast<size_t>(std::max(nAgents, 1)));
+    std::vector<int32_t> xy(static_cast<size_t>(std::max(nAgents, 1)) * cap * 2);
+    for (;;) {
+      const int k = next.fetch_add(1, std::memory_order_relaxed);
+      if (k >= n) return;
+      int64_t st[6];
+      const int rc = oracle_mapf_solve(algo, w, dimx, dimy, nObst, obstXY + static_cast<int64_t>(k) * nObst * 2, nAgents,
+                                       startsXY + static_cast<int64_t>(k) * nAgents * 2,
+                                       goalsXY + static_cast<int64_t>(k) * nAgents * 2, -1, capTotal, -1, st, len.data(),
+                                       xy.data(), cap);
+      int64_t* o = perInst + static_cast<int64_t>(k) * 7;
+      o[0] = rc;
+      o[1] = st[0];
+      o[2] = st[1];
+      o[3] = st[2];
+      o[4] = st[3];
+      o[5] = st[4];
+      uint64_t h = 0;
+      if (rc == 1) {
+        h = 14695981039346656037ull;
+        bool tooLong = false;
+        for (int a = 0; a < nAgents; ++a) {
+          if (len[a] > cap) tooLong = true;
+          for (int q = 0; q < std::min(len[a], cap); ++q) {
+            h = (h ^ (static_cast<uint32_t>(xy[(static_cast<size_t>(a) * cap + q) * 2]) & 0xFFu)) * 1099511628211ull;
+            h = (h ^ (static_cast<uint32_t>(xy[(static_cast<size_t>(a) * cap + q) * 2 + 1]) & 0xFFu)) * 1099511628211ull;
+          }
+          h = (h ^ 0xFFu) * 1099511628211ull;
+        }
+        if (tooLong) h = 1;
+      }
+      o[6] = static_cast<int64_t>(h);
+    }
+  };
+  if (nThreads <= 1) {
+    work();
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nThreads; ++t) th.emplace_back(work);
+    for (auto& x : th) x.join();
+  }
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+}
+
 // getFirstConflict (ecbs.cpp:401-452) + focalHeuristic (:315-350) of one solution given as flattened paths.
 // out[0..9] = found, time, agent1, agent2, type (0 vertex / 1 edge), x1, y1, x2, y2, focalHeuristic
 void oracle_conflict_scan(int nAgents, const int32_t* pathLen, const int32_t* pathXY, int32_t* out) {

@@ -21,6 +21,7 @@ What is produced, and from what:
                               expansions per instance (agents100_ex36 runs into it), same status as oracle_expected.json.
 * ``cbs_8x8_cap1e6.json``   — our oracle's CBS results on shipped 8x8_obst12 inputs at SURVEY.md §8(d)(iii)'s cap of
                               1 000 000 low-level expansions per instance (agents 10, 12, 16, 20).
+* ``shipped_heavy_tail_expected.json`` — our oracle's result for agents100_ex36 with NO cap (the reference has none).
 * ``ll_jobs.json``          — ~200 low-level searches harvested from the oracle's conflict trees (inputs AND outputs), so
                               that a box without a compiler for the oracle still has low-level parity vectors.
 
@@ -240,7 +241,31 @@ def ta_tests():
                 src="test/test_cbs_ta.py:24-38 (agent end states as x, y, t)")
 
 
+def heavy_tail():
+    """The one shipped input the 3 000 000-expansion cap of shipped_32x32_expected.json cuts off — agents100_ex36 — run to
+    completion by our oracle (no cap at all, as the reference has none): SURVEY.md §6 reports cost 2574, 70 612 conflict-tree
+    nodes and 56 795 846 low-level expansions from the reference's own headers."""
+    import time
+    import numpy as np
+    import oracle
+    oracle.build()
+    z = np.load(os.path.join(OUT, "shipped_32x32.npz"))
+    inst = dict(dimx=32, dimy=32, obstacles=z["obst100"][36].astype(int).tolist(), starts=z["starts100"][36].astype(int).tolist(),
+                goals=z["goals100"][36].astype(int).tolist())
+    t0 = time.time()
+    r = oracle.mapf_solve(oracle.ECBS, inst, w=1.3, cap_total=-1, path_cap=1024)
+    rec = summarize(r)
+    rec["oracle_search_seconds_in_the_build_container"] = r["elapsed_ns"] / 1e9
+    rec["wall_seconds_in_the_build_container"] = time.time() - t0
+    with open(os.path.join(OUT, "shipped_heavy_tail_expected.json"), "w") as f:
+        json.dump({"map_32by32_obst204_agents100_ex36": rec}, f, separators=(",", ":"), sort_keys=True)
+    return rec
+
+
 if __name__ == "__main__":
+    if "--heavy-tail" in sys.argv:  # round-4 addition: agents100_ex36 uncapped
+        print(heavy_tail())
+        sys.exit(0)
     if "--ta" in sys.argv:  # round-3 addition: the task-assignment fixtures go into ref_tests.json
         with open(os.path.join(OUT, "ref_tests.json")) as f:
             t = json.load(f)
