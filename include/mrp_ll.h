@@ -288,8 +288,8 @@ int mrp_ll_session_begin_sipp(mrp_ll_ctx* ctx, int32_t workgroups);
  * jobs of another algorithm come back as MRP_LL_BAD_JOB.  What the conflict-tree drivers use. */
 int mrp_ll_session_begin_algo(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups);
 /* An MRP_LL_ASTAR_EPS session as a PAIR of resident launches: `workgroups` front workgroups that run every search in the
- * LDS tier (1023 open entries, 64 time steps) and nothing else, and `heavy_workgroups` heavy ones with a 41.6 KB window
- * (4095 open entries, 128 time steps; the arena tier behind it) that take over — through a device-side queue, without the
+ * LDS tier (1023 open entries, 64 time steps) and nothing else, and `heavy_workgroups` heavy ones with a 31.4 KB window
+ * (3071 open entries, as many time steps as the arena slot holds — 512 by default; the arena tier behind it) that take over — through a device-side queue, without the
  * host — the searches that outgrow it.  Same jobs, same results as mrp_ll_session_begin_algo; the split keeps the long
  * searches out of the many small windows and gives them an LDS-resident tier of their own.
  * workgroups + heavy_workgroups <= mrp_ll_options.slots (each needs an arena slot).  If the heavy workgroups do not become
@@ -297,7 +297,7 @@ int mrp_ll_session_begin_algo(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups)
  * heavy_workgroups = 0 is that call. */
 int mrp_ll_session_begin_tiers(mrp_ll_ctx* ctx, int32_t algo, int32_t workgroups, int32_t heavy_workgroups);
 /* The same for SEVERAL contexts that begin their sessions on one device at the same time (one per host thread): a heavy
- * workgroup needs 41.6 KB of one CU's LDS in one piece, which no CU has left once the front workgroups of another context
+ * workgroup needs 31.4 KB of one CU's LDS in one piece, which no CU has left once the front workgroups of another context
  * have spread over the device.  Every caller passes the same `gate` (zero before the first call) and `parties` (the number
  * of callers): each launches its heavy workgroups, waits until they run, arrives at the gate, and launches its front
  * workgroups only when all parties have arrived (or 2 s have passed).  gate == NULL: no waiting. */

@@ -1071,12 +1071,18 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
       heavyPer = heavyTotal / nRun + (heavyTotal % nRun ? 1 : 0);
       if (heavyPer > 0) {
         const int32_t granule = 512;  // LDS allocation granularity
-        const int32_t fl = (frontLds + granule - 1) / granule * granule, hl = (heavyLds + granule - 1) / granule * granule;
+        // (a window beyond 32 KB takes room as if it had 64 KB — measured, ll_compact.h MRP_CT_WIDE_GROUPS)
+        const int32_t fl = (frontLds + granule - 1) / granule * granule;
+        const int32_t hl = heavyLds > 32768 ? 65536 : (heavyLds + granule - 1) / granule * granule;
         const int32_t cuLds = 160 * 1024;
         const int32_t frontBeside = std::max(0, (cuLds - hl) / fl);          // front workgroups on a CU that hosts a heavy one
-        const int32_t displaced = std::max(0, std::min(frontOcc, cuLds / fl) - frontBeside);
+        // (beyond five heavy workgroups per eight CUs some CUs get two, and the second one costs more: measured, 192 / 224 /
+        // 256 of them displace 3.6 front workgroups each, 160 exactly 3)
+        const int32_t displaced = std::max(0, std::min(frontOcc, cuLds / fl) - frontBeside) + (heavyPer * nRun > 160 ? 1 : 0);
         const int32_t frontTotal = 256 * std::min(frontOcc, cuLds / fl) - displaced * heavyPer * nRun;
-        sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots - heavyPer, frontTotal / nRun));
+        // (never more than fits: a grid the device cannot place completely blocks its hardware pipe, and a launch queued
+        // behind it — another worker's front workgroups — does not start until a resident kernel ends)
+        sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots - heavyPer, frontTotal / nRun - 2));
         if (sessionWgs + heavyPer > s->llOpt.slots || frontTotal <= 0) heavyPer = 0;  // (tiny engines: one launch serves all)
       }
     }

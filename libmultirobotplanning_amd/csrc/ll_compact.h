@@ -46,8 +46,8 @@ using namespace wv;
 // Two geometries of the same program (template parameter C of compactSearch):
 //   Narrow — the tier every search starts in: 1023 open entries, t <= 61, 12.9 KB of LDS with ten agents (12 searches per CU);
 //            entry  [31:23] 511 - focalH   [22:16] 127 - f   [15:10] g   [9:0] cell
-//   Wide   — the tier of the searches that outgrow it (the "heavy" resident workgroups, ll_kernel.hip): 4095 open entries,
-//            41.6 KB, and as many time steps as the job's arena slot has room for (CJob::rows, up to 958): its entry
+//   Wide   — the tier of the searches that outgrow it (the "heavy" resident workgroups, ll_kernel.hip): 3071 open entries,
+//            31.4 KB, and as many time steps as the job's arena slot has room for (CJob::rows, up to 958): its entry
 //            carries h instead of g —  [31:26] 63 - focalH   [25:16] 1023 - f   [15:10] 63 - h   [9:0] cell  — which orders
 //            the same way (equal f: g desc <=> h asc, f = g + h) and lets f span 10 bits; g = f - h, a state is named by
 //            (f, cell).  Its (time, cell) bitmap lives in device memory and is built 64 rows at a time, as t grows.
@@ -69,7 +69,7 @@ struct TierCfg {
   static constexpr uint32_t kAuxBytes = 512u * GROUPS + 32u;
   static constexpr uint32_t kAuxClamp = kAuxCap + 1u;          // odd; elements kAuxCap .. kAuxCap + 4 always hold kEmpty
   // time steps of the (time, cell) bitmap and of the cameFrom table; LONGT: of one chunk of rows (the job says how many rows)
-  static constexpr uint32_t kRows = LONGT ? 64u : (1u << L_BITS);
+  static constexpr uint32_t kRows = LONGT ? (kAuxBytes >= 64u * 128u ? 64u : 32u) : (1u << L_BITS);
   static constexpr uint32_t kFShift = 10u + L_BITS, kFhShift = 10u + L_BITS + F_BITS;
   static constexpr uint32_t kGMax = (1u << L_BITS) - 1u, kFMax = (1u << F_BITS) - 1u, kFhMax = (1u << FH_BITS) - 1u;
   static constexpr uint32_t kMO = ((1u << (F_BITS + L_BITS)) - 1u) << 10;  // open key:  f, g (or h)
@@ -112,7 +112,13 @@ struct TierCfg {
   static_assert(kMaxT + 1u + 62u <= kFMax - 3u, "f = g + h (h <= 62 on a 32 x 32 map) fits its field");
 };
 typedef TierCfg<4, 9, 7, 6> Narrow;
-typedef TierCfg<16, 6, 10, 6, true> Wide;
+// 12 groups = 3071 open entries in a 31.4 KB window.  (Measured on MI355X, scripts/r4_run10.sh / r4_run11.sh: a workgroup
+// with more than 32 KB of LDS takes room on its CU as if it had 64 KB — 16 groups, 41.6 KB, cost 5.2 narrow windows each
+// instead of 3 — so the window stays below; the largest open list seen on the benchmark shapes is 2787 entries.)
+#ifndef MRP_CT_WIDE_GROUPS
+#define MRP_CT_WIDE_GROUPS 12
+#endif
+typedef TierCfg<MRP_CT_WIDE_GROUPS, 6, 10, 6, true> Wide;
 // (names the hosting kernels and the host tests use: the narrow geometry)
 constexpr uint32_t kGroups = Narrow::kGroups, kCap = Narrow::kCap, kHeapBytes = Narrow::kHeapBytes, kAuxBytes = Narrow::kAuxBytes;
 constexpr uint32_t kRows = Narrow::kRows;

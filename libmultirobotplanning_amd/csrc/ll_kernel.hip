@@ -1011,7 +1011,7 @@ DEVI void hostStore32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOM
 //                 without heavy workgroups;
 //   kTiersFront — the compact (narrow) tier only: a search it cannot hold is handed to the heavy workgroups (runJob returns
 //                 true, nothing of the job has been reported); no arena-tier code in the kernel;
-//   kTiersHeavy — the compact tier in its WIDE geometry (4095 open entries, t <= 125, ll_compact.h), then the arena tier.
+//   kTiersHeavy — the compact tier in its WIDE geometry (3071 open entries, long horizons, ll_compact.h), then the arena tier.
 enum : int { kTiersAll = 0, kTiersFront = 1, kTiersHeavy = 2 };
 
 // Returns true when the job has to be handed to the heavy workgroups (kTiersFront only).
@@ -2735,8 +2735,8 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_persistent_kernel(L
 }
 // The front / heavy pair of an A*-epsilon session (ll_device.h heavy_q).  Front workgroups are the resident loop above
 // with the narrow compact tier alone — no arena-tier code, hence a smaller register allocation; heavy workgroups wait on
-// the device-side queue the front ones fill, run each search in the WIDE compact geometry (41.6 KB of LDS: open and focal
-// lists of 4095 entries, walk queue) and, beyond even that, in the arena tier.
+// the device-side queue the front ones fill, run each search in the WIDE compact geometry (31.4 KB of LDS: open and focal
+// lists of 3071 entries, walk queue) and, beyond even that, in the arena tier.
 extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_front_kernel(LaunchParams Parg) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   MRP_LL_WINDOW_BLOCKS(smem, jobS, resS);

@@ -24,7 +24,7 @@ int neighborIndexFromDelta(int dx, int dy) {  // Wait, Left, Right, Up, Down (ec
 extern "C" {
 
 // One low-level search through the compact tier (eps: 0 = A*, 1 = A*-epsilon, 2 = A*-epsilon with the bitmap in device
-// memory, ll_compact.h BG; 3 = the same in the WIDE geometry — 4095 open entries, t <= 510 — with the path table in
+// memory, ll_compact.h BG; 3 = the same in the WIDE geometry — 3071 open entries, t <= 510 — with the path table in
 // "device memory" too: what the heavy workgroups run).  Inputs as in include/mrp_ll.h's mrp_ll_job (constraints [n][3] / [n][5],
 // context paths flattened: path_len[n_agents], path_xy = all states back to back); lds_path_bytes = room for the focal
 // path table in the LDS window (a larger table is read from "global" memory, as on the device); open_cap / max_t > 0:

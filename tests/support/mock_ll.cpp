@@ -237,7 +237,7 @@ int mrp_ll_session_begin_tiers_gated(mrp_ll_ctx*, int32_t, int32_t, int32_t, int
 int mrp_ll_session_tiers_geometry(mrp_ll_ctx*, int32_t* occ, int32_t* front, int32_t* heavy) {
   if (occ) *occ = 12;
   if (front) *front = 12928;
-  if (heavy) *heavy = 41600;
+  if (heavy) *heavy = 31360;
   return MRP_LL_SUCCESS;
 }
 int mrp_ll_session_end(mrp_ll_ctx*) { return MRP_LL_SUCCESS; }

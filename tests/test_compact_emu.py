@@ -90,7 +90,7 @@ def _replay(L, oracle_mod, inst, algo, w, lds_path_bytes=2048, cap_total=-1, ope
 def emu(request):
     """The forms of the tier: the (time, cell) bitmap in the LDS window (CBS / mixed kernels), in device memory
     (ll_compact.h BG: the A*-epsilon-only kernels, whose window is 8 KB smaller), and the wide geometry of the heavy
-    workgroups (4095 open entries, t <= 125, other field widths; A*-epsilon only — its A* searches run the narrow form)."""
+    workgroups (3071 open entries, entries that carry h instead of g: long horizons; A*-epsilon only — its A* searches run the narrow form)."""
     L = _emu_lib()
     L._bg = request.param >= 1
     L._wide = request.param == 2

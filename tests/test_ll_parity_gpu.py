@@ -269,7 +269,7 @@ def test_session_mode_matches_oracle(oracle_mod, bench_instances):
 
 def test_front_and_heavy_workgroups(oracle_mod, bench_instances):
     """mrp_ll_session_begin_tiers: front workgroups (LDS tier only) hand the searches that outgrow their tier to heavy
-    workgroups (wide LDS tier: 4095 open entries, 128 time steps; arena tier behind it) through a device-side queue.
+    workgroups (wide LDS tier: 3071 open entries, long horizons; arena tier behind it) through a device-side queue.
     Same bits as the oracle whichever workgroup ran a search; the wide tier really takes the big ones, and the long ones (a
     198-step path through a serpentine: its entries carry h instead of g); the MRP_LL_JOB_HEAVY hint changes nothing."""
     from libmultirobotplanning_amd import ll
