@@ -167,9 +167,10 @@ def main():
 
     from libmultirobotplanning_amd import hl, sharding
     hc = usable_cpus()
-    # eight worker threads per GPU at most: each ECBS worker keeps two resident kernels (front + heavy workgroups) on
-    # streams of their own, and beyond ~20 hardware queues per process the device time-slices them
-    threads = args.threads or max(2, min(8, hc // max(1, world)))
+    # up to sixteen worker threads per GPU; the solver runs at most eight engines (each keeps two resident kernels — front
+    # + heavy workgroups — and beyond ~20 hardware queues per process the device time-slices them), worker threads beyond
+    # that share the engines two by two
+    threads = args.threads or max(2, min(16, hc // max(1, world)))
     solver = hl.BatchSolver(device=local_rank, n_threads=threads, slots=args.slots, lds_nodes=args.lds_nodes)
 
     B, K, W = args.instances, args.steps, args.warmup

@@ -320,6 +320,16 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* done);
  * many tickets are in flight.  Writes at most `cap` ticket ids to `tickets`, their number to *n. */
 int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* n);
 
+/* Session mode, TWO host threads on one context ("co-workers": the device serves about twenty resident kernels of a
+ * process well, a host core feeds about half a kernel's worth of conflict trees).  These two calls — and only these — may
+ * be made concurrently by the co-workers of a context; session_begin / session_end / everything else stay with one of
+ * them while the other is not inside a call.  `tag` (0 .. 3) names the caller: mrp_ll_poll_any_tagged hands out only the
+ * tickets submitted under the same tag (it still unpacks every finished job it comes across into its caller's result
+ * buffers, which must therefore stay valid until the ticket has been collected by its owner). */
+int mrp_ll_submit_tagged(mrp_ll_ctx* ctx, int32_t tag, int32_t n_jobs, const mrp_ll_job* jobs, mrp_ll_result* results,
+                         int32_t* ticket);
+int mrp_ll_poll_any_tagged(mrp_ll_ctx* ctx, int32_t tag, int32_t* tickets, int32_t cap, int32_t* n);
+
 /* ---- high-level conflict scans -----------------------------------------------------------
  * Environment::getFirstConflict (example/ecbs.cpp:401-452, example/cbs.cpp identical) and Environment::focalHeuristic
  * (example/ecbs.cpp:315-350) for a batch of solutions (conflict-tree nodes) in one kernel launch.

@@ -12,7 +12,7 @@ namespace mrp_hl {
 // Slot ids of the engine's device-resident path store (mrp_ll_path_store_reserve), handed out per worker thread.
 struct SlotPool {
   std::vector<int32_t> freed;
-  int32_t next = 0, cap = 0;
+  int32_t next = 0, cap = 0;  // slots next .. cap - 1 have never been handed out (a pool may own a sub-range of the store)
   int32_t take() {
     if (!freed.empty()) {
       const int32_t s = freed.back();

@@ -42,6 +42,7 @@ struct mrp_hl_solver {
   std::vector<mrp_ll_ctx*> engines;
   mrp_ll_options llOpt;
   std::string err;
+  int32_t nWorkers = 0;    // host worker threads the caller asked for (>= engines.size(): two may share an engine)
   int32_t nPreloaded = 0;  // live mrp_hl_preloaded objects (their maps are released with the last one)
   int32_t pathSlots = 0;   // slots of the engines' device path stores (0: not allocated)
 };
@@ -51,6 +52,13 @@ namespace {
 // A session loop gives up when nothing at all has come back for this long (a dead resident kernel is reported much
 // sooner by mrp_ll_poll_any's own liveness check).
 constexpr double kNoProgressLimitS = 600.0;
+
+// Two workers on one engine ("co-workers", mrp_ll.h mrp_ll_submit_tagged): the leader (index 0) begins and ends the
+// session, the other one waits for it on both sides.
+struct CoSync {
+  std::atomic<int32_t> begun{0};     // 1: the session runs, -1: it could not be started
+  std::atomic<int32_t> finished{0};  // co-workers that have left their loops
+};
 
 struct GroupResult {
   int64_t rounds = 0, searches = 0, expansions = 0;  // expansions: of the searches the conflict trees CONSUMED
@@ -299,7 +307,9 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
                      const std::vector<int32_t>& idx, const std::vector<int32_t>& mapIds, int32_t horizon,
                      int32_t workgroups, int32_t pathSlots, GroupResult& out, std::atomic<int32_t>* shared = nullptr,
                      int32_t nTotal = 0, int32_t mapBase = 0, int32_t nWorkersIn = 1, int32_t heavyWgs = 0,
-                     int32_t* gate = nullptr) {
+                     int32_t* gate = nullptr, int32_t nEngines = 1, int32_t coIndex = 0, int32_t coCount = 1,
+                     CoSync* co = nullptr) {
+  const bool shared2 = coCount > 1 && co != nullptr;  // this engine has two workers: tagged calls only
   const size_t nWorkers = static_cast<size_t>(std::max(nWorkersIn, 1));
   const size_t n = shared ? static_cast<size_t>(nTotal) : idx.size();
   struct Live {
@@ -327,7 +337,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   // f2: slots of the engine's device-resident path store, handed to the searches of this worker for their result paths;
   // declared before `live` so that it outlives every Path that returns its slot to it
   SlotPool slotPool;
-  slotPool.cap = pathSlots;
+  slotPool.next = shared2 ? coIndex * (pathSlots / coCount) : 0;  // co-workers split the engine's path store
+  slotPool.cap = shared2 ? slotPool.next + pathSlots / coCount : pathSlots;
   std::vector<int32_t> idPool;
   std::vector<size_t> idOff;
   std::vector<uint8_t> idOk;
@@ -355,11 +366,26 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   auto tg0 = std::chrono::steady_clock::now();
   // ECBS: front workgroups (the LDS tier alone) + heavy workgroups that take over the searches that outgrow it; all
   // workers' heavy launches go first (the gate), then the front ones (mrp_ll.h mrp_ll_session_begin_tiers_gated)
-  if (mrp_ll_session_begin_tiers_gated(ctx, opt.algo == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR, workgroups,
-                                       opt.algo == MRP_HL_ECBS ? heavyWgs : 0, gate, nWorkersIn) != MRP_LL_SUCCESS) {
-    out.err = std::string("mrp_ll_session_begin_tiers: ") + mrp_ll_last_error(ctx);
-    return;
+  if (!shared2 || coIndex == 0) {
+    if (mrp_ll_session_begin_tiers_gated(ctx, opt.algo == MRP_HL_ECBS ? MRP_LL_ASTAR_EPS : MRP_LL_ASTAR, workgroups,
+                                         opt.algo == MRP_HL_ECBS ? heavyWgs : 0, gate, nEngines) != MRP_LL_SUCCESS) {
+      out.err = std::string("mrp_ll_session_begin_tiers: ") + mrp_ll_last_error(ctx);
+      if (co) co->begun.store(-1, std::memory_order_release);
+      return;
+    }
+    if (co) co->begun.store(1, std::memory_order_release);
+  } else {
+    int32_t b;
+    while ((b = co->begun.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+    if (b < 0) {
+      out.err = "the engine's session could not be started (see the leading worker)";
+      return;
+    }
   }
+  auto llSubmit = [&](int32_t nJ, const mrp_ll_job* jj, mrp_ll_result* rr, int32_t* tk) {
+    return shared2 ? mrp_ll_submit_tagged(ctx, coIndex, nJ, jj, rr, tk) : mrp_ll_submit(ctx, nJ, jj, rr, tk);
+  };
+  const int32_t myWorkgroups = std::max(1, workgroups / std::max(coCount, 1));  // this worker's share of the resident wavefronts
   size_t ticketsOut = 0;
   int64_t jobsOut = 0, ranExpansions = 0;
   // Submits the first group of live[k]'s unsent requests.  Returns 1 submitted, 0 ring full (retry later), -1 error.
@@ -438,7 +464,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
         std::memset(&P.res[0], 0, sizeof(mrp_ll_result));
         P.res[0].chain_results = P.chainRes.data();
         int32_t ticket = -1;
-        int rc = mrp_ll_submit(ctx, 1, &j, P.res.data(), &ticket);
+        int rc = llSubmit(1, &j, P.res.data(), &ticket);
         if (rc != MRP_LL_SUCCESS) {
           for (int32_t sl : P.outSlot) slotPool.give(sl);
           P.chainFirst = -1;
@@ -503,7 +529,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       P.res[q].states_cap = cap;
     }
     int32_t ticket = -1;
-    int rc = mrp_ll_submit(ctx, static_cast<int32_t>(jobs.size()), jobs.data(), P.res.data(), &ticket);
+    int rc = llSubmit(static_cast<int32_t>(jobs.size()), jobs.data(), P.res.data(), &ticket);
     if (rc != MRP_LL_SUCCESS)
       for (int32_t sl : P.outSlot) slotPool.give(sl);
     if (rc == MRP_LL_E_BUSY) {
@@ -534,7 +560,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   // rounds starts within one job time instead of queueing behind thousands of searches of easy instances, so the
   // chain costs its compute time and not rounds x queue length (that, not throughput, bounded a step before).  Fresh
   // instances have priority 0 and are admitted only when nothing older is waiting.
-  int64_t ringTarget = std::max<int64_t>(2 * static_cast<int64_t>(workgroups), 32);
+  int64_t ringTarget = std::max<int64_t>(2 * static_cast<int64_t>(myWorkgroups), 32);
   if (const char* e = std::getenv("MRP_HL_RING_DEPTH"))
     if (std::atoll(e) > 0) ringTarget = std::atoll(e);  // tuning knob
   typedef std::pair<int64_t, size_t> Waiting;  // (priority, live index)
@@ -606,7 +632,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     return true;
   };
   // look ahead only while the engine has idle wavefronts: speculative searches must not queue in front of real ones
-  auto specNow = [&]() -> int32_t { return jobsOut < static_cast<int64_t>(workgroups) ? specK : 1; };
+  auto specNow = [&]() -> int32_t { return jobsOut < static_cast<int64_t>(myWorkgroups) ? specK : 1; };
   // A finished instance is written out and FREED here, inside the loop, where the host has slack and the device is busy:
   // the paths, constraint sets and heaps of 16 384 instances are ~1e6 heap blocks per worker, and freeing them after
   // the loop was 70-130 ms of a 930 ms step with the GPU idle (measured, MRP_HL_TIMING).  Searches of the instance that
@@ -675,7 +701,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     tmSubmit += secsS(tA, tB);
     // harvest: one pass over the ring's completion words, whatever the number of instances in flight
     int32_t nDone = 0;
-    if (mrp_ll_poll_any(ctx, doneTickets.data(), static_cast<int32_t>(doneTickets.size()), &nDone) != MRP_LL_SUCCESS) {
+    if ((shared2 ? mrp_ll_poll_any_tagged(ctx, coIndex, doneTickets.data(), static_cast<int32_t>(doneTickets.size()), &nDone)
+                 : mrp_ll_poll_any(ctx, doneTickets.data(), static_cast<int32_t>(doneTickets.size()), &nDone)) != MRP_LL_SUCCESS) {
       out.err = std::string("mrp_ll_poll_any: ") + mrp_ll_last_error(ctx);
       failed = true;
       break;
@@ -803,10 +830,15 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     }
   }
   auto tg3 = std::chrono::steady_clock::now();
-  if (mrp_ll_session_end(ctx) != MRP_LL_SUCCESS && out.err.empty())
+  if (shared2) {  // the leader ends the session when every co-worker has left its loop
+    co->finished.fetch_add(1, std::memory_order_acq_rel);
+    if (coIndex == 0)
+      while (co->finished.load(std::memory_order_acquire) < coCount) std::this_thread::yield();
+  }
+  if ((!shared2 || coIndex == 0) && mrp_ll_session_end(ctx) != MRP_LL_SUCCESS && out.err.empty())
     out.err = std::string("mrp_ll_session_end: ") + mrp_ll_last_error(ctx);
   auto tg4 = std::chrono::steady_clock::now();
-  if (timing) {
+  if (timing && (!shared2 || coIndex == 0)) {
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double, std::milli>(b - a).count();
     };
@@ -861,15 +893,23 @@ int mrp_hl_solver_create(int32_t device, int32_t nThreads, const mrp_ll_options*
   *out = nullptr;
   if (nThreads <= 0) {
     unsigned hc = std::thread::hardware_concurrency();
-    // eight: an ECBS worker keeps two resident kernels, and the device time-slices a process's hardware queues — idle
-    // ones included — beyond about twenty (solve_preloaded); eight workers feed 0.96 of what sixteen do
-    nThreads = static_cast<int32_t>(hc ? std::min<unsigned>(hc, 8) : 8);
+    nThreads = static_cast<int32_t>(hc ? std::min<unsigned>(hc, 16) : 8);
   }
+  // Engines: at most eight.  An engine of an ECBS batch keeps two resident kernels (front + heavy workgroups), and the
+  // device time-slices a process's hardware queues — idle ones included — beyond about twenty (measured: the LDS tier's
+  // 2.0 us per expansion becomes 2.5 with 24 streams in the process, 3.1 with 32).  Worker threads beyond the engines
+  // share them two by two (co-workers, mrp_ll.h mrp_ll_submit_tagged): host cores feed conflict trees, engines feed the
+  // device.
+  int32_t maxEngines = 8;
+  if (const char* e = std::getenv("MRP_HL_MAX_ENGINES")) maxEngines = std::max(1, std::atoi(e));
+  const int32_t nWorkers = nThreads;
+  nThreads = std::min(nThreads, maxEngines);
   // One HIP stream (= one resident kernel) per worker: each needs its own hardware queue, the ROCm default is 4.  Only
   // effective if the HIP runtime has not been initialised yet in this process; never overrides the caller.
   (void)setenv("GPU_MAX_HW_QUEUES", "64", 0);
   auto* s = new mrp_hl_solver();
   s->device = device;
+  s->nWorkers = nWorkers;
   std::memset(&s->llOpt, 0, sizeof(s->llOpt));
   if (llOpt) s->llOpt = *llOpt;
   s->llOpt.device = device;
@@ -1049,19 +1089,9 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   // front tier — 6 % of the expansions at ten agents, 17 % at a hundred, scripts/search_stats.py).  One takes the LDS of
   // `displaced` front workgroups; five eighths / three quarters / all of the CUs get one.
   int32_t heavyPer = 0;
-  // Workers that run: each keeps TWO resident kernels then, and beyond ~16 resident kernels of one process the device
-  // time-slices its hardware queues (measured: the LDS tier's 2.0 us per expansion becomes 2.5 with 24 kernels, 3.1 with
-  // 32) — so at most eight workers drive such a batch (MRP_HL_PAIR_THREADS); eight feed 0.96 of what sixteen do.
-  int32_t nRun = nThreads;
+  const int32_t nRun = nThreads;  // engines of this batch
   const bool sharedPoolMode = std::getenv("MRP_HL_STATIC_SPLIT") == nullptr;
   if (opt.algo == MRP_HL_ECBS && opt.mode != 1 && !s->engines.empty() && s->llOpt.lds_nodes >= 0) {
-    int32_t pairThreads = 8;
-    if (const char* e = std::getenv("MRP_HL_PAIR_THREADS")) pairThreads = std::max(1, std::atoi(e));
-    const bool wantHeavy = !(std::getenv("MRP_HL_HEAVY_WGS") && std::atoi(std::getenv("MRP_HL_HEAVY_WGS")) == 0);
-    if (wantHeavy && sharedPoolMode) nRun = std::min(nThreads, pairThreads);
-  }
-  if (opt.algo == MRP_HL_ECBS && opt.mode != 1 && !s->engines.empty() && s->llOpt.lds_nodes >= 0 &&
-      (sharedPoolMode || nThreads <= 8)) {
     int32_t frontOcc = 0, frontLds = 0, heavyLds = 0;
     if (mrp_ll_session_tiers_geometry(s->engines[0], &frontOcc, &frontLds, &heavyLds) == MRP_LL_SUCCESS && frontOcc > 0 &&
         frontLds > 0) {
@@ -1086,10 +1116,6 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
         if (sessionWgs + heavyPer > s->llOpt.slots || frontTotal <= 0) heavyPer = 0;  // (tiny engines: one launch serves all)
       }
     }
-  }
-  if (heavyPer == 0 && nRun != nThreads) {  // no pair after all: every worker runs, with the single launch's share
-    nRun = nThreads;
-    sessionWgs = std::max(16, std::min<int32_t>(s->llOpt.slots, (256 * occupancy) / nThreads));
   }
   if (const char* e = std::getenv("MRP_HL_SESSION_WGS")) sessionWgs = std::max(1, std::atoi(e));  // tuning knob
   // f2: the engines' device-resident path stores (ECBS only: CBS's low level has no focal context).  A search leaves its
@@ -1122,18 +1148,30 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   auto t0 = std::chrono::steady_clock::now();
   batchEpoch() = t0;
   {
+    // session mode with the shared pool: worker threads beyond the engines join them as co-workers, two per engine
+    int32_t nWork = nRun;
+    if (opt.mode != 1 && sharedPool) {
+      int32_t want = s->nWorkers;
+      if (const char* e = std::getenv("MRP_HL_WORKERS")) want = std::max(1, std::atoi(e));  // tuning knob
+      nWork = std::max(nRun, std::min(want, 2 * nRun));
+      nWork = std::min(nWork, std::max(nRun, nInst));
+    }
+    gr.resize(static_cast<size_t>(nWork));
+    std::vector<CoSync> coSync(static_cast<size_t>(nRun));
     std::vector<std::thread> th;
-    for (int32_t t = 0; t < (opt.mode == 1 ? nThreads : nRun); ++t)
+    for (int32_t t = 0; t < nWork; ++t)
       th.emplace_back([&, t]() {
         pinWorker(t);
+        const int32_t e = t % nRun, coIndex = t / nRun, coCount = 1 + (e + nRun < nWork ? 1 : 0);
         if (opt.mode == 1)
           runGroup(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, gr[t]);
         else if (sharedPool)
-          runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, pathSlots,
-                          gr[t], &nextInstance, nInst, pre->mapBase[t], nRun, heavyPer, &sessionGate);
+          runGroupSession(s->engines[e], opt, instances, solutions, idx[e], mapIds[e], horizon, sessionWgs, pathSlots,
+                          gr[t], &nextInstance, nInst, pre->mapBase[e], nWork, heavyPer, &sessionGate, nRun, coIndex, coCount,
+                          coCount > 1 ? &coSync[e] : nullptr);
         else
           runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, pathSlots,
-                          gr[t], nullptr, 0, 0, nRun, heavyPer, &sessionGate);
+                          gr[t], nullptr, 0, 0, nRun, heavyPer, &sessionGate, nRun);
       });
     for (auto& x : th) x.join();
   }

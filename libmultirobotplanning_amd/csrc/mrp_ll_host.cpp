@@ -9,6 +9,8 @@
 #include <climits>
 #include <cstring>
 #include <ctime>
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -207,6 +209,7 @@ static inline void pushFence(const Ring& g) {
 struct SessTicket {
   bool used = false;
   int32_t lane = 0;
+  int32_t tag = -1;                // mrp_ll_submit_tagged: which of the context's co-workers the ticket belongs to (-1: untagged)
   int32_t n = 0, remaining = 0;
   mrp_ll_result* res = nullptr;
   std::vector<uint8_t> state;      // per job: 0 pending, 1 consumed, 2 rejected on the host
@@ -241,6 +244,11 @@ struct mrp_ll_ctx {
   Ring ring;
   std::vector<SessTicket> sess;
   std::vector<int32_t> sessFree;   // free session-ticket ids (stack)
+  // co-workers (mrp_ll_submit_tagged / mrp_ll_poll_any_tagged): two host threads that share this context's session
+  static constexpr int kMaxTags = 4;
+  std::mutex coMu;
+  std::vector<int32_t> coStash[kMaxTags];        // finished tickets another co-worker's poll has come across (not released yet)
+  std::atomic<int32_t> coStashCount[kMaxTags];
   void* sippScratch = nullptr;     // SippScratch, created on first use (packSipp)
   // device-resident SIPP tables: chunks of sippTabsPerChunk tables of sippTabStride bytes each (about 64 MB a chunk)
   std::vector<uint8_t*> sippTabChunks;
@@ -1453,6 +1461,10 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
   g.slotChain.assign(R, 0);
   ctx->sess.clear();
   ctx->sessFree.clear();
+  for (int q = 0; q < mrp_ll_ctx::kMaxTags; ++q) {
+    ctx->coStash[q].clear();
+    ctx->coStashCount[q].store(0, std::memory_order_relaxed);
+  }
   auto devPtr = [&](void* hostPtr) {
     const uint8_t* b = static_cast<const uint8_t*>(hostPtr);
     if (g.pushInDevice && b >= g.push && b < g.push + g.pushBytes)
@@ -1846,18 +1858,18 @@ int mrp_ll_poll(mrp_ll_ctx* ctx, int32_t ticket, int32_t* doneOut) {
   return MRP_LL_SUCCESS;
 }
 
-int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOut) {
-  if (!ctx || !tickets || !nOut || cap <= 0) return MRP_LL_E_INVALID;
+// Drains the completion queue: every finished job is unpacked into its caller's result; a ticket whose last job this was
+// goes to `tickets` (tag < 0: all of them; else: those of this co-worker, the others wait in their owner's stash).
+static int32_t drainCompletions(mrp_ll_ctx* ctx, int32_t tag, int32_t* tickets, int32_t cap) {
   Ring& g = ctx->ring;
-  if (!g.active) return MRP_LL_E_INVALID;
   const uint32_t R = Ring::kSlots;
   int32_t n = 0;
-  sessionBeat(g);
   // drain the completion queue: entry k holds (k / R + 1) << 11 | slot once the k-th finished job has been published
   while (n < cap) {
-    const uint32_t e = __atomic_load_n(g.compRing + (g.compCursor % R), __ATOMIC_ACQUIRE);
-    if ((e >> mrp::kRingSlotBits) != static_cast<uint32_t>(g.compCursor / R) + 1) break;
-    g.compCursor += 1;
+    const uint64_t cursor = g.compCursor;
+    const uint32_t e = __atomic_load_n(g.compRing + (cursor % R), __ATOMIC_ACQUIRE);
+    if ((e >> mrp::kRingSlotBits) != static_cast<uint32_t>(cursor / R) + 1) break;
+    __atomic_store_n(&g.compCursor, cursor + 1, __ATOMIC_RELAXED);
     const uint32_t slot = e & mrp::kRingSlotMask;
     if (!g.busy[slot]) continue;  // already consumed through mrp_ll_poll / mrp_ll_wait
     // ... and if the slot has been re-used since, this entry is stale: only the occupant's own done word counts
@@ -1881,11 +1893,71 @@ int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOu
     g.inFlightJobs -= 1;
     g.freeSlots.push_back(slot);
     if (st.remaining == 0) {
-      st.used = false;
-      ctx->sessFree.push_back(g.slotTicket[slot]);
-      tickets[n++] = g.slotTicket[slot];
+      const int32_t id = g.slotTicket[slot];
+      if (tag >= 0 && st.tag != tag && st.tag >= 0 && st.tag < mrp_ll_ctx::kMaxTags) {
+        ctx->coStash[st.tag].push_back(id);  // its owner collects (and releases) it
+        ctx->coStashCount[st.tag].fetch_add(1, std::memory_order_release);
+      } else {
+        st.used = false;
+        ctx->sessFree.push_back(id);
+        tickets[n++] = id;
+      }
     }
   }
+  return n;
+}
+
+int mrp_ll_poll_any(mrp_ll_ctx* ctx, int32_t* tickets, int32_t cap, int32_t* nOut) {
+  if (!ctx || !tickets || !nOut || cap <= 0) return MRP_LL_E_INVALID;
+  Ring& g = ctx->ring;
+  if (!g.active) return MRP_LL_E_INVALID;
+  sessionBeat(g);
+  const int32_t n = drainCompletions(ctx, -1, tickets, cap);
+  *nOut = n;
+  if (n != 0) {
+    g.emptyPolls = 0;
+    return MRP_LL_SUCCESS;
+  }
+  return sessionAlive(ctx);
+}
+
+int mrp_ll_submit_tagged(mrp_ll_ctx* ctx, int32_t tag, int32_t nJobs, const mrp_ll_job* jobs, mrp_ll_result* results,
+                         int32_t* ticketOut) {
+  if (!ctx || !ticketOut || tag < 0 || tag >= mrp_ll_ctx::kMaxTags || nJobs < 0 || (nJobs > 0 && (!jobs || !results)))
+    return MRP_LL_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->coMu);
+  if (!ctx->ring.active) return MRP_LL_E_INVALID;
+  const int rc = sessionSubmit(ctx, 0, nJobs, jobs, results, ticketOut);
+  if (rc == MRP_LL_SUCCESS) ctx->sess[*ticketOut].tag = tag;
+  return rc;
+}
+
+int mrp_ll_poll_any_tagged(mrp_ll_ctx* ctx, int32_t tag, int32_t* tickets, int32_t cap, int32_t* nOut) {
+  if (!ctx || !tickets || !nOut || cap <= 0 || tag < 0 || tag >= mrp_ll_ctx::kMaxTags) return MRP_LL_E_INVALID;
+  Ring& g = ctx->ring;
+  *nOut = 0;
+  // a look without the lock: nothing stashed for this co-worker, nothing new in the completion queue
+  if (ctx->coStashCount[tag].load(std::memory_order_acquire) == 0) {
+    const uint64_t cursor = __atomic_load_n(&g.compCursor, __ATOMIC_RELAXED);
+    const uint32_t e = __atomic_load_n(g.compRing + (cursor % Ring::kSlots), __ATOMIC_ACQUIRE);
+    const uint64_t tsc = __builtin_ia32_rdtsc();
+    const bool beatDue = tsc - __atomic_load_n(&g.lastBeatTsc, __ATOMIC_RELAXED) >= (1ull << 24);
+    if ((e >> mrp::kRingSlotBits) != static_cast<uint32_t>(cursor / Ring::kSlots) + 1 && !beatDue) return MRP_LL_SUCCESS;
+  }
+  std::lock_guard<std::mutex> lock(ctx->coMu);
+  if (!g.active) return MRP_LL_E_INVALID;
+  sessionBeat(g);
+  int32_t n = 0;
+  std::vector<int32_t>& mine = ctx->coStash[tag];
+  while (n < cap && !mine.empty()) {
+    const int32_t id = mine.back();
+    mine.pop_back();
+    ctx->coStashCount[tag].fetch_sub(1, std::memory_order_relaxed);
+    ctx->sess[id].used = false;
+    ctx->sessFree.push_back(id);
+    tickets[n++] = id;
+  }
+  n += drainCompletions(ctx, tag, tickets + n, cap - n);
   *nOut = n;
   if (n != 0) {
     g.emptyPolls = 0;

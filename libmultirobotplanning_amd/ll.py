@@ -71,7 +71,7 @@ EXPORTS = ["mrp_ll_create", "mrp_ll_destroy", "mrp_ll_last_error", "mrp_ll_uploa
            "mrp_ll_configure_tiers", "mrp_ll_session_occupancy", "mrp_ll_session_begin_sipp", "mrp_ll_release_maps", "mrp_ll_session_begin_algo", "mrp_ll_conflict_scan",
            "mrp_ll_sipp_table_create", "mrp_ll_sipp_table_add", "mrp_ll_sipp_table_destroy", "mrp_ll_path_store_reserve",
            "mrp_ll_upload_heuristic", "mrp_ll_session_begin_tiers", "mrp_ll_session_tiers_geometry",
-           "mrp_ll_session_begin_tiers_gated"]
+           "mrp_ll_session_begin_tiers_gated", "mrp_ll_submit_tagged", "mrp_ll_poll_any_tagged"]
 
 _lib = None
 

@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/mrp_ll.h"
@@ -176,6 +178,30 @@ int mrp_ll_submit(mrp_ll_ctx* c, int32_t n, const mrp_ll_job* jobs, mrp_ll_resul
 }
 int mrp_ll_submit_lane(mrp_ll_ctx* c, int32_t, int32_t n, const mrp_ll_job* jobs, mrp_ll_result* res, int32_t* ticket) {
   return mrp_ll_submit(c, n, jobs, res, ticket);
+}
+// co-workers: two host threads on one context (mrp_ll.h); finished tickets wait per tag
+namespace {
+std::mutex g_coMu;
+std::map<mrp_ll_ctx*, std::vector<int32_t>> g_coDone[4];
+}  // namespace
+int mrp_ll_submit_tagged(mrp_ll_ctx* c, int32_t tag, int32_t n, const mrp_ll_job* jobs, mrp_ll_result* res, int32_t* ticket) {
+  if (tag < 0 || tag > 3) return MRP_LL_E_INVALID;
+  std::lock_guard<std::mutex> lock(g_coMu);
+  *ticket = c->nextTicket++ & 0xFFFF;
+  g_coDone[tag][c].push_back(*ticket);
+  return mrp_ll_search_batch(c, n, jobs, res);
+}
+int mrp_ll_poll_any_tagged(mrp_ll_ctx* c, int32_t tag, int32_t* tickets, int32_t cap, int32_t* n) {
+  if (tag < 0 || tag > 3) return MRP_LL_E_INVALID;
+  std::lock_guard<std::mutex> lock(g_coMu);
+  std::vector<int32_t>& d = g_coDone[tag][c];
+  int32_t k = 0;
+  while (!d.empty() && k < cap && k < 3) {  // a few at a time, newest first: out of submission order
+    tickets[k++] = d.back();
+    d.pop_back();
+  }
+  *n = k;
+  return MRP_LL_SUCCESS;
 }
 // MRP_MOCK_SHUFFLE=<seed>: completed tickets are reported a few at a time in a pseudo-random order, so that the drivers
 // see the groups of one instance come back out of submission order (as they do on the GPU).

@@ -60,6 +60,29 @@ def test_ecbs_batch_matches_oracle(cpu_solver, bench_instances, oracle_expected)
     assert stats["ll_expansions"] == sum(r["ll_expanded"] for r in res)
 
 
+def test_co_workers_share_an_engine(cpu_solver, bench_instances, oracle_expected):
+    """Five worker threads on two engines (mrp_ll_submit_tagged / mrp_ll_poll_any_tagged: two or three... two co-workers per
+    engine, the fifth thread stays out): same results, every instance solved exactly once."""
+    from libmultirobotplanning_amd import hl
+    names = [n for n in sorted(bench_instances) if "32by32" in n and ("agents10_" in n or "agents20_" in n)][:80]
+    os.environ["MRP_HL_MAX_ENGINES"] = "2"
+    try:
+        s = hl.BatchSolver(device=0, n_threads=5, _lib_path=os.path.join(BUILD, "libmrp_hl_cpu.so"))
+    finally:
+        del os.environ["MRP_HL_MAX_ENGINES"]
+    try:
+        for rep in range(2):
+            res, stats = s.solve([bench_instances[n] for n in names], algo=hl.ECBS, w=1.3)
+            for n, r in zip(names, res):
+                e = oracle_expected[n]["ecbs_w1.3"]
+                assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
+                    hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"]), n
+                assert _digest(r["paths"]) == e["digest"], n
+            assert stats["ll_expansions"] == sum(r["ll_expanded"] for r in res)
+    finally:
+        s.close()
+
+
 def test_cbs_batch_matches_oracle(cpu_solver, bench_instances, oracle_expected):
     from libmultirobotplanning_amd import hl
     names = [n for n in sorted(bench_instances) if "8by8" in n and oracle_expected[n]["cbs"]["rc"] == 1]
