@@ -81,6 +81,9 @@ typedef struct mrp_hl_batch_stats {
   /* look-ahead of the conflict-tree machines (session mode; MRP_HL_SPEC): searches issued before their CT node was popped,
    * and the expansions of searches that were run but whose node was never popped (work, not part of ll_expansions) */
   int64_t speculative_searches, wasted_ll_expansions;
+  /* ECBS sessions: instances whose root node had no conflict — found by the workgroup that ran the root chain
+   * (mrp_ll.h MRP_LL_JOB_ROOT_CHAIN) — and whose solution was written without a conflict-tree object */
+  int64_t root_solved;
 } mrp_hl_batch_stats;
 
 /* One engine context per calling thread is created internally for every worker thread on `device`. */

@@ -158,7 +158,12 @@ typedef struct mrp_ll_job {
  * agent order: the chain ends BEHIND an agent whose search found no path or exceeded the budget, and IN FRONT OF one
  * whose search outgrows the LDS tier — that one and every later agent come back as MRP_LL_NOT_RUN and are the caller's to
  * submit as ordinary jobs (or as another chain).  The job's own n_states = results filled in, expanded = their sum.
- * Every filled-in result is exactly what the ordinary job for that agent would have returned. */
+ * Every filled-in result is exactly what the ordinary job for that agent would have returned.
+ * When agent_idx == 0 and every agent got a path, the workgroup — which holds the whole root solution in LDS — also scans
+ * it for conflicts (Environment::getFirstConflict ecbs.cpp:401-452, focalHeuristic ecbs.cpp:315-350): the job's own
+ * cost = number of conflicts (0: the root node is the solution, the conflict tree has nothing to do) and fmin = the first
+ * one as  time << 24 | type << 16 | agent1 << 8 | agent2  (type 0 vertex / 1 edge), or -1 if there is none; both are -1
+ * when the scan did not take place. */
 #define MRP_LL_JOB_ROOT_CHAIN 4
 /* MRP_LL_JOB_HEAVY (hint, MRP_LL_ASTAR_EPS): the caller knows that this search outgrows the LDS tier every search starts in
  * (e.g. a root chain ended in front of it): no attempt is made there.  Results never depend on it. */

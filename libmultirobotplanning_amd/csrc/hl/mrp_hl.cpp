@@ -63,6 +63,7 @@ struct CoSync {
 struct GroupResult {
   int64_t rounds = 0, searches = 0, expansions = 0;  // expansions: of the searches the conflict trees CONSUMED
   int64_t specSearches = 0, specWasted = 0;          // searches issued ahead of their node's pop; expansions that were run but never consumed
+  int64_t rootSolved = 0;                            // instances whose root node was conflict-free, written out without a conflict tree
   double buildS = 0, llS = 0, consumeS = 0;
   std::string err;
 };
@@ -168,6 +169,40 @@ void writeSolution(const Instance& I, mrp_hl_solution& s) {
       }
     }
   }
+}
+
+// The solution of an instance whose ROOT node has no conflict, written straight from the results of its root chain
+// (mrp_ll.h MRP_LL_JOB_ROOT_CHAIN: the workgroup that planned the agents also scanned their paths): what ECBS::search
+// returns when the first node it pops is conflict-free (ecbs.hpp:227-240) — cost = sum of the agents' costs, one
+// high-level expansion — without building a single conflict-tree object.
+void writeRootSolution(const std::vector<mrp_ll_result>& r, mrp_hl_solution& s) {
+  s.status = MRP_HL_SOLVED;
+  s.n_ll_searches = static_cast<int32_t>(r.size());
+  s.high_level_expanded = 1;
+  s.low_level_expanded = 0;
+  s.cost = 0;
+  s.makespan = 0;
+  uint64_t h = 14695981039346656037ull;
+  for (size_t a = 0; a < r.size(); ++a) {
+    s.cost += r[a].cost;
+    s.makespan = std::max<int64_t>(s.makespan, r[a].cost);
+    s.low_level_expanded += r[a].expanded;
+    const int32_t n = r[a].n_states;
+    const int32_t* q = r[a].states_txy;
+    if (s.path_len) s.path_len[a] = n;
+    int32_t* dst = s.paths_xy ? s.paths_xy + a * static_cast<size_t>(s.path_cap) * 2 : nullptr;
+    for (int32_t k = 0; k < n; ++k) {
+      const uint32_t x = static_cast<uint32_t>(q[3 * k + 1]), y = static_cast<uint32_t>(q[3 * k + 2]);
+      h = (h ^ (x & 0xFFu)) * 1099511628211ull;
+      h = (h ^ (y & 0xFFu)) * 1099511628211ull;
+      if (dst && k < s.path_cap) {
+        dst[2 * k] = static_cast<int32_t>(x);
+        dst[2 * k + 1] = static_cast<int32_t>(y);
+      }
+    }
+    h = (h ^ 0xFFu) * 1099511628211ull;
+  }
+  s.schedule_digest = h;
 }
 
 // Speculation width of the conflict-tree machines (ct_solver.hpp): MRP_HL_SPEC=k.  Default 2: measured on the shipped
@@ -362,6 +397,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   bool rootChains = pathSlots > 0 && opt.algo == MRP_HL_ECBS &&
                     !(std::getenv("MRP_HL_ROOT_CHAIN") && std::atoi(std::getenv("MRP_HL_ROOT_CHAIN")) == 0);
   const bool timing = std::getenv("MRP_HL_TIMING") != nullptr;
+  // MRP_HL_ROOT_FAST=0: every instance goes through its conflict-tree machine (A/B; results are the same)
+  const bool rootFastPath = !(std::getenv("MRP_HL_ROOT_FAST") && std::atoi(std::getenv("MRP_HL_ROOT_FAST")) == 0);
   const int32_t specK = specWidthSetting();
   auto tg0 = std::chrono::steady_clock::now();
   // ECBS: front workgroups (the LDS tier alone) + heavy workgroups that take over the searches that outgrow it; all
@@ -750,6 +787,33 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
           break;
         }
         const size_t cnt = P.chainRes.size();
+        // The chain planned every agent and its workgroup found no conflict among the paths: the root node is the
+        // solution.  Seven ten-agent instances in ten end here, without a path object, a conflict-tree node or a scan.
+        if (rootFastPath && P.chainFirst == 0 && L.inst && !L.counted && static_cast<size_t>(P.res[0].n_states) == cnt &&
+            P.res[0].cost == 0 && static_cast<int32_t>(cnt) == L.inst->nAgents() && L.inst->llSearches() == 0 &&
+            (opt.max_hl_expansions < 0 || opt.max_hl_expansions >= 1)) {
+          writeRootSolution(P.chainRes, sols[gidx[k]]);
+          int64_t ll = 0;
+          for (const mrp_ll_result& r : P.chainRes) ll += r.expanded;
+          ranExpansions += ll;
+          out.searches += static_cast<int64_t>(cnt);
+          out.expansions += ll;
+          out.rootSolved += 1;
+          L.counted = true;
+          nActive -= 1;
+          L.hl = 1;
+          L.ll = ll;
+          L.searches = static_cast<int32_t>(cnt);
+          if (timing) L.tDone = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
+          L.req.clear();
+          L.reqHead = 0;
+          L.inst.reset();
+          for (int32_t sl : P.outSlot) slotPool.give(sl);
+          P.chainFirst = -1;
+          P.chainReq.clear();
+          pendFree.push_back(donePend[d]);
+          continue;
+        }
         size_t q = 0;
         for (; q < cnt; ++q) {
           const mrp_ll_result& r = P.chainRes[q];
@@ -1189,6 +1253,7 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
     st.ll_expansions += g.expansions;
     st.speculative_searches += g.specSearches;
     st.wasted_ll_expansions += g.specWasted;
+    st.root_solved += g.rootSolved;
     st.build_seconds += g.buildS;
     st.ll_call_seconds += g.llS;
     st.consume_seconds += g.consumeS;

@@ -1369,7 +1369,8 @@ DEVI void runChain(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_
   int64_t budget = J.max_expansions;  // < 0: unlimited
   uint32_t* hostW = (uint32_t*)hostOut;
   uint32_t pathOff = n * kChainEntryWords;  // words
-  uint32_t done = 0;
+  uint32_t done = 0, maxLen = 0;
+  bool allOk = true;
   int64_t total = 0;
   for (uint32_t a = first; a < n; ++a) {
     const uint32_t sg = rfl(hostLoad32(who + a));
@@ -1415,6 +1416,7 @@ DEVI void runChain(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_
       res.prof[6] += expanded;
       res.prof[7] += 1;
 #endif
+      allOk = false;
       break;  // not a search of this tier: the caller runs it as an ordinary job
     }
     {  // the agent's entry
@@ -1425,8 +1427,12 @@ DEVI void runChain(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_
     }
     done += 1;
     total += expanded;
-    if (crc != ct::C_OK) break;  // no path / expansion budget: the conflict tree ends with this answer
+    if (crc != ct::C_OK) {  // no path / expansion budget: the conflict tree ends with this answer
+      allOk = false;
+      break;
+    }
     const uint32_t len = (uint32_t)nStates;
+    maxLen = len > maxLen ? len : maxLen;
     {  // the path: to the host, to its path-store slot, into the table
       const uint32_t words = (len + 1u) / 2u;
       const uint32_t* src = (const uint32_t*)outPath;
@@ -1446,8 +1452,40 @@ DEVI void runChain(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_
   res.status = ST_OK;
   res.n_states = (int32_t)done;
   res.expanded = total;
-  res.cost = 0;
-  res.fmin = 0;
+  res.cost = -1;
+  res.fmin = -1;
+  // ---- the root node's conflicts (SURVEY.md §8 f1 on the drivers' path): when the chain has planned EVERY agent of the
+  // instance, the table in the window is the root's whole solution, and this workgroup says at once whether the conflict
+  // tree has anything to do — getFirstConflict (ecbs.cpp:401-452) and focalHeuristic (ecbs.cpp:315-350) over t = 0 ..
+  // max_t - 1 (the final time step is never checked) and all pairs i < j:
+  //   vertex conflict at t: state_i(t) == state_j(t);  edge conflict: state_i(t) == state_j(t+1) && state_i(t+1) == state_j(t)
+  // Lane = time step (every path of this tier has at most 63 states); the first conflict is the smallest
+  // (t, vertex before edge, i, j).  Seven instances in ten of the ten-agent workload end here: HL 1, no conflict.
+  if (first == 0 && done == n && allOk && maxLen >= 1u && maxLen <= kChainRows) {
+    const uint32_t T = maxLen - 1u;  // <= 62
+    const bool inT = lane < T;
+    const uint32_t rowC = lane * npad, rowN = (lane + 1u < kChainRows ? lane + 1u : kChainRows - 1u) * npad;
+    uint32_t cnt = 0, bestV = 0xFFFFu, bestE = 0xFFFFu;  // this lane's (time step's) first vertex / edge pair: i << 8 | j
+    for (uint32_t i = 0; i + 1u < n; ++i) {
+      const uint32_t ci = table[rowC + i], ni = table[rowN + i];
+      for (uint32_t j = i + 1u; j < n; ++j) {
+        const uint32_t cj = table[rowC + j], nj = table[rowN + j];
+        const bool v = inT && ci == cj, e = inT && ci == nj && ni == cj;
+        cnt += (v ? 1u : 0u) + (e ? 1u : 0u);
+        if (v && bestV == 0xFFFFu) bestV = (i << 8) | j;
+        if (e && bestE == 0xFFFFu) bestE = (i << 8) | j;
+      }
+    }
+    uint32_t key = bestV != 0xFFFFu ? (lane << 24) | bestV : bestE != 0xFFFFu ? (lane << 24) | (1u << 16) | bestE : 0x7FFFFFFFu;
+#pragma unroll
+    for (uint32_t off = 32; off >= 1; off >>= 1) {
+      cnt += (uint32_t)__shfl_xor((int)cnt, (int)off, 64);
+      const uint32_t other = (uint32_t)__shfl_xor((int)key, (int)off, 64);
+      key = other < key ? other : key;
+    }
+    res.cost = (int32_t)rfl(cnt);
+    res.fmin = rfl(key) == 0x7FFFFFFFu ? -1 : (int32_t)rfl(key);
+  }
 }
 
 // MRP_LL_ASTAR_TA: the low level of the task-assignment callers, served by the compact tier alone

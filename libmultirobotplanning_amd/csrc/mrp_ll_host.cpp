@@ -917,7 +917,9 @@ void unpackResult(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* p, bool r
 void unpackChain(mrp_ll_ctx* ctx, const DevResult& d, const uint16_t* out, bool rejected, mrp_ll_result& r, int32_t count,
                  uint32_t outWords) {
   r.status = rejected ? MRP_LL_BAD_JOB : d.status;
-  r.cost = r.fmin = 0;
+  // the root node's conflicts, when the chain planned every agent of the instance (mrp_ll.h): count and first one, else -1
+  r.cost = (rejected || d.status != mrp::ST_OK) ? -1 : d.cost;
+  r.fmin = (rejected || d.status != mrp::ST_OK) ? -1 : d.fmin;
   r.tier = 0;
   const int32_t done = (rejected || d.status != mrp::ST_OK) ? 0 : std::min<int32_t>(d.n_states, count);
   r.n_states = done;

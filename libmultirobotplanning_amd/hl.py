@@ -47,7 +47,8 @@ class mrp_hl_batch_stats(ctypes.Structure):
     _fields_ = [("wall_seconds", ctypes.c_double), ("rounds", ctypes.c_int64), ("ll_searches", ctypes.c_int64),
                 ("ll_expansions", ctypes.c_int64), ("solved", ctypes.c_int64), ("build_seconds", ctypes.c_double),
                 ("ll_call_seconds", ctypes.c_double), ("consume_seconds", ctypes.c_double),
-                ("speculative_searches", ctypes.c_int64), ("wasted_ll_expansions", ctypes.c_int64)]
+                ("speculative_searches", ctypes.c_int64), ("wasted_ll_expansions", ctypes.c_int64),
+                ("root_solved", ctypes.c_int64)]
 
 
 class mrp_hl_sipp_solution(ctypes.Structure):
@@ -315,7 +316,8 @@ class BatchSolver:
         stats = dict(wall_seconds=st.wall_seconds, rounds=st.rounds, ll_searches=st.ll_searches,
                      ll_expansions=st.ll_expansions, solved=st.solved, build_seconds=st.build_seconds,
                      ll_call_seconds=st.ll_call_seconds, consume_seconds=st.consume_seconds,
-                     speculative_searches=st.speculative_searches, wasted_ll_expansions=st.wasted_ll_expansions)
+                     speculative_searches=st.speculative_searches, wasted_ll_expansions=st.wasted_ll_expansions,
+                     root_solved=st.root_solved)
         return (None if raw else self.results_of(prep)), stats
 
     def result_arrays(self, prep) -> Dict[str, np.ndarray]:

@@ -13,6 +13,7 @@
 
 #include "../../include/mrp_ll.h"
 
+extern "C" void oracle_conflict_scan(int nAgents, const int32_t* pathLen, const int32_t* pathXY, int32_t* out);
 extern "C" int oracle_ll_search(int algo, float w, int dimx, int dimy, int nObst, const int32_t* obstXY, int agentIdx,
                                 int startX, int startY, int goalX, int goalY, int nVC, const int32_t* vc, int nEC,
                                 const int32_t* ec, int nCtx, const int32_t* ctxLen, const int32_t* ctxXY,
@@ -114,6 +115,20 @@ static void mockChain(mrp_ll_ctx* c, const mrp_ll_job& j, mrp_ll_result& r) {
   }
   r.n_states = done;
   r.expanded = total;
+  // the root node's conflicts (mrp_ll.h): the oracle's getFirstConflict + focalHeuristic over the chain's paths
+  r.cost = r.fmin = -1;
+  if (first == 0 && done == n && !stopped) {
+    std::vector<int32_t> len, xy;
+    for (int a = 0; a < n; ++a) {
+      const std::vector<int32_t>& p = c->store[j.path_ids[a]];
+      len.push_back(static_cast<int32_t>(p.size() / 2));
+      xy.insert(xy.end(), p.begin(), p.end());
+    }
+    int32_t o[10];
+    oracle_conflict_scan(n, len.data(), xy.data(), o);
+    r.cost = o[9];
+    r.fmin = o[0] ? (o[1] << 24) | (o[4] << 16) | (o[2] << 8) | o[3] : -1;
+  }
 }
 
 int mrp_ll_search_batch(mrp_ll_ctx* c, int32_t n, const mrp_ll_job* jobs, mrp_ll_result* res) {

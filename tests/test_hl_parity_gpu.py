@@ -220,6 +220,35 @@ def test_root_chains_change_nothing_but_the_number_of_jobs(solver, oracle_mod, b
             hl.SOLVED, o["cost"], o["hl_expanded"], o["ll_expanded"])
 
 
+def test_conflict_free_roots_are_written_without_a_conflict_tree(solver, oracle_mod):
+    """The workgroup that runs a root chain also scans the root solution for conflicts (getFirstConflict ecbs.cpp:401-452 +
+    focalHeuristic :315-350, mrp_ll.h MRP_LL_JOB_ROOT_CHAIN); a conflict-free root is written out by the driver without
+    building a conflict tree.  Same results — every counter, every path, the schedule digest — as with the fast path
+    switched off, and as the oracle; about seven ten-agent instances in ten take it."""
+    import os
+    from libmultirobotplanning_amd import hl
+    insts = [hl.generate_instance(1000 * 10 + 55000 + k, 32, 32, 204, 10) for k in range(1500)]
+    insts += [hl.generate_instance(1000 * 4 + 500 + k, 8, 8, 12, 4) for k in range(200)]   # tiny maps: many conflicts
+    insts += [hl.generate_instance(1000 * 28 + 900 + k, 32, 32, 204, 28) for k in range(40)]
+    res_on, st_on = solver.solve(insts, algo=hl.ECBS, w=1.3, max_ll_expansions=200000)
+    os.environ["MRP_HL_ROOT_FAST"] = "0"
+    try:
+        res_off, st_off = solver.solve(insts, algo=hl.ECBS, w=1.3, max_ll_expansions=200000)
+    finally:
+        del os.environ["MRP_HL_ROOT_FAST"]
+    assert st_off["root_solved"] == 0 and st_on["root_solved"] > 900
+    # (a root chain that stopped in front of a search too large for the LDS tier is resumed behind it: no scan, usual path)
+    n_hl1 = sum(1 for r in res_on if r["status"] == hl.SOLVED and r["hl_expanded"] == 1 and len(r["paths"]) >= 2)
+    assert n_hl1 * 0.97 <= st_on["root_solved"] <= n_hl1
+    keys = ("status", "cost", "makespan", "hl_expanded", "ll_expanded", "ll_searches", "paths", "schedule_digest")
+    for i, (a, b) in enumerate(zip(res_on, res_off)):
+        assert [a.get(k) for k in keys] == [b.get(k) for k in keys], i
+    for inst, r in list(zip(insts, res_on))[:300] + list(zip(insts, res_on))[1500:1600]:
+        o = oracle_mod.mapf_solve(oracle_mod.ECBS, inst, w=1.3, cap_total=200000, path_cap=1024)
+        assert o["rc"] == 1 and (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"], r["paths"]) == (
+            hl.SOLVED, o["cost"], o["makespan"], o["hl_expanded"], o["ll_expanded"], o["paths"])
+
+
 def test_ecbs_without_the_compact_tier(oracle_mod, bench_instances):
     """mrp_ll_options.lds_nodes < 0 switches the compact tier off; results never depend on it (mrp_ll.h).  The engine then
     cannot run root chains either: it rejects the first one and the driver goes on with one job per root search."""

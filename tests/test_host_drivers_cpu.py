@@ -202,5 +202,7 @@ def test_root_chains_on_the_mock(cpu_solver, bench_instances, oracle_expected, m
         # chains: far fewer tickets than searches; "0": every chain breaks at its first search, one ticket more per search
         if brk is None:
             assert st["rounds"] * 3 < searches
+            # conflict-free roots (the chain's own scan says so) are written without a conflict tree
+            assert st["root_solved"] == sum(1 for r in res if r["hl_expanded"] == 1) > 0
         if brk == "0":
             assert st["rounds"] > searches
