@@ -167,6 +167,11 @@ struct CRes {              // at oRes
 #define MRP_CT_PROF_MARK(k) do { const uint64_t n_ = wv::clock64(); prof_[k] += (uint32_t)(n_ - profT_); profT_ = n_; } while (0)
 #define MRP_CT_PROF_ADD(k, v) prof_[k] += (v)
 #define MRP_CT_PROF_STORE(lds) do { for (uint32_t q_ = 0; q_ < 8; ++q_) ldsStoreS(lds, oRes + 32u + 4u * q_, prof_[q_]); } while (0)
+#elif defined(MRP_CT_ASM_MARKS)  // dev tool: "; PHASE k" comments in the compiler's assembly (instruction counts per phase)
+#define MRP_CT_PROF_DECL do { } while (0)
+#define MRP_CT_PROF_MARK(k) asm volatile("; PHASE " #k ::: "memory")
+#define MRP_CT_PROF_ADD(k, v) do { } while (0)
+#define MRP_CT_PROF_STORE(lds) do { } while (0)
 #else
 #define MRP_CT_PROF_DECL do { } while (0)
 #define MRP_CT_PROF_MARK(k) do { } while (0)

@@ -126,6 +126,24 @@ def solve_sharded(inst: Dict, executor: Callable[[Sequence[Dict]], List[Dict]], 
                          max_hl_expansions=max_hl_expansions, _lib_path=_lib_path)
     rounds = ran = 0
     native = isinstance(executor, NativeEngine)
+    import time
+    t_search = t_coll = t_deliver = 0.0
+    width = _HDR + max_states
+    # Buffers of the native rounds, allocated ONCE: this rank's rows (pinned when they travel to a GPU), their device
+    # copy, the gathered rows of all ranks on the device and on the host.  A round moves `stride` rows per rank — the
+    # largest share of the round — through views of these; nothing is allocated, stacked or converted per round.
+    cap_rows = max(8, 4 * spec_width + 4)
+    on_gpu = native and device != "cpu" and world > 1
+    if native:
+        rows_t = torch.zeros((cap_rows, width), dtype=torch.int32)
+        gath_t = torch.zeros((world * cap_rows * width,), dtype=torch.int32)
+        if on_gpu:
+            rows_t, gath_t = rows_t.pin_memory(), gath_t.pin_memory()
+            send_dev = torch.zeros((cap_rows, width), dtype=torch.int32, device=device)
+            gath_dev = torch.zeros((world * cap_rows * width,), dtype=torch.int32, device=device)
+        rows = rows_t.numpy()
+        gath = gath_t.numpy()
+        per_rank = np.zeros(world, dtype=np.int32)
     try:
         while not ct.done():
             if native:
@@ -133,21 +151,35 @@ def solve_sharded(inst: Dict, executor: Callable[[Sequence[Dict]], List[Dict]], 
                 n_req = ct.n_requests()
                 if n_req == 0:
                     raise RuntimeError("conflict tree is neither done nor asking for searches")
-                rows = np.zeros((n_req, 8 + max_states), dtype=np.int32)
-                per_rank = np.zeros(world, dtype=np.int32)
-                n_mine = ct.round_mine(executor.handle, me, world, rows, per_rank)
+                if n_req > cap_rows:
+                    raise RuntimeError("more requests in a round than the row buffers hold")
+                t0 = time.perf_counter()
+                n_mine = ct.round_mine(executor.handle, me, world, rows[:n_req], per_rank)
+                t1 = time.perf_counter()
                 stride = max(int(per_rank.max()), 1)
                 ran += max(n_mine, 0)
                 rounds += 1
-                mine_rows = np.ascontiguousarray(rows[:stride])
                 if world == 1:
-                    gathered = mine_rows[None]
+                    gathered = rows[None, :stride]
                 else:
-                    buf = torch.from_numpy(mine_rows).to(device)
-                    parts = [torch.empty_like(buf) for _ in range(world)]
-                    dist.all_gather(parts, buf)
-                    gathered = torch.stack(parts).cpu().numpy()
+                    n_words = world * stride * width
+                    if on_gpu:
+                        send_dev[:stride].copy_(rows_t[:stride], non_blocking=True)
+                        dist.all_gather_into_tensor(gath_dev[:n_words], send_dev[:stride].reshape(-1))
+                        gath_t[:n_words].copy_(gath_dev[:n_words])
+                    else:
+                        try:
+                            dist.all_gather_into_tensor(gath_t[:n_words], rows_t[:stride].reshape(-1))
+                        except (RuntimeError, AttributeError):  # a backend without the flat form
+                            dist.all_gather([gath_t[k * stride * width:(k + 1) * stride * width] for k in range(world)],
+                                            rows_t[:stride].reshape(-1))
+                    gathered = gath[:n_words].reshape(world, stride, width)
+                t2 = time.perf_counter()
                 ct.deliver_rows(gathered)  # raises on EVERY rank if any rank sent a failure row
+                t3 = time.perf_counter()
+                t_search += t1 - t0
+                t_coll += t2 - t1
+                t_deliver += t3 - t2
                 continue
             reqs = ct.requests()
             if not reqs:
@@ -216,4 +248,7 @@ def solve_sharded(inst: Dict, executor: Callable[[Sequence[Dict]], List[Dict]], 
         ct.close()
     out["rounds"] = rounds
     out["searches_run_here"] = ran
+    if native and rounds:  # where a round's time goes on this rank (microseconds per round)
+        out["us_per_round"] = dict(search_and_pack=1e6 * t_search / rounds, collective=1e6 * t_coll / rounds,
+                                   deliver=1e6 * t_deliver / rounds)
     return out

@@ -270,8 +270,7 @@ class BatchSolver:
                 sv["path_len"] = lens.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(na * 4)
                 sv["paths_xy"] = paths.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(na * path_cap * 8)
                 sv["path_cap"] = path_cap
-                plen = [lens[i] for i in range(n)] if n <= 4096 else lens
-                pxy = [paths[i] for i in range(n)] if n <= 4096 else paths
+                plen, pxy = lens, paths
             instances = ()
         for i, inst in enumerate(instances):
             ob = np.ascontiguousarray(np.asarray(inst["obstacles"], dtype=np.int32).reshape(-1, 2))
@@ -329,6 +328,8 @@ class BatchSolver:
                    ll_searches=sv["n_ll_searches"].copy(), schedule_digest=sv["schedule_digest"].copy())
         if prep["want_paths"] and isinstance(prep["plen"], np.ndarray):
             out["path_len"] = prep["plen"]
+        elif prep["want_paths"] and prep["n"]:
+            out["path_len"] = np.concatenate([np.asarray(a).ravel() for a in prep["plen"]])
         return out
 
     def results_of(self, prep) -> List[Dict]:
