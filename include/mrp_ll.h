@@ -54,8 +54,11 @@ extern "C" {
                            /* the task-assignment callers (cbs_ta.hpp:106-109,155-158,196-199; ecbs_ta's Environment is the */
                            /* same): optional goal (MRP_LL_JOB_NO_GOAL), h = an uploaded shortest-path table               */
                            /* (mrp_ll_upload_heuristic), Wait costs 0 at the goal, so g != time and decrease-key is live.  */
-                           /* Maps up to 32 x 32, at most 64 vertex and 64 edge constraints, time steps <= 61, f <= 254,   */
-                           /* 1023 open nodes; beyond that a job ends with MRP_LL_CAP_NODES / MRP_LL_CAP_HORIZON.          */
+                           /* Two tiers, like the other searches: the LDS tier (maps up to 32 x 32, at most 64 vertex and  */
+                           /* 64 edge constraints, time steps <= 61, f <= 254, 1023 open nodes) and, for everything beyond */
+                           /* it, the arena tier (any map the context accepts, any number of constraints; limits:           */
+                           /* mrp_ll_options.arena_nodes / max_horizon — MRP_LL_CAP_NODES / MRP_LL_CAP_HORIZON — and as many */
+                           /* time steps as arena_nodes x 4 status words hold: 512 on a 32 x 32 map by default).            */
 
 /* ---- per-job status (mrp_ll_result.status) ----------------------------------------------------------------- */
 #define MRP_LL_OK 0             /* search() returned true                                                    */
@@ -218,7 +221,7 @@ int mrp_ll_upload_map(mrp_ll_ctx* ctx, int32_t dimx, int32_t dimy, int32_t n_obs
 /* MRP_LL_ASTAR_TA: the heuristic of one goal cell of map `map_id` — dist[dimy][dimx] (row-major, dist[y * dimx + x]) =
  * ShortestPathHeuristic::getValue(cell, goal) (example/shortest_path_heuristic.hpp:56-60: all-pairs shortest paths on the
  * free cells; INT32_MAX = unreachable).  Computing it is the caller's business (the reference does it once per
- * Environment, cbs_ta.cpp:267); the engine keeps it next to the maps.  MRP_LL_E_BUSY during a session. */
+ * Environment, cbs_ta.cpp:267); the engine keeps it next to the maps (any map size).  MRP_LL_E_BUSY during a session. */
 int mrp_ll_upload_heuristic(mrp_ll_ctx* ctx, int32_t map_id, const int32_t* dist, int32_t* heuristic_id);
 
 /* Copies every map uploaded so far to the device now (otherwise done lazily by the next submit / session_begin). */

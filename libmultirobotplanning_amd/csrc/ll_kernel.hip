@@ -1488,57 +1488,263 @@ DEVI void runChain(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_
   }
 }
 
-// MRP_LL_ASTAR_TA: the low level of the task-assignment callers, served by the compact tier alone
-// (ll_compact.h compactSearchTA).  The job's constraint words are read where the host put them; the goal's shortest-path
-// table sits in the maps buffer (mrp_ll_upload_heuristic).
-DEVI void runJobTA(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t* arenaSlot, DevResult& res, uint16_t* outPath) {
-  res.tier = 0;
-  if (P.lds_nodes == 0 || P.lds_paths_bytes < 2048u || J.dimx > 32u || J.dimy > 32u || J.n_vc > 64u || J.n_ec > 64u ||
-      (uint64_t)P.arena_nodes * 16u < ct::kParentBytes) {
-    res.status = ST_BAD;  // (the host packer refuses such a job; a context without the compact tier cannot run it)
+// MRP_LL_ASTAR_TA in the arena tier: AStar::search (a_star.hpp:63-161) over the Environment of example/cbs_ta.cpp:283-372
+// for the searches the compact tier cannot hold (more than 1023 open nodes, t > 61, f > 254, more than 64 + 64
+// constraints, maps beyond 32 x 32).  Same rules as ct::compactSearchTA — optional task, shortest-path heuristic from the
+// uploaded table, a Wait at the goal is free, so a state can be reached again with a smaller g and
+// `openSet.increase(handle)` (a_star.hpp:139-145) is live — on the arena's node records:
+//   node   {x | y << 8 | t << 16 | action << 27, parent, g, position of its entry in the open array}
+//   entry  TierHbm: key = (f asc, g desc), low word = node id
+//   status one word per (t, cell) in the (unused) focal + walk-queue areas of the slot: 0 unseen, node + 1 in the open
+//          list, bit 31 closed (stateToHeap + closedSet, a_star.hpp:116-117)
+//   bits   (time, cell) bitmap: obstacles | vertex constraints (stateValid, cbs_ta.cpp:483-489), rows made on demand
+// Time steps: as many as the status table has room for (and the job's horizon); beyond: MRP_LL_CAP_HORIZON.
+DEVI void runTaArena(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, DevResult& res, uint16_t* outPath,
+                     const uint32_t* vc, const uint32_t* ec, const uint16_t* heur, uint32_t heurStride) {
+  typedef TierHbm T;
+  const uint32_t lane = threadIdx.x;
+  Mem<T> g;
+  {
+    uint8_t* p = arenaSlot;
+    g.nodes = (Mem<T>::PN32)p;             p += (size_t)P.arena_nodes * 16;
+    g.pos = nullptr;
+    g.gOf = nullptr;
+    g.open = (Mem<T>::PE)(p + 8);          p += (size_t)P.arena_nodes * 8 + 16;
+    g.focal = (Mem<T>::PE)(p + 8);         // (the status table lives from here on)
+    g.aux = g.focal;
+    g.bits = (Mem<T>::P32)(arenaSlot + (size_t)P.arena_nodes * 16 + 3 * ((size_t)P.arena_nodes * 8 + 16));
+    g.capNodes = P.arena_nodes; g.capHeap = P.arena_nodes; g.capRows = P.arena_rows; g.rowWords = P.arena_row_words;
+  }
+  uint32_t* status = (uint32_t*)(arenaSlot + (size_t)P.arena_nodes * 16 + ((size_t)P.arena_nodes * 8 + 16));
+  const uint32_t dimx = J.dimx, dimy = J.dimy, cells = dimx * dimy;
+  const uint64_t statusWords = ((uint64_t)P.arena_nodes * 8 + 16) * 2 / 4;
+  uint32_t rows = (uint32_t)(statusWords / cells < P.arena_rows ? statusWords / cells : P.arena_rows);
+  const bool noGoal = (J.ctx_flags & kTaNoGoal) != 0;
+  Ctx c;
+  c.dimx = dimx; c.dimy = dimy; c.wpr = J.words_per_row;
+  c.gx = J.gx; c.gy = J.gy; c.sx = J.sx; c.sy = J.sy;
+  c.lastGoal = J.last_goal_constraint;
+  c.w = 1.0f;
+  c.nVc = J.n_vc; c.nEc = J.n_ec;
+  c.vc = vc; c.ec = ec;
+  c.obst = P.maps + J.map_word_off;
+  c.paths = nullptr; c.pathsLds = nullptr;
+  c.nAgentsPad = 0; c.tPad = 0;
+  c.maxExp = J.max_expansions;
+  c.debug = P.debug;
+  res.tier = 1;
+  res.status = ST_NO_SOLUTION;
+  if (rows < 2u) {
+    res.status = ST_CAP_HORIZON;
     return;
   }
-  ct::CJob cj;
-  cj.dimx = J.dimx; cj.dimy = J.dimy; cj.sx = J.sx; cj.sy = J.sy; cj.gx = J.gx; cj.gy = J.gy;
-  cj.lastGoal = J.last_goal_constraint;
-  cj.w = 1.0f;
-  cj.nVc = J.n_vc; cj.nEc = J.n_ec;
-  cj.obstWords = J.words_per_row;
-  cj.nAgentsPad = 0; cj.tPad = 0;
-  cj.maxExp = J.max_expansions < 0 ? 0xFFFFFFFFu : (J.max_expansions > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)J.max_expansions);
-  cj.openCap = P.lds_nodes / 2u < ct::kCap ? P.lds_nodes / 2u : ct::kCap;
-  cj.maxT = P.lds_rows >= 3u && P.lds_rows - 2u < ct::kMaxT ? P.lds_rows - 2u : ct::kMaxT;
-  cj.taNoGoal = (J.ctx_flags & kTaNoGoal) ? 1u : 0u;
-  cj.rows = 0;
-  {  // the constraint words leave host memory in one pass (at most 64 + 64 of them)
-    uint32_t* consLocal = (uint32_t*)(arenaSlot + P.arena_scratch_off + (size_t)P.out_stride * 2);
-    const uint32_t lane = threadIdx.x;
-    if (lane < J.n_vc) consLocal[lane] = hostLoad32(P.cons + J.vc_off + lane);
-    if (lane < J.n_ec) consLocal[64 + lane] = hostLoad32(P.cons + J.ec_off + lane);
-    cj.vc = (uint64_t)consLocal; cj.ec = (uint64_t)(consLocal + 64);
+  SState s;
+  s.nNodes = 1; s.nOpen = 1; s.nFocal = 0; s.rowsReady = 0; s.bestF = 0; s.expansions = 0;
+  {  // the table: nothing seen (rows are zeroed as the bitmap's rows are made, below: `statusReady`)
+    const uint32_t sc = J.sy * dimx + J.sx;
+    const uint32_t h0 = noGoal ? 0u : heur[J.sy * heurStride + J.sx];
+    if (h0 > kFMax - 2u) {  // the task cannot be reached from here (the reference's table says INT_MAX), or not within f's field
+      res.status = ST_CAP_HORIZON;
+      return;
+    }
+    u32x4 n0;
+    n0.x = J.sx | (J.sy << 8) | (0u << 16) | (7u << 27);
+    n0.y = kNoParent;
+    n0.z = 0;
+    n0.w = 0;
+    ((Mem<T>::PNode4)g.nodes)[0] = n0;
+    g.open[0] = T::pack(0, h0, 0, 0);
+    for (uint32_t i = lane; i < cells; i += 64) status[i] = 0;
+    __syncthreads();
+    status[sc] = 1u;  // node 0, in the open list
+  }
+  uint32_t statusReady = 1;  // rows of the status table that have been zeroed
+  const uint32_t ecReg = lane < c.nEc ? c.ec[lane] : 0xFFFFFFFFu;
+  const int32_t dx = (lane == 2) - (lane == 1);
+  const int32_t dy = (lane == 3) - (lane == 4);
+  for (;;) {
+    if (s.nOpen == 0) {
+      res.status = ST_NO_SOLUTION;
+      break;
+    }
+    const T::E curE = ldU<T>(g.open, 0);
+    const uint32_t curId = T::id(curE), gcur = T::g(curE), fcur = T::f(curE);
+    const u32x4 nd = ((Mem<T>::PNode4)g.nodes)[curId];
+    const uint32_t xyt = rfl(nd.x);
+    const uint32_t x = xyt & 0xFFu, y = (xyt >> 8) & 0xFFu, t = (xyt >> 16) & 0x7FFu;
+    const bool atGoal = noGoal || (x == c.gx && y == c.gy);
+    s.expansions += 1;  // onExpandNode (a_star.hpp:87)
+    if (c.maxExp >= 0 && s.expansions > c.maxExp) {
+      res.status = ST_CAP_EXP;
+      break;
+    }
+    if (atGoal && (int32_t)t > c.lastGoal) {  // isSolution (cbs_ta.cpp:313-319) -> a_star.hpp:89-106
+      if (t + 1u > P.out_stride) {
+        res.status = ST_CAP_HORIZON;
+        break;
+      }
+      uint32_t nid = curId;
+      for (int32_t k = (int32_t)t; k >= 0; --k) {
+        const u32x4 pn = ((Mem<T>::PNode4)g.nodes)[nid];
+        outPath[k] = (uint16_t)(rfl(pn.x) & 0xFFFFu);
+        nid = rfl(pn.y);
+      }
+      res.status = ST_OK;
+      res.cost = (int32_t)gcur;
+      res.fmin = (int32_t)fcur;
+      res.n_states = (int32_t)t + 1;
+      break;
+    }
+    const uint32_t t1 = t + 1u;
+    if (t1 >= rows || t1 >= g.capRows) {
+      res.status = ST_CAP_HORIZON;
+      break;
+    }
+    if (s.nNodes + 5u > g.capNodes || s.nOpen + 5u > g.capHeap) {
+      res.status = ST_CAP_NODES;
+      break;
+    }
+    heapPop<T, 0, true>(g, g.open, s.nOpen);  // openSet.pop() (a_star.hpp:109)
+    status[t * cells + y * dimx + x] = 0x80000000u;  // closedSet.insert (a_star.hpp:110)
+    ensureRows<T>(g, s, c, t1, (Mem<T>::P32)c.obst, false);
+    while (statusReady <= t1) {  // the status rows of the next time steps: nothing seen
+      for (uint32_t i = lane; i < cells; i += 64) status[statusReady * cells + i] = 0;
+      statusReady += 1;
+    }
+    __syncthreads();
+    // getNeighbors (cbs_ta.cpp:321-367): Wait, Left, Right, Up, Down on lanes 0..4 — bounds, obstacle | vertex constraint
+    // (one bit of the bitmap), edge constraints by key
+    const uint32_t nx = x + (uint32_t)dx, ny = y + (uint32_t)dy;
+    const bool inb = (lane < 5) && (nx < dimx) && (ny < dimy);
+    const uint32_t ncell = inb ? ny * dimx + nx : 0;
+    const uint32_t word = g.bits[t1 * g.rowWords + (ncell >> 5)];
+    const uint32_t hN = (noGoal || !inb) ? 0u : heur[ny * heurStride + nx];
+    const uint32_t stN = inb ? status[t1 * cells + ncell] : 0u;
+    uint32_t mask = (uint32_t)(ballot64(inb && !((word >> (ncell & 31)) & 1u)) & 0x1Full);
+    if (c.nEc) {  // transitionValid (cbs_ta.cpp:491-496)
+      const uint32_t base = (t << 19) | ((y * dimx + x) << 3);
+      uint32_t blocked = 0;
+      for (uint32_t j0 = 0; j0 < c.nEc; j0 += 64) {
+        const uint32_t d = (j0 == 0 ? ecReg : (j0 + lane < c.nEc ? c.ec[j0 + lane] : 0xFFFFFFFFu)) - base;
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) blocked |= ballot64(d == k) ? (1u << k) : 0u;
+      }
+      mask &= ~blocked;
+    }
+    bool fail = false;
+    for (uint32_t mm = mask; mm && !fail; mm &= mm - 1) {  // the new / rediscovered / closed cases of a_star.hpp:116-153, in order
+      const uint32_t k = (uint32_t)__builtin_ctz(mm);
+      const uint32_t st = __builtin_amdgcn_readlane(stN, k);
+      if (st & 0x80000000u) continue;  // closed
+      const uint32_t nc = __builtin_amdgcn_readlane(ncell, k), h = __builtin_amdgcn_readlane(hN, k);
+      const uint32_t nxk = __builtin_amdgcn_readlane(nx, k), nyk = __builtin_amdgcn_readlane(ny, k);
+      const uint32_t g2 = gcur + ((k == 0 && atGoal) ? 0u : 1u);  // tentative_gScore (a_star.hpp:118)
+      if (st == 0) {  // not in the open list, not closed: a new node (a_star.hpp:120-129)
+        if (h > kFMax || g2 + h > kFMax - 2u || g2 > kGMask) {
+          res.status = ST_CAP_HORIZON;
+          fail = true;
+          break;
+        }
+        const uint32_t nid = s.nNodes++;
+        u32x4 nn;
+        nn.x = nxk | (nyk << 8) | (t1 << 16) | (k << 27);
+        nn.y = curId;
+        nn.z = g2;
+        nn.w = 0;
+        ((Mem<T>::PNode4)g.nodes)[nid] = nn;
+        status[t1 * cells + nc] = nid + 1u;
+        siftUp<T, 0, true>(g, g.open, s.nOpen, T::pack(0, g2 + h, g2, nid));
+        s.nOpen += 1;
+      } else {        // still in the open list (a_star.hpp:130-146)
+        const uint32_t nid = st - 1u;
+        const u32x4 on = ((Mem<T>::PNode4)g.nodes)[nid];
+        const uint32_t gOld = rfl(on.z), posOld = rfl(on.w);
+        if (g2 >= gOld) continue;  // not an improvement (a_star.hpp:135-137)
+        const uint32_t fOld = T::f(ldU<T>(g.open, posOld));
+        const uint32_t fNew = fOld - (gOld - g2);  // fScore -= delta (a_star.hpp:141-142)
+        g.nodes[nid * 4 + 0] = (rfl(on.x) & 0x07FFFFFFu) | (k << 27);  // cameFrom is replaced (a_star.hpp:150-152)
+        g.nodes[nid * 4 + 1] = curId;
+        g.nodes[nid * 4 + 2] = g2;
+        siftUp<T, 0, true>(g, g.open, posOld, T::pack(0, fNew, g2, nid));  // increase(handle)
+      }
+    }
+    if (fail) break;
+  }
+  res.expanded = s.expansions;
+  res.nodes_created = s.nNodes;
+}
+
+// MRP_LL_ASTAR_TA: the low level of the task-assignment callers: the compact tier (ll_compact.h
+// compactSearchTA) when the job fits it — a map up to 32 x 32, at most 64 vertex and 64 edge constraints — and the arena
+// tier above when it does not, or when the search outgrows the compact tier on the way (its capacity statuses are then
+// not an answer).  The goal's shortest-path table sits in the maps buffer (mrp_ll_upload_heuristic): [32][32] halfwords
+// for maps up to 32 x 32, [dimy][dimx] beyond.
+DEVI void runJobTA(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_t* arenaSlot, DevResult& res, uint16_t* outPath) {
+  res.tier = 0;
+  const uint32_t lane = threadIdx.x;
+  // the constraint words leave host memory in one pass (the arena's copy area holds 2048 of them; longer lists are read in place)
+  uint32_t* consLocal = (uint32_t*)(arenaSlot + P.arena_scratch_off + (size_t)P.out_stride * 2);
+  const uint32_t* vc = consLocal;
+  const uint32_t* ec = consLocal + J.n_vc;
+  if (J.n_vc + J.n_ec <= kConsLocalWords) {
+    for (uint32_t i = lane; i < J.n_vc; i += 64) consLocal[i] = hostLoad32(P.cons + J.vc_off + i);
+    for (uint32_t i = lane; i < J.n_ec; i += 64) consLocal[J.n_vc + i] = hostLoad32(P.cons + J.ec_off + i);
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    vc = P.cons + J.vc_off;
+    ec = P.cons + J.ec_off;
+  }
+  __syncthreads();
+  const bool small = J.dimx <= 32u && J.dimy <= 32u;
+  const uint16_t* heur = (const uint16_t*)(P.maps + J.path_off);
+  const bool compactOk = P.lds_nodes != 0 && P.lds_paths_bytes >= 2048u && small && J.n_vc <= 64u && J.n_ec <= 64u &&
+                         (uint64_t)P.arena_nodes * 16u >= ct::kParentBytes;
+  if (compactOk) {
+    ct::CJob cj;
+    cj.dimx = J.dimx; cj.dimy = J.dimy; cj.sx = J.sx; cj.sy = J.sy; cj.gx = J.gx; cj.gy = J.gy;
+    cj.lastGoal = J.last_goal_constraint;
+    cj.w = 1.0f;
+    cj.nVc = J.n_vc; cj.nEc = J.n_ec;
+    cj.obstWords = J.words_per_row;
+    cj.nAgentsPad = 0; cj.tPad = 0;
+    cj.maxExp = J.max_expansions < 0 ? 0xFFFFFFFFu : (J.max_expansions > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)J.max_expansions);
+    cj.openCap = P.lds_nodes / 2u < ct::kCap ? P.lds_nodes / 2u : ct::kCap;
+    cj.maxT = P.lds_rows >= 3u && P.lds_rows - 2u < ct::kMaxT ? P.lds_rows - 2u : ct::kMaxT;
+    cj.taNoGoal = (J.ctx_flags & kTaNoGoal) ? 1u : 0u;
+    cj.rows = 0;
+    cj.vc = (uint64_t)vc; cj.ec = (uint64_t)ec;
+    cj.obst = (uint64_t)(P.maps + J.map_word_off);
+    cj.pathsG = (uint64_t)heur;
+    cj.parentTab = (uint64_t)arenaSlot;
+    cj.outPath = (uint64_t)outPath;
+    {
+      auto w32 = (__attribute__((address_space(3))) uint32_t*)((wv::Lds)smem + ct::oJob);
+      const uint32_t* src = (const uint32_t*)&cj;
+#pragma unroll
+      for (uint32_t q = 0; q < sizeof(ct::CJob) / 4; ++q) w32[q] = src[q];
+    }
+    const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
+    const int32_t crc = ct::compactSearchTA((wv::Lds)smem);
+    auto r32 = (__attribute__((address_space(3))) const uint32_t*)((wv::Lds)smem + ct::oRes);
+    res.prof[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);
+    res.prof[1] = rfl(r32[4]);
+    if (crc != ct::C_CAP_NODES && crc != ct::C_CAP_HORIZON) {  // an answer (C_OK / C_NO_SOLUTION / C_CAP_EXP == the ST_ codes)
+      res.status = crc;
+      res.cost = (int32_t)rfl(r32[1]);
+      res.fmin = (int32_t)rfl(r32[2]);
+      res.n_states = (int32_t)rfl(r32[3]);
+      res.expanded = rfl(r32[4]);
+      res.nodes_created = rfl(r32[5]);
+      return;
+    }
+    res.prof[6] = rfl(r32[4]);  // expansions thrown away with the attempt
+    res.prof[7] = 1;
     __syncthreads();
   }
-  cj.obst = (uint64_t)(P.maps + J.map_word_off);
-  cj.pathsG = (uint64_t)(P.maps + J.path_off);
-  cj.parentTab = (uint64_t)arenaSlot;
-  cj.outPath = (uint64_t)outPath;
-  {
-    auto w32 = (__attribute__((address_space(3))) uint32_t*)((wv::Lds)smem + ct::oJob);
-    const uint32_t* src = (const uint32_t*)&cj;
-#pragma unroll
-    for (uint32_t q = 0; q < sizeof(ct::CJob) / 4; ++q) w32[q] = src[q];
-  }
-  const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
-  const int32_t crc = ct::compactSearchTA((wv::Lds)smem);
-  auto r32 = (__attribute__((address_space(3))) const uint32_t*)((wv::Lds)smem + ct::oRes);
-  res.status = crc;  // C_OK / C_NO_SOLUTION / C_CAP_EXP / C_CAP_NODES / C_CAP_HORIZON == the ST_ codes
-  res.cost = (int32_t)rfl(r32[1]);
-  res.fmin = (int32_t)rfl(r32[2]);
-  res.n_states = (int32_t)rfl(r32[3]);
-  res.expanded = rfl(r32[4]);
-  res.nodes_created = rfl(r32[5]);
-  res.prof[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);
-  res.prof[1] = (uint32_t)res.expanded;
+  const uint64_t th0 = __builtin_amdgcn_s_memrealtime();
+  runTaArena(P, J, arenaSlot, res, outPath, vc, ec, heur, small ? 32u : J.dimx);
+  res.prof[2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - th0);
+  res.prof[3] = (uint32_t)res.expanded;
 }
 
 // ---- SIPP (config 5): A* over (cell, safe interval) states ---------------------------------------------------

@@ -798,8 +798,8 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   d.max_expansions = j.max_expansions;
   if (j.algo == MRP_LL_SIPP) return packSipp(ctx, j, mp, cs, d);
   if (j.algo == MRP_LL_ASTAR_TA) {
-    // the compact tier serves these jobs, and only it (ll_compact.h compactSearchTA)
-    if (mp.dimx > 32 || mp.dimy > 32 || j.initial_cost != 0) return false;
+    // (the compact tier serves what fits it — maps up to 32 x 32, 64 + 64 constraints —, the arena tier the rest)
+    if (j.initial_cost != 0) return false;
     if (!taNoGoal) {
       if (j.heuristic_id < 0 || j.heuristic_id >= static_cast<int32_t>(ctx->heurs.size()) ||
           ctx->heurs[j.heuristic_id].mapId != j.map_id)
@@ -831,9 +831,8 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
   }
   d.n_ec = static_cast<uint32_t>(cs.size()) - d.ec_off;
   if (cs.failed) return false;
-  if (j.algo == MRP_LL_ASTAR_TA) {  // one constraint key per lane of the wave (mrp_ll.h)
+  if (j.algo == MRP_LL_ASTAR_TA) {
     const uint32_t heurOff = d.path_off;
-    if (d.n_vc > 64 || d.n_ec > 64) return false;
     d.n_agents_pad = 0;
     d.t_pad = 0;
     d.path_off = heurOff;
@@ -1283,21 +1282,21 @@ int mrp_ll_upload_heuristic(mrp_ll_ctx* ctx, int32_t mapId, const int32_t* dist,
   if (!ctx || !dist || !heurId || mapId < 0 || mapId >= static_cast<int32_t>(ctx->maps.size())) return MRP_LL_E_INVALID;
   if (ctx->ring.active) return MRP_LL_E_BUSY;  // (the maps buffer may have to grow)
   const MapRec& mp = ctx->maps[mapId];
-  if (mp.dimx > 32 || mp.dimy > 32) {
-    ctx->err = "mrp_ll_upload_heuristic: MRP_LL_ASTAR_TA serves maps up to 32 x 32";
-    return MRP_LL_E_INVALID;
-  }
   while (ctx->mapWords.size() & 31u) ctx->mapWords.push_back(0);  // own 128-byte lines, as the bitmaps
   HeurRec h;
   h.mapId = mapId;
   h.wordOff = static_cast<uint32_t>(ctx->mapWords.size());
-  ctx->mapWords.resize(ctx->mapWords.size() + mrp::kHeurWords, 0xFFFFFFFFu);
-  // [y * 32 + x] halfwords, 0xFFFF = unreachable (the reference's table holds INT_MAX there)
+  // halfwords, 0xFFFF = unreachable (the reference's table holds INT_MAX there): [y * 32 + x] for maps up to 32 x 32 (what
+  // the compact tier copies into its window), [y * dimx + x] beyond (arena tier only)
+  const bool small = mp.dimx <= 32 && mp.dimy <= 32;
+  const int stride = small ? 32 : mp.dimx;
+  const size_t words = small ? mrp::kHeurWords : (static_cast<size_t>(mp.dimx) * mp.dimy + 1) / 2;
+  ctx->mapWords.resize(ctx->mapWords.size() + words, 0xFFFFFFFFu);
   uint16_t* t16 = reinterpret_cast<uint16_t*>(ctx->mapWords.data() + h.wordOff);
   for (int y = 0; y < mp.dimy; ++y)
     for (int x = 0; x < mp.dimx; ++x) {
       const int32_t v = dist[y * mp.dimx + x];
-      t16[y * 32 + x] = (v < 0 || v > 0xFFFE) ? 0xFFFFu : static_cast<uint16_t>(v);
+      t16[y * stride + x] = (v < 0 || v > 0xFFFE) ? 0xFFFFu : static_cast<uint16_t>(v);
     }
   ctx->heurs.push_back(h);
   ctx->mapsDirty = true;

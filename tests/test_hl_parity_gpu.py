@@ -392,6 +392,27 @@ def test_all_1000_shipped_32x32_inputs(solver, shipped_corpus):
     assert capped == 1 and exp["map_32by32_obst204_agents100_ex36"]["rc"] != 1
 
 
+@pytest.mark.timeout(900)
+def test_the_heavy_tail_input_runs_to_completion(solver, shipped_corpus):
+    """benchmark/32x32_obst204/map_32by32_obst204_agents100_ex36 with NO cap, as the reference runs it (a_star_epsilon.hpp:116
+    and ecbs.hpp:151 have none): one conflict tree of 70 612 nodes, 56.8 million low-level expansions — SURVEY.md §6's
+    figures from the reference's own headers, reproduced by the uncapped oracle vector
+    tests/golden/shipped_heavy_tail_expected.json — about a minute on the GPU (one dependent chain of rounds)."""
+    import json
+    import os
+    from libmultirobotplanning_amd import hl
+    with open(os.path.join(os.path.dirname(__file__), "golden", "shipped_heavy_tail_expected.json")) as f:
+        e = json.load(f)["map_32by32_obst204_agents100_ex36"]
+    assert (e["cost"], e["hl"], e["ll"]) == (2574, 70612, 56795846)  # SURVEY.md §6
+    corpus, _ = shipped_corpus
+    inst = dict(corpus)["map_32by32_obst204_agents100_ex36"]
+    res, _ = solver.solve([inst], algo=hl.ECBS, w=1.3, max_ll_expansions=-1, path_cap=1024)
+    r = res[0]
+    assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
+        hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"])
+    assert _digest(r["paths"]) == e["digest"]
+
+
 def test_cbs_8x8_at_the_surveys_cap(solver, bench_instances):
     """CBS on shipped 8x8_obst12 inputs with a cap of 1 000 000 low-level expansions per instance —
     agents10 / 12 inputs that need hundreds of thousands of expansions get real parity, agents16 / 20 cap on both sides."""
