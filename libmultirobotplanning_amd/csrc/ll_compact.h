@@ -716,6 +716,8 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       uint32_t p = 0;
       if (EPS) {  // where is the popped node in the open array?  Lane L looks at elements 4L - 1 .. 4L + 2 of a group.
         const V key = splat(curE & C::kStateMask);
+        // (narrow geometry: no early exit — a state is in the open array exactly once, and a loop with one exit compiles to
+        // half the scalar bookkeeping; the groups behind the hit cost one LDS read each)
         for (uint32_t g = 0; g < kGroups && g * 256u <= nOld; ++g) {  // (element 256 g - 1 belongs to group g)
           const V4 grp = ldsLoad128(lds, splat(oOpen + g * 1024u) + lane * 16u);
           const B m0 = (grp.x & C::kStateMask) == key, m1 = (grp.y & C::kStateMask) == key, m2 = (grp.z & C::kStateMask) == key,
@@ -724,7 +726,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
           if (any) {
             const V pos = lane * 4u + sel(m0, splat(0xFFFFFFFFu), sel(m1, splat(0u), sel(m2, splat(1u), splat(2u))));
             p = g * 256u + readlane(pos, ctz64(any));
-            break;
+            if (kGroups > 4u) break;  // (the wide geometry: up to twelve groups, worth leaving early)
           }
         }
       }
