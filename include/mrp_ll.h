@@ -145,13 +145,15 @@ typedef struct mrp_ll_job {
   /* MRP_LL_ASTAR_TA only: the shortest-path table of this job's goal cell (mrp_ll_upload_heuristic); ignored with
    * MRP_LL_JOB_NO_GOAL.  (Zero-initialised jobs of the other algorithms never look at it.) */
   int32_t heuristic_id;
-  int32_t reserved3;
+  int32_t chain_count;     /* MRP_LL_JOB_ROOT_CHAIN: plan at most this many agents (0 = all from agent_idx on): a caller with many
+                            * agents cuts the root step into jobs of bounded length; the agents behind come back MRP_LL_NOT_RUN */
   /* MRP_LL_JOB_ROOT_CHAIN only: [n_agents][4] = start x, start y, goal x, goal y of every agent of the instance. */
   const int32_t* chain_starts_goals_xy;
 } mrp_ll_job;
 
 #define MRP_LL_JOB_STORE_RESULT 1 /* mrp_ll_job.flags: also leave the result path in path-store slot result_path_id */
-/* MRP_LL_JOB_ROOT_CHAIN (sessions of MRP_LL_ASTAR_EPS with a path store; maps up to 32 x 32, at most 32 agents): ONE job
+/* MRP_LL_JOB_ROOT_CHAIN (sessions of MRP_LL_ASTAR_EPS with a path store; maps up to 32 x 32, at most 128 agents, and room
+ * for the 64-row focal table of all agents in the LDS window — mrp_ll_configure_tiers' lds_path_bytes): ONE job
  * that is the root step of an ECBS conflict tree (ecbs.hpp:118-136) from agent `agent_idx` on: agent a = agent_idx ..
  * n_agents - 1 is planned with no constraints against the paths of the agents 0 .. a - 1, one after the other, by one
  * workgroup that keeps the focal context in LDS.  path_ids[n_agents] names the path-store slot of EVERY agent: where the

@@ -367,6 +367,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     // a root chain (MRP_LL_JOB_ROOT_CHAIN): ONE job whose result fans out into chainRes, one per agent from chainFirst on
     std::vector<mrp_ll_result> chainRes;
     int32_t chainFirst = -1;
+    int32_t chainCount = 0;           // agents the job was asked to plan (MRP_LL_NOT_RUN behind them is not a tier overflow)
     std::vector<LLRequest> chainReq;  // the request the chain was made from (restored if the chain ran nothing)
   };
   // f2: slots of the engine's device-resident path store, handed to the searches of this worker for their result paths;
@@ -391,6 +392,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
 
   std::vector<int32_t> chainIds, chainXy;
   const bool chainDebug = std::getenv("MRP_HL_CHAIN_DEBUG") != nullptr;  // one line per chain answer on stderr
+  const int32_t chainChunk = std::getenv("MRP_HL_CHAIN_CHUNK") ? std::max(1, std::atoi(std::getenv("MRP_HL_CHAIN_CHUNK"))) : 8;
   // MRP_HL_ROOT_CHAIN=0: every root search is its own job (A/B; results are the same)
   // (not const: an engine that cannot run chains — no compact tier, a window too small for the chain's focal table —
   // rejects the first one, and this worker goes on with one job per root search)
@@ -441,7 +443,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     // later one against the paths before them and keeps the focal table in LDS; the host sees one completion instead of
     // ten.  Only when every existing path sits in the device store and there are slots for the new ones.
     if (rootChains && group == kRootGroup && I.algo() == MRP_HL_ECBS && L.req[L.reqHead].context &&
-        L.reqHead + 1 == L.req.size() && I.nAgents() >= 2 && I.nAgents() <= 32 && L.req[L.reqHead].agent != L.noChainAgent) {
+        L.reqHead + 1 == L.req.size() && I.nAgents() >= 2 && I.nAgents() <= 128 && L.req[L.reqHead].agent != L.noChainAgent) {
       const LLRequest& r = L.req[L.reqHead];
       const int32_t nA = I.nAgents(), first = r.agent;
       chainIds.assign(nA, -1);
@@ -476,6 +478,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
         j.max_expansions = I.remainingLL();
         j.result_path_id = -1;
         j.flags = MRP_LL_JOB_ROOT_CHAIN;
+        // many agents: jobs of at most eight searches — a root step of fifty searches in ONE job holds its wavefront for
+        // tens of milliseconds, and the two-search rounds of deep conflict trees queue behind such jobs (measured at fifty
+        // agents: the step 26 % longer than with one job per root search)
+        j.chain_count = nA > 32 ? chainChunk : 0;
         int32_t pi;
         if (!pendFree.empty()) {
           pi = pendFree.back();
@@ -489,6 +495,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
         P.live = k;
         P.group = group;
         P.chainFirst = first;
+        P.chainCount = j.chain_count > 0 ? std::min(j.chain_count, nA - first) : nA - first;
         P.outSlot.assign(chainIds.begin() + first, chainIds.end());
         P.chainRes.assign(static_cast<size_t>(cnt), mrp_ll_result());
         P.states.resize(static_cast<size_t>(cnt) * static_cast<size_t>(cap) * 3);
@@ -832,7 +839,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
           ans.clear();
           retire(k);
         }
-        if (L.inst && q < cnt && P.chainRes[q].status == MRP_LL_NOT_RUN) {
+        if (L.inst && q < cnt && static_cast<int32_t>(q) < P.chainCount && P.chainRes[q].status == MRP_LL_NOT_RUN) {
           // the search of this agent did not fit the compact tier: it goes as an ordinary job (any tier), chains resume behind it
           L.noChainAgent = P.chainFirst + static_cast<int32_t>(q);
           if (q == 0) {  // nothing was delivered, so nothing re-created the request

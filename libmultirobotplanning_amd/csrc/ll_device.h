@@ -62,14 +62,15 @@ constexpr uint32_t kCtxById = 1u;
 // Output (the job slot's host area, words): per planned agent eight words {status, cost, fmin, n_states, expanded,
 // offset of its path in words, 0, 0}, then the paths (x | y << 8 halfwords).  DevResult: n_states = entries written,
 // expanded = their sum.  The chain stops behind a search that found no path or ran into the expansion budget, and IN
-// FRONT OF one that outgrows the compact tier (the caller submits that one as an ordinary job).
+// FRONT OF one that outgrows the compact tier (the caller submits that one as an ordinary job).  `reserved` = one past the
+// last agent this job plans (a caller with many agents cuts the root step into jobs of bounded length).
 constexpr uint32_t kCtxChain = 32u;
 // ctx_flags bit 6 (MRP_LL_JOB_HEAVY): the caller knows that this search outgrows the compact tier (a root chain stopped in
 // front of it): no attempt there — a front workgroup hands it to the heavy workgroups at once, an all-tier kernel starts
 // it in the arena tier.
 constexpr uint32_t kCtxHeavy = 64u;
 constexpr uint32_t kChainEntryWords = 8;
-constexpr uint32_t kChainMaxAgents = 32;
+constexpr uint32_t kChainMaxAgents = 128;                          // (what the compact tier's focal context holds: two 64-lane row loads)
 constexpr uint32_t kChainRows = 64;                                // rows of the chain's focal table (the compact tier ends at t = 62)
 // MRP_LL_SIPP with a device-resident table (mrp_ll_sipp_table_* in a session): ctx_flags bit 1.  The table lives in
 // device memory at the 64-bit address (n_agents_pad | path_off << 32), in a fixed-capacity layout the search reads directly:

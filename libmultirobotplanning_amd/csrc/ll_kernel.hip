@@ -1341,6 +1341,7 @@ DEVI void runChain(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_
   constexpr bool BG = true;
   const uint32_t lane = threadIdx.x;
   const uint32_t n = J.n_ctx, first = J.t_pad, npad = J.n_agents_pad;
+  const uint32_t end = J.reserved > first && J.reserved < n ? J.reserved : n;  // one past the last agent of this job
   res.tier = 0;
   res.n_states = 0;
   res.expanded = 0;
@@ -1372,7 +1373,7 @@ DEVI void runChain(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_
   uint32_t done = 0, maxLen = 0;
   bool allOk = true;
   int64_t total = 0;
-  for (uint32_t a = first; a < n; ++a) {
+  for (uint32_t a = first; a < end; ++a) {
     const uint32_t sg = rfl(hostLoad32(who + a));
     ct::CJob cj;
     cj.dimx = J.dimx; cj.dimy = J.dimy;
@@ -1461,7 +1462,7 @@ DEVI void runChain(const LaunchParams& P, const DevJob& J, uint8_t* smem, uint8_
   //   vertex conflict at t: state_i(t) == state_j(t);  edge conflict: state_i(t) == state_j(t+1) && state_i(t+1) == state_j(t)
   // Lane = time step (every path of this tier has at most 63 states); the first conflict is the smallest
   // (t, vertex before edge, i, j).  Seven instances in ten of the ten-agent workload end here: HL 1, no conflict.
-  if (first == 0 && done == n && allOk && maxLen >= 1u && maxLen <= kChainRows) {
+  if (first == 0 && end == n && done == n && allOk && maxLen >= 1u && maxLen <= kChainRows) {
     const uint32_t T = maxLen - 1u;  // <= 62
     const bool inT = lane < T;
     const uint32_t rowC = lane * npad, rowN = (lane + 1u < kChainRows ? lane + 1u : kChainRows - 1u) * npad;

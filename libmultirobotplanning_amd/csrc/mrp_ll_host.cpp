@@ -760,6 +760,7 @@ bool packJob(mrp_ll_ctx* ctx, const mrp_ll_job& j, ConsSink& cs, PathSink& ps, D
     d.t_pad = static_cast<uint32_t>(first);
     d.n_agents_pad = static_cast<uint32_t>((n + 15) & ~15);
     d.store_out_id = mrp::kNoStoreSlot;
+    d.reserved = static_cast<uint32_t>(j.chain_count > 0 ? std::min(n, first + j.chain_count) : n);  // one past the last agent planned
     d.vc_off = static_cast<uint32_t>(cs.size());
     for (int a = 0; a < n; ++a) {
       const int32_t* q = j.chain_starts_goals_xy + 4 * a;
@@ -1361,7 +1362,8 @@ static int sessionBegin(mrp_ll_ctx* ctx, int32_t workgroups, bool sipp, int kind
   if (rc != MRP_LL_SUCCESS) return rc;
   const uint32_t R = Ring::kSlots;
   // halfwords per job slot of the host output area: a path, or the output of a root chain (ll_device.h kCtxChain)
-  g.outStride = std::max<uint32_t>(static_cast<uint32_t>(ctx->opt.max_horizon), 4096u);
+  // (a chain of 128 agents: 16 halfwords of header + up to 64 states each)
+  g.outStride = std::max<uint32_t>(static_cast<uint32_t>(ctx->opt.max_horizon), mrp::kChainMaxAgents * 80u);
   if (!g.block) {
     size_t off = 0;
     auto take = [&](size_t bytes) {

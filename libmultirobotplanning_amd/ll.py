@@ -40,7 +40,7 @@ class mrp_ll_job(ctypes.Structure):
                 ("n_collision_locations", ctypes.c_int32), ("collision_xy", I32P), ("collision_count", I32P),
                 ("collision_intervals", I32P), ("initial_cost", ctypes.c_int32), ("sipp_commit", ctypes.c_int32),
                 ("sipp_table", ctypes.c_void_p), ("path_ids", I32P), ("result_path_id", ctypes.c_int32),
-                ("flags", ctypes.c_int32), ("heuristic_id", ctypes.c_int32), ("reserved3", ctypes.c_int32),
+                ("flags", ctypes.c_int32), ("heuristic_id", ctypes.c_int32), ("chain_count", ctypes.c_int32),
                 ("chain_starts_goals_xy", I32P)]
 
 

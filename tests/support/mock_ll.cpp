@@ -56,6 +56,7 @@ int mrp_ll_upload_map(mrp_ll_ctx* c, int32_t dimx, int32_t dimy, int32_t n, cons
 static void mockChain(mrp_ll_ctx* c, const mrp_ll_job& j, mrp_ll_result& r) {
   const MockMap& m = c->maps[j.map_id];
   const int n = j.n_agents, first = j.agent_idx;
+  const int end = j.chain_count > 0 ? std::min(n, first + j.chain_count) : n;
   const char* bk = std::getenv("MRP_MOCK_CHAIN_BREAK");
   const int64_t breakAt = bk ? std::atoll(bk) : -1;
   int64_t budget = j.max_expansions, total = 0;
@@ -67,7 +68,7 @@ static void mockChain(mrp_ll_ctx* c, const mrp_ll_job& j, mrp_ll_result& r) {
     ri.status = MRP_LL_NOT_RUN;
     ri.cost = ri.fmin = ri.n_states = 0;
     ri.expanded = 0;
-    if (stopped) continue;
+    if (stopped || a >= end) continue;
     std::vector<int32_t> ctxLen, ctxXY;
     for (int b = 0; b < n; ++b) {
       const std::vector<int32_t>* p = b < a ? &c->store[j.path_ids[b]] : nullptr;
@@ -117,7 +118,7 @@ static void mockChain(mrp_ll_ctx* c, const mrp_ll_job& j, mrp_ll_result& r) {
   r.expanded = total;
   // the root node's conflicts (mrp_ll.h): the oracle's getFirstConflict + focalHeuristic over the chain's paths
   r.cost = r.fmin = -1;
-  if (first == 0 && done == n && !stopped) {
+  if (first == 0 && end == n && done == n && !stopped) {
     std::vector<int32_t> len, xy;
     for (int a = 0; a < n; ++a) {
       const std::vector<int32_t>& p = c->store[j.path_ids[a]];
