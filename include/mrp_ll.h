@@ -241,7 +241,7 @@ int mrp_ll_path_store_reserve(mrp_ll_ctx* ctx, int32_t n_slots);
  * appends [s, e] to that location's collision list and is equivalent to calling setCollisionIntervals(location, list)
  * with the extended list.  A table belongs to one map (its dimensions); it is not thread-safe.
  * In a session (mrp_ll_session_begin_sipp) the table also has a DEVICE-RESIDENT copy: a job on it carries only the cells
- * changed since the table's previous job, and the search reads the copy in place (up to 16 safe intervals per cell; a
+ * changed since the table's previous job, and the search reads the copy in place (up to 15 safe intervals per cell, bounds below 65535; a
  * table that needs more, and any table outside a session, travels whole with each job — same results).  One job per
  * table is in flight at a time (a second one simply travels whole).  mrp_ll_job.sipp_commit lets the engine add the
  * found path's stays itself. */

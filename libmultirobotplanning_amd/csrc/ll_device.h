@@ -74,12 +74,17 @@ constexpr uint32_t kChainMaxAgents = 128;                          // (what the 
 constexpr uint32_t kChainRows = 64;                                // rows of the chain's focal table (the compact tier ends at t = 62)
 // MRP_LL_SIPP with a device-resident table (mrp_ll_sipp_table_* in a session): ctx_flags bit 1.  The table lives in
 // device memory at the 64-bit address (n_agents_pad | path_off << 32), in a fixed-capacity layout the search reads directly:
-//   cnt[cells] bytes (0 = the default single interval, n + 1 = n safe intervals), padded to 256 bytes,
-//   iv[cells][kSippCap][2] int32 {start, end},
-//   status[cells][kSippCap] words  epoch << 24 | closed << 23 | node + 1   (a word of another epoch reads as "unseen").
-// cons[vc_off] holds only the DELTA since the table's previous job: ec_off & 0x7FFFFFFF records (bit 31: zero cnt and
-// status first), as  hdr[nRec]  (cell | count << 16; padded to a multiple of 4 words)  then  nRec x n_vc x {start, end}
-// (n_vc = room per record of this job: the longest list among its records, as a power of two >= 2).
+// two 64-byte rows per cell —
+//   bounds[cells][16]  words 0 .. 14: interval i as  start | end << 16, both below kSippEndInf, end == kSippEndInf: INT_MAX;
+//                      word 15: 0 = the default single interval [0, INT_MAX], n + 1 = n safe intervals (n <= kSippCap)
+//   status[cells][16]  word i:  epoch << 24 | closed << 23 | node + 1   (a word of another epoch reads as "unseen")
+// — so a neighbour cell costs an expansion one 64-byte sector that the search only reads (count and bounds: it stays in
+// the L1 of the CU) and one that it also writes.  (Measured, scripts/r4_run23.sh: ONE 128-byte record per cell with count,
+// bounds and status words interleaved is slower than the three separate arrays of round 3, 2.59 against 2.27 us per
+// expansion — every status write takes the line with the bounds out of the L1.)
+// cons[vc_off] holds only the DELTA since the table's previous job: ec_off & 0x7FFFFFFF records (bit 31: zero the table
+// first), as  hdr[nRec]  (cell | count << 16; padded to a multiple of 4 words)  then  nRec x n_vc bounds words
+// (n_vc = room per record of this job: the longest list among its records, as a power of two >= 4).
 // n_ctx = the job's epoch (1..255).  One job per table in flight.  The workgroup finds the start interval itself
 // (findSafeInterval, sipp.hpp:286-296) — the host's copy of the table may be behind the device's (kSippCommit).
 constexpr uint32_t kTaNoGoal = 16u;                                // MRP_LL_ASTAR_TA: ctx_flags bit 4: the agent has no task; path_off =
@@ -90,7 +95,9 @@ constexpr uint32_t kSippCommit = 8u;                               // ctx_flags 
 constexpr uint32_t kSippTierCommitFailed = 0x100u;                 // DevResult.tier flag: a stay did not fit (more than kSippCap intervals,
                                                                    // or no safe interval contains it): the host redoes the table
 constexpr uint32_t kSippNoLds = 4u;                                // ctx_flags bit 2: keep nodes and open list in the arena (MRP_LL_SIPP_NO_LDS=1)
-constexpr uint32_t kSippCap = 16;                                  // safe intervals per cell the resident layout holds
+constexpr uint32_t kSippCap = 15;                                  // safe intervals per cell the resident layout holds
+constexpr uint32_t kSippRowWords = 16;                             // words of a cell's bounds row and of its status row
+constexpr uint32_t kSippEndInf = 0xFFFFu;                          // "ends at INT_MAX" in a bounds word; finite bounds are below it
 constexpr uint32_t kSippEpochShift = 24, kSippEpochMax = 255;
 constexpr uint32_t kSippStClosed = 1u << 23;
 

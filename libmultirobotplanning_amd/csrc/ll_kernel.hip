@@ -42,8 +42,8 @@ typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
 // SIPP node "x" word as the search loop sees it: cell | interval << 16 | (interval ends at INT_MAX) << 31.  Packed forms
 // (LDS node records, TierXT heap entries) squeeze it to kSippXBits = 16 + kSippIvBits + 1 bits.
-constexpr uint32_t kSippIvBits = 4;  // kSippCap = 16 intervals per cell
-static_assert((1u << kSippIvBits) == kSippCap, "interval index width");
+constexpr uint32_t kSippIvBits = 4;  // kSippCap = 15 intervals per cell
+static_assert((1u << kSippIvBits) > kSippCap, "interval index width");
 constexpr uint32_t kSippXBits = 16 + kSippIvBits + 1;                       // 21
 constexpr uint32_t kSippXLow = (1u << (16 + kSippIvBits)) - 1u;             // cell and interval
 DEVI uint32_t sippPackX(uint32_t x) { return (x & kSippXLow) | (x >> 31) << (16 + kSippIvBits); }
@@ -1762,8 +1762,9 @@ constexpr int32_t kIntMax = 0x7FFFFFFF;
 // Where runSipp finds a cell's safe intervals and a state's open/closed status.
 //   RES = false: the job's own compact table, copied from the host into the arena (layout above); status words
 //                (0 unseen, node + 1 in open, bit 31 closed) in the arena too, zeroed per job.
-//   RES = true:  the device-resident table of an mrp_ll_sipp_table (ll_device.h kSippResident): cnt byte per cell,
-//                kSippCap interval slots per cell, status words tagged with the job's epoch so nothing is zeroed per job.
+//   RES = true:  the device-resident table of an mrp_ll_sipp_table (ll_device.h kSippResident): per cell a 64-byte row
+//                of bounds words + count (`ivals`) and a 64-byte row of status words, tagged with the job's epoch so
+//                nothing is zeroed per job.
 template <bool RES>
 struct SippView {
   static constexpr uint32_t kClosed = RES ? kSippStClosed : 0x80000000u;
@@ -1777,8 +1778,8 @@ struct SippView {
   // nk != 0: the cell has its own interval list, `n` entries from ivals[2 * first]; nk == 0: the default [0, INT_MAX]
   DEVI void lookup(uint32_t cell, uint32_t& nk, uint32_t& first, uint32_t& n) const {
     if constexpr (RES) {
-      nk = cnt[cell];
-      first = cell * kSippCap;
+      nk = (uint32_t)ivals[cell * kSippRowWords + 15u];
+      first = 0;
       n = nk ? nk - 1 : 1;
     } else {
       nk = cellIdx[cell];
@@ -1791,7 +1792,7 @@ struct SippView {
     }
   }
   DEVI uint32_t sid(uint32_t cell, uint32_t nk, uint32_t first, uint32_t i) const {
-    if constexpr (RES) return cell * kSippCap + i;
+    if constexpr (RES) return cell * kSippRowWords + i;
     return nk ? cells + first + i : cell;
   }
   DEVI uint32_t getSt(uint32_t id) const {
@@ -1800,6 +1801,10 @@ struct SippView {
     return v;
   }
   DEVI void putSt(uint32_t id, uint32_t v) const { status[id] = RES ? (v | epochBits) : v; }
+  // a bounds word of the resident table (ll_device.h)
+  DEVI static int32_t bStart(uint32_t w) { return (int32_t)(w & 0xFFFFu); }
+  DEVI static int32_t bEnd(uint32_t w) { return (w >> 16) == kSippEndInf ? 0x7FFFFFFF : (int32_t)(w >> 16); }
+  DEVI static uint32_t bPack(int32_t s, int32_t e) { return (uint32_t)s | (e == 0x7FFFFFFF ? kSippEndInf : (uint32_t)e) << 16; }
 };
 
 // SIPP node records.  Arena tier: u32x4 { x = cell | interval << 16 | (RES: interval ends at INT_MAX) << 31, parent, g,
@@ -1910,13 +1915,15 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
     const uint32_t cx = cell % dimx, cy = cell / dimx;
     // RES: every table word this expansion needs has an address that follows from (cell, iv) alone — the cell's own
     // list length and interval end, and for the four neighbours (lanes 16 * motion + i) the obstacle word, the list
-    // length, interval slot i and its status word.  All of it is requested here, in ONE round trip to HBM, and the
-    // heap pop below (LDS tier) runs while it is in flight; slots beyond a list's length hold stale words that are
-    // loaded and ignored.  "Ends at INT_MAX", which the goal test needs at once, rides in bit 31 of the node's x.
+    // length, interval slot i and its status word: two 64-byte sectors per cell.  All of
+    // it is requested here, in ONE round trip, and the heap pop below (LDS tier) runs while it is in flight; slots beyond
+    // a list's length hold stale words that are loaded and ignored.  "Ends at INT_MAX", which the goal test needs at
+    // once, rides in bit 31 of the node's x.
     uint32_t ck = 0, f0 = 0, nCur = 0;
     int32_t endT = kIntMax;
     uint32_t r_nc = 0, r_obstW = 0xFFFFFFFFu, r_nk = 0, r_st = 0, r_ck = 0, r_h = 0;
-    int32_t r_s = 0, r_e = kIntMax, r_endT = kIntMax;
+    uint32_t r_bw = 0, r_endW = 0;  // raw bounds words: decoded where they are used, BEHIND the heap pop (a decode here
+                                    // would make the wavefront wait for the table before it pops)
     bool r_inb = false;
     if constexpr (RES) {
       const uint32_t mm = lane >> 4, i = lane & 15u;
@@ -1924,15 +1931,14 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
       r_inb = nx < dimx && ny < dimy;
       r_nc = r_inb ? ny * dimx + nx : 0;
       r_h = (nx > gx ? nx - gx : gx - nx) + (ny > gy ? ny - gy : gy - ny);
-      r_ck = tv.cnt[cell];
-      r_endT = ivals[2 * (cell * kSippCap + iv) + 1];
+      const int32_t* rowN = ivals + r_nc * kSippRowWords;
+      r_ck = (uint32_t)ivals[cell * kSippRowWords + 15u];
+      r_endW = (uint32_t)ivals[cell * kSippRowWords + iv];
       r_obstW = obst[r_nc >> 5];
-      r_nk = tv.cnt[r_nc];
+      r_nk = (uint32_t)rowN[15];
       if (i < kSippCap) {
-        const i32x2 se = *(const i32x2*)(ivals + 2 * (r_nc * kSippCap + i));
-        r_s = se.x;
-        r_e = se.y;
-        r_st = tv.status[r_nc * kSippCap + i];
+        r_bw = (uint32_t)rowN[i];
+        r_st = tv.status[r_nc * kSippRowWords + i];
       }
       if (!(cw >> 31)) endT = 0;  // any finite value: the goal test below only asks whether it is INT_MAX
     } else {
@@ -1979,8 +1985,8 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
     heapPop<T, 0, true>(g, g.open, nOpen);
     if constexpr (RES) {
       ck = rfl(r_ck);
-      f0 = cell * kSippCap;
-      if (ck) endT = rfli(r_endT);
+      f0 = 0;
+      if (ck) endT = SippView<RES>::bEnd(rfl(r_endW));
       else endT = kIntMax;
     }
     const uint32_t curSid = tv.sid(cell, ck, f0, iv);
@@ -2029,14 +2035,14 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
         nkM = r_nk;
         ncM = r_nc;
         hM = r_h;
-        firstM = r_nc * kSippCap;
+        firstM = 0;
         cntM = valid ? (nkM ? nkM - 1 : 1u) : 0u;
         act = i < cntM;
-        sidL = r_nc * kSippCap + i;
+        sidL = tv.sid(r_nc, 0, 0, i);
         if (act) {
           if (nkM) {
-            siS = r_s;
-            siE = r_e;
+            siS = SippView<RES>::bStart(r_bw);
+            siE = SippView<RES>::bEnd(r_bw);
           }
           stL = (r_st >> kSippEpochShift) == (tv.epochBits >> kSippEpochShift) ? (r_st & ((1u << kSippEpochShift) - 1u)) : 0u;
         }
@@ -2205,7 +2211,6 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
 // intervals or a stay is not inside a safe interval: the table is then left half-updated and the host redoes it.
 DEVI bool sippCommitPath(const SippView<true>& tv, const uint32_t* path, uint32_t len) {
   const uint32_t lane = threadIdx.x;
-  uint8_t* cnt8 = (uint8_t*)tv.cnt;
   bool bad = false;
   for (uint32_t base = 0; base < len; base += 64) {
     const uint32_t k = base + lane;
@@ -2226,16 +2231,21 @@ DEVI bool sippCommitPath(const SippView<true>& tv, const uint32_t* path, uint32_
     for (uint32_t turn = 0; todo; ++turn) {
       const bool mine = act && rank == turn;
       if (mine) {
-        const uint32_t n1 = cnt8[cell];
+        u32x4* row4 = (u32x4*)(tv.ivals + cell * kSippRowWords);  // bounds words 0 .. 14, the count in word 15
+        uint32_t rw[kSippRowWords];
+#pragma unroll
+        for (uint32_t v4 = 0; v4 < kSippRowWords / 4; ++v4) {
+          const u32x4 v = row4[v4];
+          rw[4 * v4] = v.x; rw[4 * v4 + 1] = v.y; rw[4 * v4 + 2] = v.z; rw[4 * v4 + 3] = v.w;
+        }
+        const uint32_t n1 = rw[15];
         const uint32_t n = n1 ? n1 - 1 : 1u;
-        u32x4* row4 = (u32x4*)(tv.ivals + 2 * cell * kSippCap);
         int32_t rs[kSippCap], re[kSippCap];
         if (n1) {
 #pragma unroll
-          for (uint32_t q = 0; q < kSippCap / 2; ++q) {
-            const u32x4 v = row4[q];
-            rs[2 * q] = (int32_t)v.x; re[2 * q] = (int32_t)v.y;
-            rs[2 * q + 1] = (int32_t)v.z; re[2 * q + 1] = (int32_t)v.w;
+          for (uint32_t q = 0; q < kSippCap; ++q) {
+            rs[q] = SippView<true>::bStart(rw[q]);
+            re[q] = SippView<true>::bEnd(rw[q]);
           }
         } else {
 #pragma unroll
@@ -2278,14 +2288,17 @@ DEVI bool sippCommitPath(const SippView<true>& tv, const uint32_t* path, uint32_
             ns[q] = vs;
             ne[q] = ve;
           }
+          // (slots beyond the new list get whatever the shift brought along; nobody reads them.  The status words are
+          // left alone: they belong to this job's epoch, and the next job of the table has another)
 #pragma unroll
-          for (uint32_t q = 0; q < kSippCap / 2; ++q) {
+          for (uint32_t q = 0; q < kSippCap; ++q) rw[q] = SippView<true>::bPack(ns[q] & 0xFFFF, ne[q] == kIntMax ? kIntMax : (ne[q] & 0xFFFF));
+          rw[15] = n + d + 1;
+#pragma unroll
+          for (uint32_t v4 = 0; v4 < kSippRowWords / 4; ++v4) {
             u32x4 v;
-            v.x = (uint32_t)ns[2 * q]; v.y = (uint32_t)ne[2 * q];
-            v.z = (uint32_t)ns[2 * q + 1]; v.w = (uint32_t)ne[2 * q + 1];
-            row4[q] = v;
+            v.x = rw[4 * v4]; v.y = rw[4 * v4 + 1]; v.z = rw[4 * v4 + 2]; v.w = rw[4 * v4 + 3];
+            row4[v4] = v;
           }
-          cnt8[cell] = (uint8_t)(n + d + 1);
         }
       }
       todo &= ~ballot64(mine);
@@ -2347,12 +2360,10 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
   tv.uncached = 0;
   if constexpr (RES) {
     uint8_t* rt = (uint8_t*)((uint64_t)J.n_agents_pad | ((uint64_t)J.path_off << 32));
-    const uint32_t cntBytes = (cells + 255u) & ~255u;
-    uint8_t* cnt8 = rt;
-    u32x4* iv4 = (u32x4*)(rt + cntBytes);
-    tv.cnt = cnt8;
-    tv.ivals = (const int32_t*)iv4;
-    tv.status = (uint32_t*)(rt + cntBytes + (size_t)cells * kSippCap * 8);
+    uint32_t* rec = (uint32_t*)rt;  // bounds rows, then status rows (ll_device.h)
+    tv.cnt = nullptr;
+    tv.ivals = (const int32_t*)rec;
+    tv.status = rec + (size_t)cells * kSippRowWords;
     tv.epochBits = J.n_ctx << kSippEpochShift;
     tv.cellIdx = nullptr;
     tv.specFirst = nullptr;
@@ -2364,18 +2375,15 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
     if (J.ec_off >> 31) {  // first job of the table (or its epochs are used up): no cell has a list, no state is seen
       u32x4 z;
       z.x = z.y = z.z = z.w = 0;
-      u32x4* c4 = (u32x4*)cnt8;
-      for (uint32_t i = lane; i < cntBytes / 16; i += 64) c4[i] = z;
-      u32x4* s4 = (u32x4*)tv.status;
-      for (uint32_t i = lane; i < cells * (kSippCap / 4); i += 64) s4[i] = z;
+      u32x4* s4 = (u32x4*)rec;
+      for (uint32_t i = lane; i < cells * (2u * kSippRowWords / 4); i += 64) s4[i] = z;
       __syncthreads();
     }
     // the cells whose lists changed since the table's previous job, out of pinned host memory: lane u copies 16 bytes
-    // of record u / recUnits, four rounds in flight
+    // (four bounds words) of record u / recUnits, four rounds in flight
     const uint32_t* hdr = P.cons + J.vc_off;
     const u32x4* recs = (const u32x4*)(hdr + ((nRec + 3u) & ~3u));
-    constexpr uint32_t kUnits = kSippCap / 2;  // 16-byte units per row of the table
-    const uint32_t recUnits = J.n_vc / 2;      // ... per record of this job (a power of two, 1 .. kUnits)
+    const uint32_t recUnits = J.n_vc / 4;      // 16-byte units per record of this job (a power of two, 1 .. 4)
     const uint32_t recShift = 31u - (uint32_t)__builtin_clz(recUnits | 1u);
     const uint32_t nUnits = nRec * recUnits;
     for (uint32_t u0 = 0; u0 < nUnits; u0 += 256) {
@@ -2394,8 +2402,11 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
         const uint32_t u = u0 + q * 64 + lane;
         if (u < nUnits) {
           const uint32_t cell = h[q] & 0xFFFFu;
-          iv4[cell * kUnits + (u & (recUnits - 1u))] = v[q];
-          if ((u & (recUnits - 1u)) == 0) cnt8[cell] = (uint8_t)((h[q] >> 16) + 1u);
+          // the unit holds bounds words q0 .. q0 + 3; word 15 of a row is the count, which the host has put into the last
+          // word of a 16-word record (packSippResident), and which the lane of unit 0 writes for a shorter one
+          const uint32_t q0 = u & (recUnits - 1u);
+          ((u32x4*)rec)[cell * (kSippRowWords / 4) + q0] = v[q];
+          if (q0 == 0 && recUnits < 4u) rec[cell * kSippRowWords + 15u] = (h[q] >> 16) + 1u;
         }
       }
     }
@@ -2448,16 +2459,16 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
   if constexpr (RES) {
     const uint32_t sc = J.sy * dimx + J.sx;
     const int32_t st0 = J.last_goal_constraint;
-    const uint32_t n1 = rfl((uint32_t)tv.cnt[sc]);
+    const uint32_t n1 = rfl((uint32_t)tv.ivals[sc * kSippRowWords + 15u]);
     if (n1 == 0) {
       startIv = 0;
       startInf = 1;
     } else {
       int32_t a = 0, b = -1;
       if (lane < n1 - 1) {
-        const i32x2 se = *(const i32x2*)(tv.ivals + 2 * (sc * kSippCap + lane));
-        a = se.x;
-        b = se.y;
+        const uint32_t bw = (uint32_t)tv.ivals[sc * kSippRowWords + lane];
+        a = SippView<true>::bStart(bw);
+        b = SippView<true>::bEnd(bw);
       }
       const uint64_t hit = ballot64(lane < n1 - 1 && a <= st0 && b >= st0);
       if (hit) {

@@ -571,19 +571,24 @@ bool packSippResident(mrp_ll_ctx* ctx, const mrp_ll_job& j, const MapRec& mp, Co
   } else {
     for (int32_t cell : T.dirty) longest = std::max(longest, T.spec[T.cellIdx[cell] - 1].safe.size());
   }
-  size_t recIv = 2;
+  size_t recIv = 4;  // bounds words per record: whole 16-byte units
   while (recIv < longest) recIv *= 2;
   const size_t hdrWords = (nRec + 3) & ~size_t(3);
-  if ((cs.size() & 3u) != 0 || !cs.fits(hdrWords + nRec * 2 * recIv)) return false;  // nothing consumed yet
+  if ((cs.size() & 3u) != 0 || !cs.fits(hdrWords + nRec * recIv)) return false;  // nothing consumed yet
   d.vc_off = static_cast<uint32_t>(cs.size());
-  uint32_t* hdr = cs.grow(hdrWords + nRec * 2 * recIv);
+  uint32_t* hdr = cs.grow(hdrWords + nRec * recIv);
   if (!hdr) return false;
   uint32_t* body = hdr + hdrWords;
   size_t r = 0;
   auto emit = [&](int32_t cell) {
     const mrp_ll_sipp_table::Spec& sp = T.spec[T.cellIdx[cell] - 1];
     hdr[r] = static_cast<uint32_t>(cell) | (static_cast<uint32_t>(sp.safe.size()) << 16);
-    std::memcpy(body + r * 2 * recIv, sp.safe.data(), sizeof(SippScratch::Iv) * sp.safe.size());
+    uint32_t* b = body + r * recIv;
+    for (size_t q = 0; q < recIv; ++q)  // start | end << 16 (ll_device.h; T.overflow has vouched for the ranges)
+      b[q] = q < sp.safe.size() ? static_cast<uint32_t>(sp.safe[q].s) |
+                                      (sp.safe[q].e == INT32_MAX ? mrp::kSippEndInf : static_cast<uint32_t>(sp.safe[q].e)) << 16
+                                : 0u;
+    if (recIv == mrp::kSippRowWords) b[15] = static_cast<uint32_t>(sp.safe.size()) + 1u;  // a whole row: its last word is the count
     r += 1;
   };
   if (fresh) {
@@ -2194,7 +2199,7 @@ int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t mapId, mrp_ll_sipp_table**
   // an error: such a table simply ships its whole contents with every job.
   if (ctx->sippTabStride == 0) {
     const size_t maxCells = static_cast<size_t>(ctx->opt.max_cells);
-    ctx->sippTabStride = ((maxCells + 255) & ~size_t(255)) + maxCells * mrp::kSippCap * 12;  // cnt, iv, status
+    ctx->sippTabStride = maxCells * mrp::kSippRowWords * 8;  // a bounds row and a status row per cell (ll_device.h)
     ctx->sippTabsPerChunk = static_cast<int32_t>(std::max<size_t>(1, std::min<size_t>(64, (size_t(64) << 20) / ctx->sippTabStride)));
   }
   if (!ctx->sippTabFree.empty()) {
@@ -2260,7 +2265,12 @@ void sippTableAddCell(mrp_ll_sipp_table* t, size_t cell, int32_t start, int32_t 
     safeFromCollisions(sp.collisions.data(), static_cast<int>(sp.collisions.size() / 2), t->scratch, sp.safe);
   }
   t->totalSafe += static_cast<uint32_t>(sp.safe.size());
-  if (sp.safe.size() > mrp::kSippCap) t->overflow = true;  // from now on this table travels whole (packSippFromTable)
+  // what the resident layout cannot hold — more than kSippCap intervals on a cell, a finite bound that does not fit a
+  // halfword: from now on this table travels whole (packSippFromTable)
+  if (sp.safe.size() > mrp::kSippCap) t->overflow = true;
+  for (const SippScratch::Iv& v : sp.safe)
+    if (v.s < 0 || v.s >= static_cast<int32_t>(mrp::kSippEndInf) || (v.e != INT32_MAX && (v.e < 0 || v.e >= static_cast<int32_t>(mrp::kSippEndInf))))
+      t->overflow = true;
   if (markDirty && !t->isDirty[cell]) {
     t->isDirty[cell] = 1;
     t->dirty.push_back(static_cast<int32_t>(cell));

@@ -689,7 +689,7 @@ def test_sipp_device_resident_tables(oracle_mod):
     """mrp_ll_sipp_table_* inside a SIPP session: the table lives on the device and a job carries only the cells that
     changed since the table's previous job.  A prioritized-planner-like sequence (search, add intervals, search ...) on
     several tables at once must match the oracle job by job — including a table that outgrows the resident layout
-    (a cell with more than 16 safe intervals: falls back to whole tables), more jobs on one table than there are epochs
+    (a cell with more than 15 safe intervals: falls back to whole tables), more jobs on one table than there are epochs
     (the status words are re-zeroed), two jobs on one table in flight (the second travels whole), a start time inside a
     collision interval (no start interval; the delta must still be applied) and the table surviving session boundaries."""
     import random
@@ -766,6 +766,11 @@ def test_sipp_device_resident_tables(oracle_mod):
                 # what a prioritized planner does next: the cells of this agent's path become collision intervals
                 for c in rng.sample(free, rng.randrange(1, 25)):
                     tb.add(c)
+            if rnd == 10:
+                tabs[5].add(free[7], n=14)                    # 14 collision intervals -> 15 safe intervals: the layout's last slot
+            if rnd == 12:                                     # a bound that does not fit the layout's halfwords: travels whole
+                tabs[4].cis.setdefault(tuple(free[9]), []).append([70000, 70010])
+                eng.sipp_table_add(tabs[4].h, free[9][0], free[9][1], 70000, 70010)
             if rnd == 20:
                 tabs[2].add(free[5], n=20)                    # 20 collision intervals -> 21 safe intervals: beyond the layout
         small = (eng.stats()["staged_bytes"] - st0) / n_jobs
