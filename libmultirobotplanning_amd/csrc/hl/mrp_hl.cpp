@@ -393,6 +393,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   std::vector<int32_t> chainIds, chainXy;
   const bool chainDebug = std::getenv("MRP_HL_CHAIN_DEBUG") != nullptr;  // one line per chain answer on stderr
   const int32_t chainChunk = std::getenv("MRP_HL_CHAIN_CHUNK") ? std::max(1, std::atoi(std::getenv("MRP_HL_CHAIN_CHUNK"))) : 8;
+  // Between 33 and 63 agents the root step goes out one job per search: measured at fifty agents every form of chain
+  // (whole, or in jobs of 4 / 8 / 16 searches) is 5-25 % slower than that, at a hundred agents jobs of eight are 15 %
+  // faster (scripts/r4_run19.sh, r4_run20.sh)
+  const int32_t chainChunkFrom = std::getenv("MRP_HL_CHAIN_CHUNK_FROM") ? std::atoi(std::getenv("MRP_HL_CHAIN_CHUNK_FROM")) : 64;
   // MRP_HL_ROOT_CHAIN=0: every root search is its own job (A/B; results are the same)
   // (not const: an engine that cannot run chains — no compact tier, a window too small for the chain's focal table —
   // rejects the first one, and this worker goes on with one job per root search)
@@ -443,7 +447,8 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     // later one against the paths before them and keeps the focal table in LDS; the host sees one completion instead of
     // ten.  Only when every existing path sits in the device store and there are slots for the new ones.
     if (rootChains && group == kRootGroup && I.algo() == MRP_HL_ECBS && L.req[L.reqHead].context &&
-        L.reqHead + 1 == L.req.size() && I.nAgents() >= 2 && I.nAgents() <= 128 && L.req[L.reqHead].agent != L.noChainAgent) {
+        L.reqHead + 1 == L.req.size() && I.nAgents() >= 2 && I.nAgents() <= 128 && (I.nAgents() <= 32 || I.nAgents() >= chainChunkFrom) &&
+        L.req[L.reqHead].agent != L.noChainAgent) {
       const LLRequest& r = L.req[L.reqHead];
       const int32_t nA = I.nAgents(), first = r.agent;
       chainIds.assign(nA, -1);
