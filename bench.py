@@ -311,7 +311,8 @@ def main():
                 "per_launch": {"achieved": per_launch_achieved, "frac": per_launch_achieved / HBM_PEAK_GBS,
                                "launches": lls["launches"], "avg_launch_ms": lls["kernel_ms"] / max(lls["launches"], 1),
                                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EXPANSION * lls["expansions"] / max(lls["launches"], 1),
-                               "note": "rank-0 launches of the timed region, hipEvent durations on their own streams"},
+                               "note": "rank-0 launches of the timed region (an ECBS session is a front and a heavy launch, both counted), "
+                                       "hipEvent durations on their own streams; a launch stays resident for its engine's share of a step"},
                 "pipes": pipes,
             },
             "tiers": {"front_us_per_expansion": lls["prof"][0] / 100.0 / max(lls["prof"][1], 1), "front_expansions": lls["prof"][1],

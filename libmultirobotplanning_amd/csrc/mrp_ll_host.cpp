@@ -1674,6 +1674,8 @@ int mrp_ll_session_end(mrp_ll_ctx* ctx) {
   if (g.grid2) HIPCHK(ctx, hipEventSynchronize(g.ev2));
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) ctx->stats.kernel_ms += ms;
+  // (the heavy launch is a launch of its own in stats.launches: its duration counts too — ev0 is where its stream started)
+  if (g.grid2 && hipEventElapsedTime(&ms, g.ev0, g.ev2) == hipSuccess) ctx->stats.kernel_ms += ms;
   {
     unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpy(tk, g.ticksDev, 64, hipMemcpyDeviceToHost) == hipSuccess) {
