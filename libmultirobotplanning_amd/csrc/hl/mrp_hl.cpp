@@ -486,7 +486,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
         // many agents: jobs of at most eight searches — a root step of fifty searches in ONE job holds its wavefront for
         // tens of milliseconds, and the two-search rounds of deep conflict trees queue behind such jobs (measured at fifty
         // agents: the step 26 % longer than with one job per root search)
-        j.chain_count = nA > 32 ? chainChunk : 0;
+        j.chain_count = nA >= chainChunkFrom ? chainChunk : 0;
         int32_t pi;
         if (!pendFree.empty()) {
           pi = pendFree.back();

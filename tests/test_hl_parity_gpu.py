@@ -214,6 +214,15 @@ def test_root_chains_change_nothing_but_the_number_of_jobs(solver, oracle_mod, b
     keys = ("status", "cost", "makespan", "hl_expanded", "ll_expanded", "ll_searches", "paths")
     for i, (a, b) in enumerate(zip(res_on, res_off)):
         assert [a.get(k) for k in keys] == [b.get(k) for k in keys], i
+    # the root step in jobs of bounded length (mrp_ll_job.chain_count; the drivers' rule from 64 agents on, forced here)
+    os.environ["MRP_HL_CHAIN_CHUNK"], os.environ["MRP_HL_CHAIN_CHUNK_FROM"] = "4", "2"
+    try:
+        res_ch, st_ch = solver.solve(insts, algo=hl.ECBS, w=1.3, max_ll_expansions=200000)
+    finally:
+        del os.environ["MRP_HL_CHAIN_CHUNK"], os.environ["MRP_HL_CHAIN_CHUNK_FROM"]
+    assert st_on["rounds"] < st_ch["rounds"] < st_off["rounds"]
+    for i, (a, b) in enumerate(zip(res_ch, res_off)):
+        assert [a.get(k) for k in keys] == [b.get(k) for k in keys], i
     for inst, r in list(zip(insts, res_on))[:40]:
         o = oracle_mod.mapf_solve(oracle_mod.ECBS, inst, w=1.3, cap_total=200000)
         assert o["rc"] == 1 and (r["status"], r["cost"], r["hl_expanded"], r["ll_expanded"]) == (

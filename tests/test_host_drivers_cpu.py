@@ -182,11 +182,17 @@ def test_root_chains_on_the_mock(cpu_solver, bench_instances, oracle_expected, m
                                                                                 "map_32by32_obst204_agents30_ex2"]
     lib = os.path.join(BUILD, "libmrp_hl_cpu.so")
     monkeypatch.setenv("MRP_MOCK_PATH_STORE", "1")
-    for brk in (None, "150", "0"):
-        if brk is None:
+    # "chunks": the root step in jobs of three searches (mrp_ll_job.chain_count; the drivers do this from 64 agents on)
+    for brk in (None, "150", "0", "chunks"):
+        monkeypatch.delenv("MRP_HL_CHAIN_CHUNK", raising=False)
+        monkeypatch.delenv("MRP_HL_CHAIN_CHUNK_FROM", raising=False)
+        if brk is None or brk == "chunks":
             monkeypatch.delenv("MRP_MOCK_CHAIN_BREAK", raising=False)
         else:
             monkeypatch.setenv("MRP_MOCK_CHAIN_BREAK", brk)
+        if brk == "chunks":
+            monkeypatch.setenv("MRP_HL_CHAIN_CHUNK", "3")
+            monkeypatch.setenv("MRP_HL_CHAIN_CHUNK_FROM", "2")
         s = hl.BatchSolver(device=0, n_threads=2, _lib_path=lib)
         try:
             res, st = s.solve([bench_instances[n] for n in names], algo=hl.ECBS, w=1.3)
@@ -206,3 +212,5 @@ def test_root_chains_on_the_mock(cpu_solver, bench_instances, oracle_expected, m
             assert st["root_solved"] == sum(1 for r in res if r["hl_expanded"] == 1) > 0
         if brk == "0":
             assert st["rounds"] > searches
+        if brk == "chunks":  # ten agents = four jobs (3 + 3 + 3 + 1) instead of one: more tickets than whole chains, far fewer than searches
+            assert st["rounds"] * 2 < searches and st["rounds"] >= 4 * len(names)
