@@ -254,7 +254,7 @@ struct mrp_ll_ctx {
   std::vector<uint8_t*> sippTabChunks;
   std::vector<int32_t> sippTabFree;
   int32_t sippTabNext = 0;
-  bool sippUncached = false;       // MRP_LL_SIPP_TABLES_UNCACHED at creation
+  bool sippUncached = true;        // the device-resident SIPP tables are uncached device memory (sippTablesUncachedEnv)
   size_t sippTabStride = 0;
   int32_t sippTabsPerChunk = 64;
   uint16_t* pathStore = nullptr;   // device-resident path store (mrp_ll_path_store_reserve)
@@ -278,12 +278,16 @@ static const bool kDebug = std::getenv("MRP_LL_DEBUG") != nullptr;
     }                                                                                             \
   } while (0)
 
-// MRP_LL_SIPP_TABLES_UNCACHED=1 (read when a context is created): the device-resident SIPP tables in uncached device
-// memory — no cache fences around their use, every table access goes to memory
-bool sippTablesUncachedEnv() {
-  const char* e = std::getenv("MRP_LL_SIPP_TABLES_UNCACHED");
-  return e && *e == '1';
-}
+// The device-resident SIPP tables live in uncached device memory: consecutive jobs of a table run on different XCDs, whose
+// L2s are not coherent with each other, so cached tables needed an acquire fence at every job start and a release at its
+// end (an invalidate / write-back of the XCD's whole L2, shared with ~190 other searches); uncached, every table access
+// goes to memory and no fence is needed.  Measured on the three prioritized-SIPP legs: 2-3 % faster per expansion
+// (scripts/r4_run24.sh, r4_run25.sh).  The cached form is gone: besides being slower, its commit test (sipp_commit with
+// the fence pair per job) returned ONE expansion count that differed from the oracle's in one of seven otherwise green runs
+// in round 4 — never seen with uncached tables — and a protocol that rests on L2 invalidates across XCDs is not worth
+// keeping as an option nobody measures.  A device without uncached allocations keeps no resident tables (jobs ship whole
+// tables: same results).
+bool sippTablesUncachedEnv() { return true; }
 
 int actionFromDelta(int dx, int dy) {
   if (dx == 0 && dy == 0) return MRP_LL_ACT_WAIT;

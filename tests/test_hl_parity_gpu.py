@@ -276,9 +276,8 @@ def test_ecbs_without_the_compact_tier(oracle_mod, bench_instances):
 
 
 def test_opt_in_memory_placements_give_the_same_results(oracle_mod, ref_tests):
-    """MRP_LL_RING_IN_DEVICE=1 (the host-to-device half of the job ring in uncached device memory, written through the BAR)
-    and MRP_LL_SIPP_TABLES_UNCACHED=1 (SIPP tables in uncached device memory, no fences around their use): off by
-    default, same answers."""
+    """MRP_LL_RING_IN_DEVICE=1 (the host-to-device half of the job ring in uncached device memory, written through the BAR;
+    off by default): same answers, ECBS and prioritized SIPP."""
     import os
     from libmultirobotplanning_amd import hl
     insts = [hl.generate_instance(1000 * 10 + 55000 + k, 32, 32, 204, 10) for k in range(512)]
@@ -290,7 +289,6 @@ def test_opt_in_memory_placements_give_the_same_results(oracle_mod, ref_tests):
     finally:
         base.close()
     os.environ["MRP_LL_RING_IN_DEVICE"] = "1"
-    os.environ["MRP_LL_SIPP_TABLES_UNCACHED"] = "1"
     try:
         s = hl.BatchSolver(device=0, n_threads=4)
         try:
@@ -300,7 +298,6 @@ def test_opt_in_memory_placements_give_the_same_results(oracle_mod, ref_tests):
             s.close()
     finally:
         del os.environ["MRP_LL_RING_IN_DEVICE"]
-        del os.environ["MRP_LL_SIPP_TABLES_UNCACHED"]
     assert got == want
     assert got_sipp == want_sipp
     o = oracle_mod.prioritized_sipp(sipp[0])
