@@ -265,9 +265,9 @@ int mrp_ll_release_maps(mrp_ll_ctx* ctx);
 int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t lds_nodes, int32_t lds_rows, int32_t lds_path_bytes,
                            int32_t* occupancy_out);
 
-/* Resident searches per CU of a session of `algo` (MRP_LL_ASTAR_EPS, MRP_LL_ASTAR or MRP_LL_ASTAR_TA) with the current
- * tier limits, as the HIP runtime grants them: what a caller sizes mrp_ll_session_begin_algo's `workgroups` with
- * (256 CUs x this).  The A*-epsilon-only kernels keep the tier's (time, cell) bitmap in device memory and take 8 KB less
+/* Resident searches per CU of a session of `algo` (MRP_LL_ASTAR_EPS, MRP_LL_ASTAR, MRP_LL_ASTAR_TA or MRP_LL_SIPP) with the
+ * current tier limits, as the HIP runtime grants them: what a caller sizes mrp_ll_session_begin_algo's / _sipp's
+ * `workgroups` with (256 CUs x this; the SIPP kernel's LDS tier is fixed: 16 per CU).  The A*-epsilon-only kernels keep the tier's (time, cell) bitmap in device memory and take 8 KB less
  * LDS per search than the others, so the answer depends on the algorithm. */
 int mrp_ll_session_occupancy(mrp_ll_ctx* ctx, int32_t algo, int32_t* occupancy_out);
 

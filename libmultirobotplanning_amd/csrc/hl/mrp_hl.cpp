@@ -1504,11 +1504,13 @@ void runSippGroupSession(mrp_ll_ctx* ctx, int32_t horizon, int32_t slots, int32_
       for (Prio& p : st) mrp_ll_sipp_table_destroy(p.tab);
     }
   } tableGuard{st};
-  // at most one wavefront per instance, and about two per SIMD over all workers: the SIPP kernel waits on HBM for most
-  // of an expansion, more resident wavefronts only slow each other down (round 2, 2048 instances x 100 agents, 64 / 96 /
-  // 128 / 192 / 256 per worker: 0.43 / 0.38 / 0.42 / 0.51 / 0.61 s)
-  // (that was with sixteen workers: 1536 wavefronts on the device, whatever the number of workers)
-  const size_t perWorker = static_cast<size_t>(std::max(96, 1536 / std::max(nWorkers, 1)));
+  // at most one wavefront per instance, and as many over all workers as the device holds (mrp_ll_session_occupancy:
+  // sixteen per CU with the kernel's 9.2 KB LDS tier).  Round 2 found that more resident wavefronts only slowed each other
+  // down; that was with cached tables and a fence pair per job — with uncached tables residency pays (ll_kernel.hip,
+  // MRP_LL_SIPP_LDS_NODES).
+  int32_t occS = 6;
+  if (mrp_ll_session_occupancy(ctx, MRP_LL_SIPP, &occS) != MRP_LL_SUCCESS || occS <= 0) occS = 6;
+  const size_t perWorker = static_cast<size_t>(std::max(96, 256 * occS / std::max(nWorkers, 1)));
   int32_t wgs = static_cast<int32_t>(std::min<size_t>(std::min<size_t>(std::max<size_t>(n, 16), slots), perWorker));
   if (const char* e = std::getenv("MRP_HL_SIPP_WGS")) wgs = std::max(1, std::atoi(e));          // tuning knob
   if (mrp_ll_session_begin_sipp(ctx, wgs) != MRP_LL_SUCCESS) {

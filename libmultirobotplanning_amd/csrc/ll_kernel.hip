@@ -2324,8 +2324,12 @@ DEVI bool sippCommitPath(const SippView<true>& tv, const uint32_t* path, uint32_
 }
 
 // LDS of a resident SIPP workgroup: TierLdsSipp's nodes, positions, g and open list — or TierMix's open list alone
+// 768 nodes = 9.2 KB = 16 searches per CU.  With the tables in uncached memory and no fence pair per job, residency pays
+// (scripts/r4_run35.sh, r4_run36.sh, 100 / 200 agents: 2048 nodes, 6 per CU: 5.5 / 5.5e8 expansions/s; 1536, 8 per CU:
+// 6.5 / 6.5e8; 1024, 12 per CU: 7.2 / 7.4e8; 768, 16 per CU: 7.8 / 8.0e8; 512, 16 per CU: 7.6 / 7.1e8) although every
+// expansion gets slower (2.2 -> 2.7 us) and more searches continue in the middle tier (open list in LDS, nodes in the arena).
 #ifndef MRP_LL_SIPP_LDS_NODES
-#define MRP_LL_SIPP_LDS_NODES 2048
+#define MRP_LL_SIPP_LDS_NODES 768
 #endif
 constexpr uint32_t kSippLdsCap = MRP_LL_SIPP_LDS_NODES;  // <= TierLdsSipp::kMaxNodes; ids 0 .. kSippLdsCap - 2 are used
 static_assert(kSippLdsCap <= TierLdsSipp::kMaxNodes && kSippLdsCap % 4 == 0, "SIPP LDS tier capacity");
@@ -3123,6 +3127,15 @@ extern "C" int mrp_ll_persistent_occupancy(int kind, uint32_t ldsBytes) {
   if (mrp::allowFullLds(reinterpret_cast<const void*>(k), 3 + kind) != hipSuccess) return 0;
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), 64, ldsBytes) != hipSuccess) return 0;
+  return n;
+}
+
+// ... and for the resident SIPP kernel (its LDS is static)
+extern "C" int mrp_ll_sipp_persistent_occupancy(void) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(mrp::mrp_ll_sipp_persistent_kernel), 64, 0) !=
+      hipSuccess)
+    return 0;
   return n;
 }
 

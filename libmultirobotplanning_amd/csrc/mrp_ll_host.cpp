@@ -19,6 +19,7 @@
 
 extern "C" uint32_t mrp_ll_lds_bytes(int kind, uint32_t capNodes, uint32_t rows, uint32_t rowWords, uint32_t pathBytes);
 extern "C" int mrp_ll_persistent_occupancy(int kind, uint32_t ldsBytes);
+extern "C" int mrp_ll_sipp_persistent_occupancy(void);
 extern "C" hipError_t mrp_ll_launch(const mrp::LaunchParams* P, uint32_t grid, uint32_t ldsBytes, int kind,
                                     hipStream_t stream);
 extern "C" hipError_t mrp_ll_launch_sipp(const mrp::LaunchParams* P, uint32_t grid, hipStream_t stream);
@@ -1336,8 +1337,13 @@ int mrp_ll_configure_tiers(mrp_ll_ctx* ctx, int32_t ldsNodes, int32_t ldsRows, i
 
 int mrp_ll_session_occupancy(mrp_ll_ctx* ctx, int32_t algo, int32_t* occOut) {
   if (!ctx || !occOut) return MRP_LL_E_INVALID;
-  if (algo != MRP_LL_ASTAR && algo != MRP_LL_ASTAR_EPS && algo != MRP_LL_ASTAR_TA) return MRP_LL_E_INVALID;
+  if (algo != MRP_LL_ASTAR && algo != MRP_LL_ASTAR_EPS && algo != MRP_LL_ASTAR_TA && algo != MRP_LL_SIPP) return MRP_LL_E_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (algo == MRP_LL_SIPP) {  // the resident SIPP kernel: a fixed LDS tier (ll_kernel.hip MRP_LL_SIPP_LDS_NODES)
+    const int occS = mrp_ll_sipp_persistent_occupancy();
+    *occOut = occS > 0 ? std::min(occS, 32) : 6;
+    return MRP_LL_SUCCESS;
+  }
   const int kind = algo == MRP_LL_ASTAR_EPS ? 1 : 2;
   const uint32_t rowWords = (ctx->maxWpr + 3u) & ~3u;
   const uint32_t bytes = mrp_ll_lds_bytes(kind, static_cast<uint32_t>(ctx->opt.lds_nodes), ctx->tierRows, rowWords,
