@@ -103,7 +103,12 @@ struct TierCfg {
   static constexpr uint32_t windowBytes(bool bg) { return pathsOff(bg); }
   static_assert(kFhShift + FH_BITS == 32u, "an entry is 32 bits");
   static_assert(!LONGT || L_BITS == 6u, "h <= 62 on a 32 x 32 map");
-  static_assert(2u * kHeapBytes >= kBitsBytes, "BG builds the bitmap in the (not yet initialised) open + focal areas");
+  // BG (not LONGT) puts the bitmap together in the not yet initialised open + focal areas, kBuildRows rows at a time, and
+  // the goal branch stages kStageRows 1 KB rows of the cameFrom table in the areas in front of the obstacle row
+  static constexpr uint32_t kBuildRows = LONGT ? kRows : (2u * kHeapBytes >= kRows * kRowBytes ? kRows : kRows / 2u);
+  static constexpr uint32_t kStageRows = (2u * kHeapBytes + kAuxBytes) / 1024u >= 8u ? 8u : (2u * kHeapBytes + kAuxBytes) / 1024u;
+  static_assert(2u * kHeapBytes >= kBuildRows * kRowBytes && kRows % kBuildRows == 0u, "room for a chunk of bitmap rows");
+  static_assert(kStageRows >= 4u, "room for the goal branch's rows");
   static_assert(!LONGT || kAuxBytes >= kBitsBytes, "LONGT builds a chunk of bitmap rows in the walk queue's area");
   static_assert(oFocal % 16 == 0 && oAux % 16 == 0 && oBits % 16 == 0 && oObst % 16 == 0 && oPaths % 16 == 0, "16-byte aligned areas");
   static_assert((kHeapClamp & 1u) == 1u && 4u * (kHeapClamp + 3u) <= kHeapBytes, "clamped child pair stays inside the heap area");
@@ -111,7 +116,11 @@ struct TierCfg {
   static_assert(256u * GROUPS <= kAuxIdxMask + 1u && 10u + F_BITS + L_BITS + kAuxShift <= 32u, "walk-queue entry: key above index");
   static_assert(kMaxT + 1u + 62u <= kFMax - 3u, "f = g + h (h <= 62 on a 32 x 32 map) fits its field");
 };
-typedef TierCfg<4, 9, 7, 6> Narrow;
+// (MRP_CT_NARROW_GROUPS: 4 = 1023 open entries, 12.9 KB with ten agents; 3 = 767 entries, 10.1 KB)
+#ifndef MRP_CT_NARROW_GROUPS
+#define MRP_CT_NARROW_GROUPS 4
+#endif
+typedef TierCfg<MRP_CT_NARROW_GROUPS, 9, 7, 6> Narrow;
 // 12 groups = 3071 open entries in a 31.4 KB window.  (Measured on MI355X, scripts/r4_run10.sh / r4_run11.sh: a workgroup
 // with more than 32 KB of LDS takes room on its CU as if it had 64 KB — 16 groups, 41.6 KB, cost 5.2 narrow windows each
 // instead of 3 — so the window stays below; the largest open list seen on the benchmark shapes is 2787 entries.)
@@ -403,9 +412,9 @@ WV_ENTRY int32_t compactSearch(Lds window) {
   sync();
   // Bitmap rows r0 .. r0 + kRows - 1 (row t = obstacles | vertex constraints at t | states discovered, during the search),
   // put together at `where` in the window.
-  auto buildRows = [&](uint32_t where, uint32_t r0) {
+  auto buildRows = [&](uint32_t where, uint32_t r0, uint32_t nRows) {
     const V4 chunk = ldsLoad128(lds, splat(oObstX) + (lane & 7u) * 16u);
-    for (uint32_t i = 0; i < kRows / 8u; ++i)
+    for (uint32_t i = 0; i < nRows / 8u; ++i)
       ldsStore128(lds, splat(where + i * 8u * kRowBytes) + (lane >> 3) * kRowBytes + (lane & 7u) * 16u, chunk);
     sync();
     // stateValid's vertex constraints (ecbs.cpp:499-502)
@@ -415,7 +424,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       const B in = (lane + j0) < nVc;
       const V v = gLoad32m(vc, lane + j0, in);
       const V tt = (v >> 16) - r0, yy = (v >> 8) & 0xFFu, xx = v & 0xFFu;  // (rows in front of r0: a huge number)
-      ldsOr32m(lds, splat(where) + tt * kRowBytes + yy * 4u, splat(1u) << xx, in & (tt < kRows) & (yy < 32u) & (xx < 32u));
+      ldsOr32m(lds, splat(where) + tt * kRowBytes + yy * 4u, splat(1u) << xx, in & (tt < nRows) & (yy < 32u) & (xx < 32u));
     }
   };
   // LONGT: the rows exist up to rowsReady (exclusive); the next chunk is put together in the walk queue's area — free
@@ -423,7 +432,7 @@ WV_ENTRY int32_t compactSearch(Lds window) {
   uint32_t rowsReady = 0;
   auto moreRows = [&]() {
     sync();
-    buildRows(oAux, rowsReady);
+    buildRows(oAux, rowsReady, kRows);
     sync();
     for (uint32_t i = 0; i < kBitsBytes / 1024u; ++i)
       gStore128(bitsG, splat(rowsReady * (kRowBytes / 16u) + i * 64u) + lane, ldsLoad128(lds, splat(oAux + i * 1024u) + lane * 16u));
@@ -437,15 +446,18 @@ WV_ENTRY int32_t compactSearch(Lds window) {
   };
   if (C::kLongT) {
     moreRows();  // (later chunks: in the loop, as t grows)
-  } else {
-    buildRows(oBuild, 0u);
-    if (BG) {  // the finished rows leave for device memory (8 x 1 KB, coalesced); then the heaps take the area over
+  } else if (BG) {  // the finished rows leave for device memory (1 KB stores, coalesced); then the heaps take the area over
+    constexpr uint32_t kBuildRows = C::kBuildRows;
+    for (uint32_t r0 = 0; r0 < kRows; r0 += kBuildRows) {
+      buildRows(oBuild, r0, kBuildRows);
       sync();
-      for (uint32_t i = 0; i < kBitsBytes / 1024u; ++i)
-        gStore128(bitsG, splat(i * 64u) + lane, ldsLoad128(lds, splat(oBuild + i * 1024u) + lane * 16u));
+      for (uint32_t i = 0; i < kBuildRows * kRowBytes / 1024u; ++i)
+        gStore128(bitsG, splat(r0 * (kRowBytes / 16u) + i * 64u) + lane, ldsLoad128(lds, splat(oBuild + i * 1024u) + lane * 16u));
       sync();
-      initHeaps();
     }
+    initHeaps();
+  } else {
+    buildRows(oBuild, 0u, kRows);
   }
   // edge-constraint keys, one per lane.  They pass through the window (the walk queue's area, restored afterwards) so that
   // the loop below holds no register a vector-memory load is still writing.
@@ -645,15 +657,16 @@ WV_ENTRY int32_t compactSearch(Lds window) {
       sync();  // this wave's action stores have left the CU
       uint32_t c = cell;
       const uint32_t* tab32 = (const uint32_t*)parentTab;
-      for (int32_t k0 = (int32_t)t; k0 >= 1; k0 -= 8) {
-        V rowW[8][4];
-        for (int32_t r = 0; r < 8; ++r)
+      constexpr int32_t kStage = BG ? (int32_t)C::kStageRows : 8;  // (the bitmap's own area holds eight rows)
+      for (int32_t k0 = (int32_t)t; k0 >= 1; k0 -= kStage) {
+        V rowW[kStage][4];
+        for (int32_t r = 0; r < kStage; ++r)
           for (uint32_t q = 0; q < 4; ++q)
             rowW[r][q] = (k0 - r >= 1) ? gLoad32Coherent(tab32, splat((uint32_t)(k0 - r) * 256u + q * 64u) + lane) : splat(0u);
-        for (int32_t r = 0; r < 8; ++r)
+        for (int32_t r = 0; r < kStage; ++r)
           for (uint32_t q = 0; q < 4; ++q) ldsStore32(lds, splat(oBuild + (uint32_t)r * 1024u + q * 256u) + lane * 4u, rowW[r][q]);
         sync();
-        for (int32_t r = 0; r < 8 && k0 - r >= 1; ++r) {
+        for (int32_t r = 0; r < kStage && k0 - r >= 1; ++r) {
           const uint32_t k = (uint32_t)(k0 - r);
           gStoreU16m(outPath, splat(k), splat((c & 31u) | ((c >> 5) << 8)), lane == 0u);
           const uint32_t a = first(ldsLoadU8(lds, splat(oBuild + (uint32_t)r * 1024u + c)));

@@ -2997,7 +2997,14 @@ extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_persistent_kernel(L
 // with the narrow compact tier alone — no arena-tier code, hence a smaller register allocation; heavy workgroups wait on
 // the device-side queue the front ones fill, run each search in the WIDE compact geometry (31.4 KB of LDS: open and focal
 // lists of 3071 entries, walk queue) and, beyond even that, in the arena tier.
-extern "C" __global__ void __launch_bounds__(64) mrp_ll_ecbs_front_kernel(LaunchParams Parg) {
+// (MRP_LL_FRONT_WAVES4: at most 128 VGPRs = four waves per SIMD; the searches' own function needs 118, what is spilled is
+// state of the job set-up and of the chain's conflict scan)
+#ifdef MRP_LL_FRONT_WAVES4
+#define MRP_LL_FRONT_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define MRP_LL_FRONT_ATTR
+#endif
+extern "C" __global__ void __launch_bounds__(64) MRP_LL_FRONT_ATTR mrp_ll_ecbs_front_kernel(LaunchParams Parg) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   MRP_LL_WINDOW_BLOCKS(smem, jobS, resS);
   const LaunchParams& P = Parg;

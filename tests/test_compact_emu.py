@@ -18,7 +18,7 @@ I64P = ctypes.POINTER(ctypes.c_int64)
 def _emu_lib(force_walk=False):
     build = os.path.join(ROOT, "tests", "_build")
     os.makedirs(build, exist_ok=True)
-    groups = os.environ.get("MRP_CT_GROUPS")  # experiments with larger open lists (the product builds the default)
+    groups = os.environ.get("MRP_CT_GROUPS")  # the narrow tier with another number of 256-entry groups (the product builds 4)
     sanitize = bool(os.environ.get("MRP_EMU_SANITIZE"))
     # the build flavour is part of the file name: a sanitizer build left behind can never be picked up by a plain run
     # (dlopen of an ASan library into a plain interpreter ends the process without a report)
@@ -29,7 +29,7 @@ def _emu_lib(force_walk=False):
     if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
         san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if sanitize else []
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"] + san +
-                              (["-DMRP_CT_GROUPS=" + groups] if groups else []) +
+                              (["-DMRP_CT_NARROW_GROUPS=" + groups] if groups else []) +
                               (["-DMRP_CT_FORCE_WALK"] if force_walk else []) + ["-o", lib, deps[0]])
     L = ctypes.CDLL(lib)
     L.emu_compact_search.restype = ctypes.c_int
