@@ -1898,6 +1898,7 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
   uint32_t& nNodes = s.nNodes;
   uint32_t& nOpen = s.nOpen;
   int64_t& expansions = s.expansions;
+  const uint32_t divMagic = rfl(0xFFFFFFFFu / dimx + 1u);
   for (;;) {
     if (nOpen == 0) {
       res.status = ST_NO_SOLUTION;
@@ -1912,7 +1913,9 @@ DEVI int32_t sippLoop(const LaunchParams& P, const DevJob& J, Mem<T>& g, const S
       cw = sippNodeX<T>(g, curId);
     const uint32_t cell = cw & 0xFFFF, iv = RES ? (cw >> 16) & 0x7FFFu : cw >> 16;
     const uint32_t gcur = T::g(curE);  // == the node's g: every entry is packed with it
-    const uint32_t cx = cell % dimx, cy = cell / dimx;
+    // cell / dimx without the ~30-instruction division sequence: one multiply-high by floor(2^32 / dimx) + 1 is exact for
+    // cell < 2^16 and dimx <= 2^16 (the product overshoots cell / dimx by less than 2^-16 < 1 / dimx)
+    const uint32_t cy = dimx == 1u ? cell : __umulhi(cell, divMagic), cx = cell - cy * dimx;
     // RES: every table word this expansion needs has an address that follows from (cell, iv) alone — the cell's own
     // list length and interval end, and for the four neighbours (lanes 16 * motion + i) the obstacle word, the list
     // length, interval slot i and its status word: two 64-byte sectors per cell.  All of
