@@ -157,7 +157,6 @@ struct LaunchParams {
   uint16_t* path_store;       // device (uncached allocation: written by one workgroup, read by others of a resident kernel)
   uint32_t path_store_stride; // halfwords per slot (0 = no store)
   uint32_t path_store_slots;
-  uint32_t sipp_tables_uncached;  // the device-resident SIPP tables live in uncached memory: no cache fences around their use
   // ---- heavy workgroups (A*-epsilon sessions): a second resident launch with the WIDE window (ll_compact.h) that takes
   // over the searches the front workgroups' compact tier cannot hold.  Device-side queue, device memory:
   //   heavy_ctr[0] = entries written so far (front workgroups: fetch-add), heavy_ctr[16] = tickets taken (heavy workgroups),

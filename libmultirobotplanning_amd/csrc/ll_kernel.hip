@@ -1774,7 +1774,6 @@ struct SippView {
   const int32_t* ivals;
   uint32_t* status;
   uint32_t cells, epochBits;
-  uint32_t uncached;  // the table is in uncached memory (LaunchParams::sipp_tables_uncached)
   // nk != 0: the cell has its own interval list, `n` entries from ivals[2 * first]; nk == 0: the default [0, INT_MAX]
   DEVI void lookup(uint32_t cell, uint32_t& nk, uint32_t& first, uint32_t& n) const {
     if constexpr (RES) {
@@ -2305,23 +2304,11 @@ DEVI bool sippCommitPath(const SippView<true>& tv, const uint32_t* path, uint32_
         }
       }
       todo &= ~ballot64(mine);
-      if (todo) {  // the next turn reads rows this one wrote (other lanes of the same wave: through L2, not a stale L1 line)
-        if (tv.uncached) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-      }
+      // the next turn reads rows this one wrote (other lanes of the same wave; the table is uncached memory, so a store
+      // that has been acknowledged is what a later load sees)
+      if (todo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (base + 64 < len) {
-      if (tv.uncached) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-    }
+    if (base + 64 < len) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   return ballot64(bad) == 0;
 }
@@ -2364,7 +2351,6 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
   SippView<RES> tv;
   tv.cells = cells;
   tv.epochBits = 0;
-  tv.uncached = 0;
   if constexpr (RES) {
     uint8_t* rt = (uint8_t*)((uint64_t)J.n_agents_pad | ((uint64_t)J.path_off << 32));
     uint32_t* rec = (uint32_t*)rt;  // bounds rows, then status rows (ll_device.h)
@@ -2374,10 +2360,8 @@ DEVI void runSipp(const LaunchParams& P, const DevJob& J, uint8_t* arenaSlot, ui
     tv.epochBits = J.n_ctx << kSippEpochShift;
     tv.cellIdx = nullptr;
     tv.specFirst = nullptr;
-    // the table was last written by another workgroup, possibly on another XCD (its results were released at system
-    // scope before the host saw them and packed this job)
-    tv.uncached = P.sipp_tables_uncached;
-    if (!tv.uncached) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (the table was last written by another workgroup, possibly on another XCD: it is uncached memory, that workgroup's
+    // stores had been acknowledged before it published its job as done, and the host packed this job after seeing that)
     const uint32_t nRec = J.ec_off & 0x7FFFFFFFu;
     if (J.ec_off >> 31) {  // first job of the table (or its epochs are used up): no cell has a list, no state is seen
       u32x4 z;
@@ -2842,7 +2826,6 @@ DEVI void publishDone(const LaunchParams& P, uint32_t slot, uint32_t doneVal) {
   // observed out of order by any agent.  That is the release half of the model's store-release code sequence
   // (`buffer_wbl2 sc0 sc1; s_waitcnt vmcnt(0); store sc0 sc1`) minus the write-back, which exists for data written with
   // weaker scopes — of which the host reads none.
-  if (SIPP && !P.sipp_tables_uncached) __threadfence_system();  // (cached tables: the commits are plain stores)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __hip_atomic_store(P.ring_done + slot, doneVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // completion queue: the host consumes finished jobs in O(1) each instead of scanning the ring; it looks at the done

@@ -255,7 +255,6 @@ struct mrp_ll_ctx {
   std::vector<uint8_t*> sippTabChunks;
   std::vector<int32_t> sippTabFree;
   int32_t sippTabNext = 0;
-  bool sippUncached = true;        // the device-resident SIPP tables are uncached device memory (sippTablesUncachedEnv)
   size_t sippTabStride = 0;
   int32_t sippTabsPerChunk = 64;
   uint16_t* pathStore = nullptr;   // device-resident path store (mrp_ll_path_store_reserve)
@@ -278,17 +277,6 @@ static const bool kDebug = std::getenv("MRP_LL_DEBUG") != nullptr;
       return MRP_LL_E_DEVICE;                                                                     \
     }                                                                                             \
   } while (0)
-
-// The device-resident SIPP tables live in uncached device memory: consecutive jobs of a table run on different XCDs, whose
-// L2s are not coherent with each other, so cached tables needed an acquire fence at every job start and a release at its
-// end (an invalidate / write-back of the XCD's whole L2, shared with ~190 other searches); uncached, every table access
-// goes to memory and no fence is needed.  Measured on the three prioritized-SIPP legs: 2-3 % faster per expansion
-// (scripts/r4_run24.sh, r4_run25.sh).  The cached form is gone: besides being slower, its commit test (sipp_commit with
-// the fence pair per job) returned ONE expansion count that differed from the oracle's in one of seven otherwise green runs
-// in round 4 — never seen with uncached tables — and a protocol that rests on L2 invalidates across XCDs is not worth
-// keeping as an option nobody measures.  A device without uncached allocations keeps no resident tables (jobs ship whole
-// tables: same results).
-bool sippTablesUncachedEnv() { return true; }
 
 int actionFromDelta(int dx, int dy) {
   if (dx == 0 && dy == 0) return MRP_LL_ACT_WAIT;
@@ -1000,7 +988,6 @@ int fillCommonParams(mrp_ll_ctx* ctx, Ticket& t, mrp::LaunchParams& P, uint32_t&
   P.path_store = ctx->pathStore;
   P.path_store_stride = ctx->pathStoreStride;
   P.path_store_slots = ctx->pathStore ? ctx->pathStoreSlots : 0;
-  P.sipp_tables_uncached = ctx->sippUncached ? 1u : 0u;
   P.lds_nodes = ldsNodes;
   P.lds_rows = rows;
   P.lds_row_words = rowWords;
@@ -1165,7 +1152,6 @@ int mrp_ll_create(const mrp_ll_options* optIn, mrp_ll_ctx** out) {
   }
   mrp_ll_ctx* ctx = new mrp_ll_ctx();
   ctx->opt = o;
-  ctx->sippUncached = sippTablesUncachedEnv();
   ctx->device = o.device;
   std::memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (hipSetDevice(o.device) != hipSuccess) {
@@ -2219,10 +2205,18 @@ int mrp_ll_sipp_table_create(mrp_ll_ctx* ctx, int32_t mapId, mrp_ll_sipp_table**
     ctx->sippTabFree.pop_back();
   } else {
     if (ctx->sippTabNext == static_cast<int32_t>(ctx->sippTabChunks.size()) * ctx->sippTabsPerChunk) {
+      // The device-resident SIPP tables live in uncached device memory: consecutive jobs of a table run on different XCDs, whose
+      // L2s are not coherent with each other, so cached tables needed an acquire fence at every job start and a release at its
+      // end (an invalidate / write-back of the XCD's whole L2, shared with ~190 other searches); uncached, every table access
+      // goes to memory and no fence is needed.  Measured on the three prioritized-SIPP legs: 2-3 % faster per expansion
+      // (scripts/r4_run24.sh, r4_run25.sh).  The cached form is gone: besides being slower, its commit test (sipp_commit with
+      // the fence pair per job) returned ONE expansion count that differed from the oracle's in one of seven otherwise green runs
+      // in round 4 — never seen with uncached tables — and a protocol that rests on L2 invalidates across XCDs is not worth
+      // keeping as an option nobody measures.  A device without uncached allocations keeps no resident tables (jobs ship whole
+      // tables: same results).
       void* c = nullptr;
       if (hipSetDevice(ctx->device) == hipSuccess &&
-          (ctx->sippUncached ? hipExtMallocWithFlags(&c, ctx->sippTabStride * ctx->sippTabsPerChunk, hipDeviceMallocUncached)
-                                : hipMalloc(&c, ctx->sippTabStride * ctx->sippTabsPerChunk)) == hipSuccess)
+          hipExtMallocWithFlags(&c, ctx->sippTabStride * ctx->sippTabsPerChunk, hipDeviceMallocUncached) == hipSuccess)
         ctx->sippTabChunks.push_back(static_cast<uint8_t*>(c));
     }
     if (ctx->sippTabNext < static_cast<int32_t>(ctx->sippTabChunks.size()) * ctx->sippTabsPerChunk) t->devIndex = ctx->sippTabNext++;
