@@ -136,6 +136,11 @@ def main():
     ap.add_argument("--path-cap", type=int, default=128, help="states per agent the caller's schedule buffers hold in the "
                                                                "headline region (a longer path would be reported, not hidden)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream", action="store_true",
+                    help="one solver call per step with a barrier between steps (the default hands the K timed steps to the "
+                         "solver as one stream of batches, mrp_hl_solver_solve_stream)")
+    ap.add_argument("--sync-steps", type=int, default=2,
+                    help="after the timed region: that many of its steps again, one call each (reported as one_call_per_step)")
     ap.add_argument("--legs", default="auto", help="'auto' (all at N=1, none otherwise), 'none', or a comma list of "
                                                    "agents50,agents100,shipped,sipp50,sipp100,sipp200")
     ap.add_argument("--max-ll-expansions", type=int, default=50000,
@@ -201,16 +206,42 @@ def main():
     solved_total = 0
     searches_total = 0
     rounds_total = 0
-    for i in range(W, W + K):
-        _, st = solver.solve_prepared(prepared[i], algo=hl.ECBS, w=1.3, max_ll_expansions=args.max_ll_expansions,
-                                      raw=True)
-        exp_total += st["ll_expansions"]
-        solved_total += st["solved"]
-        searches_total += st["ll_searches"]
-        rounds_total += st["rounds"]
+    stream = not args.no_stream and K > 1
+    if stream:
+        # the K steps as ONE stream of K batches: every batch is solved completely and its schedules delivered inside the
+        # timed region, but the solver's workers go on to batch i + 1 while the last conflict trees of batch i finish
+        st = solver.solve_stream(prepared[W:W + K], algo=hl.ECBS, w=1.3, max_ll_expansions=args.max_ll_expansions)
+        exp_total, solved_total, searches_total, rounds_total = (st["ll_expansions"], st["solved"], st["ll_searches"],
+                                                                 st["rounds"])
+    else:
+        for i in range(W, W + K):
+            _, st = solver.solve_prepared(prepared[i], algo=hl.ECBS, w=1.3, max_ll_expansions=args.max_ll_expansions,
+                                          raw=True)
+            exp_total += st["ll_expansions"]
+            solved_total += st["solved"]
+            searches_total += st["ll_searches"]
+            rounds_total += st["rounds"]
     barrier()
     elapsed = time.perf_counter() - t0
     lls = solver.ll_stats()
+    # the same steps again, one solver call each (a barrier between steps): what the stream is worth
+    sync_ref = None
+    if stream and args.sync_steps > 0:
+        ns = min(args.sync_steps, K)
+        digest0 = solver.result_arrays(prepared[W])["schedule_digest"].copy()
+        barrier()
+        ts = time.perf_counter()
+        es = 0
+        for i in range(W, W + ns):
+            _, st1 = solver.solve_prepared(prepared[i], algo=hl.ECBS, w=1.3, max_ll_expansions=args.max_ll_expansions,
+                                           raw=True)
+            es += st1["ll_expansions"]
+        barrier()
+        ts = time.perf_counter() - ts
+        import numpy as _np
+        sync_ref = {"steps": ns, "value": es / max(ts, 1e-12), "ms_per_step": 1e3 * ts / ns,
+                    "same_schedules_as_the_stream": bool(_np.array_equal(
+                        digest0, solver.result_arrays(prepared[W])["schedule_digest"]))}
     first_ra = solver.result_arrays(prepared[W]) if K > 0 else None
     first_batch = batches[W] if K > 0 else None
     for i, p in enumerate(prepared):
@@ -290,6 +321,7 @@ def main():
                        "instances_per_gpu_per_step": B, "agents": args.agents, "host_threads_per_gpu": threads,
                        "host_cpus_usable": hc, "max_ll_expansions_per_instance": args.max_ll_expansions,
                        "delivers_schedules": True, "schedule_buffer_states_per_agent": args.path_cap,
+                       "steps_as_one_stream": stream,
                        "longest_path_in_first_timed_step": longest_path,
                        "parallelism": "instances sharded per GPU, no data-path collective"},
             "instances_per_s": inst_all / elapsed_max,
@@ -298,6 +330,7 @@ def main():
             "capped_in_first_timed_step": capped_first,
             "ll_searches": int(searches_all),
             "setup_seconds_generate_and_preload": t_gen,
+            "one_call_per_step": sync_ref,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -319,7 +352,7 @@ def main():
                       "beyond_front_us_per_expansion": lls["prof"][2] / 100.0 / max(lls["prof"][3], 1),
                       "beyond_front_expansions": lls["prof"][3], "searches_handed_over": lls["prof"][7],
                       "front_workgroups_busy_fraction": lls["session_busy_ms"] / max(lls["session_busy_ms"] + lls["session_idle_ms"], 1e-9),
-                      "heavy_workgroups": lls["heavy_active_wgs"] // max(K, 1),
+                      "heavy_workgroups": lls["heavy_active_wgs"] // max(1 if stream else K, 1),
                       "heavy_workgroups_busy_fraction": lls["heavy_busy_ms"] / max(lls["heavy_busy_ms"] + lls["heavy_idle_ms"], 1e-9),
                       "tickets_per_step": int(rounds_total // max(K, 1))},
         }

@@ -104,6 +104,16 @@ int mrp_hl_solver_preload(mrp_hl_solver* s, int32_t n_threads, int32_t n_instanc
                           mrp_hl_preloaded** out);
 int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* opt, mrp_hl_preloaded* p,
                                   mrp_hl_solution* solutions, mrp_hl_batch_stats* stats);
+/* Several preloaded batches (of this solver, preloaded with the same n_threads) as ONE stream: the worker threads draw
+ * batch 0's instances, then batch 1's, ... from one pool with no barrier between batches, so the dependent chains that end
+ * a batch — deep conflict trees (ecbs.hpp:151-285 is a sequential loop per instance), searches that run to the harness cap —
+ * overlap with the root searches of the next batch instead of leaving the device idle.  Instances are independent
+ * (one conflict tree each), so solutions[b][k] is exactly what mrp_hl_solver_solve_preloaded(batches[b]) writes; `stats`
+ * is the aggregate over the stream (wall_seconds: the whole call).  n_batches = 1 is mrp_hl_solver_solve_preloaded.
+ * Several batches need the session driver (mrp_hl_options.mode 0). */
+int mrp_hl_solver_solve_stream(mrp_hl_solver* s, const mrp_hl_options* opt, int32_t n_batches,
+                               mrp_hl_preloaded* const* batches, mrp_hl_solution* const* solutions,
+                               mrp_hl_batch_stats* stats);
 void mrp_hl_preloaded_free(mrp_hl_preloaded* p);
 int mrp_hl_solver_ll_stats(mrp_hl_solver* s, mrp_ll_stats* out, int32_t reset); /* summed over its engines */
 const char* mrp_hl_solver_last_error(const mrp_hl_solver* s);

@@ -68,6 +68,22 @@ struct GroupResult {
   std::string err;
 };
 
+// Several preloaded batches as ONE pool of instances (mrp_hl.h mrp_hl_solver_solve_stream): global index k names instance
+// k - first[b] of batch b; its map id on engine e is mapBase[b][e] + that.
+struct StreamView {
+  std::vector<int32_t> first;                      // first[b] = global index of batch b's instance 0; first[nBatches] = total
+  std::vector<const mrp_hl_instance*> inst;        // per batch
+  std::vector<mrp_hl_solution*> sols;              // per batch
+  std::vector<const std::vector<int32_t>*> mapBase;  // per batch: per engine
+  int32_t batchOf(int32_t k) const {
+    return static_cast<int32_t>(std::upper_bound(first.begin(), first.end(), k) - first.begin()) - 1;
+  }
+  mrp_hl_solution& sol(int32_t k) const {
+    const int32_t b = batchOf(k);
+    return sols[b][k - first[b]];
+  }
+};
+
 // One low-level job of the C-ABI for request `r` of instance `I`; the focal-context arrays go to the pools (pointers
 // are patched in by the caller once the pools have stopped growing).
 // `idPool` != nullptr: also name the context paths by their device path-store slots (f2) when every one of them has one.
@@ -343,7 +359,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
                      int32_t workgroups, int32_t pathSlots, GroupResult& out, std::atomic<int32_t>* shared = nullptr,
                      int32_t nTotal = 0, int32_t mapBase = 0, int32_t nWorkersIn = 1, int32_t heavyWgs = 0,
                      int32_t* gate = nullptr, int32_t nEngines = 1, int32_t coIndex = 0, int32_t coCount = 1,
-                     CoSync* co = nullptr) {
+                     CoSync* co = nullptr, const StreamView* view = nullptr, int32_t engineIdx = 0) {
+  // `view` (shared pool only): the pool is several batches back to back; instIn / sols / mapBase are not used then
+  auto solOf = [&](int32_t g) -> mrp_hl_solution& { return view ? view->sol(g) : sols[g]; };
+  int32_t viewBatch = 0;  // the counter only grows, so the batch of the next instance is found by walking forward
   const bool shared2 = coCount > 1 && co != nullptr;  // this engine has two workers: tagged calls only
   const size_t nWorkers = static_cast<size_t>(std::max(nWorkersIn, 1));
   const size_t n = shared ? static_cast<size_t>(nTotal) : idx.size();
@@ -665,6 +684,10 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
         return false;
       }
       mid = mapBase + k;
+      if (view) {
+        while (k >= view->first[viewBatch + 1]) ++viewBatch;
+        mid = (*view->mapBase[viewBatch])[engineIdx] + (k - view->first[viewBatch]);
+      }
     } else {
       if (nextStatic >= n) {
         exhausted = true;
@@ -676,7 +699,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
     }
     live.emplace_back();
     gidx.push_back(k);
-    live.back().inst.reset(new Instance(instIn[k], mid, opt));
+    live.back().inst.reset(new Instance(view ? view->inst[viewBatch][k - view->first[viewBatch]] : instIn[k], mid, opt));
     if (timing) live.back().tAdmit = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
     return true;
   };
@@ -694,7 +717,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
       L.req.clear();  // requests of a finished instance point into freed CT nodes
       L.reqHead = 0;
       if (timing) L.tDone = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
-      writeSolution(*L.inst, sols[gidx[k]]);
+      writeSolution(*L.inst, solOf(gidx[k]));
       L.hl = L.inst->hlExpanded();
       L.ll = L.inst->llExpanded();
       L.spec = L.inst->specSearches();
@@ -804,7 +827,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
         if (rootFastPath && P.chainFirst == 0 && L.inst && !L.counted && static_cast<size_t>(P.res[0].n_states) == cnt &&
             P.res[0].cost == 0 && static_cast<int32_t>(cnt) == L.inst->nAgents() && L.inst->llSearches() == 0 &&
             (opt.max_hl_expansions < 0 || opt.max_hl_expansions >= 1)) {
-          writeRootSolution(P.chainRes, sols[gidx[k]]);
+          writeRootSolution(P.chainRes, solOf(gidx[k]));
           int64_t ll = 0;
           for (const mrp_ll_result& r : P.chainRes) ll += r.expanded;
           ranExpansions += ll;
@@ -943,7 +966,7 @@ void runGroupSession(mrp_ll_ctx* ctx, const mrp_hl_options& opt, const mrp_hl_in
   if (failed) return;
   for (size_t k = 0; k < live.size(); ++k)
     if (live[k].inst) {  // (none: the loop ends when every instance has been retired)
-      writeSolution(*live[k].inst, sols[gidx[k]]);
+      writeSolution(*live[k].inst, solOf(gidx[k]));
       out.expansions += live[k].inst->llExpanded();
       out.specSearches += live[k].inst->specSearches();
     }
@@ -1054,6 +1077,7 @@ int mrp_hl_solver_preload(mrp_hl_solver* s, int32_t nThreadsWanted, int32_t nIns
   *out = nullptr;
   int32_t nThreads = static_cast<int32_t>(s->engines.size());
   if (nThreadsWanted > 0) nThreads = std::min(nThreads, nThreadsWanted);
+  const int32_t nEng = std::max(1, nThreads);  // engines that receive the maps: all the caller allows, however small the batch
   nThreads = std::max(1, std::min(nThreads, std::max(nInst, 1)));
   auto* p = new mrp_hl_preloaded();
   p->owner = s;
@@ -1065,11 +1089,11 @@ int mrp_hl_solver_preload(mrp_hl_solver* s, int32_t nThreadsWanted, int32_t nIns
   // driver lets the workers draw instances from one pool.  idx / mapIds keep the interleaved static split (instance k ->
   // thread k % nThreads) for the round-based schedule.
   for (int32_t k = 0; k < nInst; ++k) p->idx[k % nThreads].push_back(k);
-  p->mapBase.assign(nThreads, 0);
-  std::vector<int> rcs(nThreads, MRP_LL_SUCCESS);
+  p->mapBase.assign(nEng, 0);
+  std::vector<int> rcs(nEng, MRP_LL_SUCCESS);
   {
     std::vector<std::thread> th;
-    for (int32_t t = 0; t < nThreads; ++t)
+    for (int32_t t = 0; t < nEng; ++t)
       th.emplace_back([&, t]() {
         for (int32_t k = 0; k < nInst; ++k) {
           const mrp_hl_instance& in = instances[k];
@@ -1085,13 +1109,14 @@ int mrp_hl_solver_preload(mrp_hl_solver* s, int32_t nThreadsWanted, int32_t nIns
       });
     for (auto& x : th) x.join();
   }
-  for (int32_t t = 0; t < nThreads; ++t) {
+  for (int32_t t = 0; t < nEng; ++t) {
     if (rcs[t] != MRP_LL_SUCCESS) {
       s->err = std::string("mrp_ll_upload_map / mrp_ll_sync_maps: ") + mrp_ll_last_error(s->engines[t]);
       delete p;
       return rcs[t];
     }
-    for (int32_t k : p->idx[t]) p->mapIds[t].push_back(p->mapBase[t] + k);
+    if (t < nThreads)
+      for (int32_t k : p->idx[t]) p->mapIds[t].push_back(p->mapBase[t] + k);
   }
   s->nPreloaded += 1;
   *out = p;
@@ -1120,11 +1145,43 @@ int mrp_hl_solver_solve(mrp_hl_solver* s, const mrp_hl_options* optIn, int32_t n
 
 int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn, mrp_hl_preloaded* pre,
                                   mrp_hl_solution* solutions, mrp_hl_batch_stats* stats) {
-  if (!s || !optIn || !pre || (pre->nInst > 0 && !solutions)) return MRP_LL_E_INVALID;
+  return mrp_hl_solver_solve_stream(s, optIn, 1, &pre, &solutions, stats);
+}
+
+// mrp_hl.h: n batches as one pool of instances.  One batch: every schedule of the drivers (rounds, static split, shared
+// pool); several: the shared pool of the session driver (the others keep a barrier between batches by construction).
+int mrp_hl_solver_solve_stream(mrp_hl_solver* s, const mrp_hl_options* optIn, int32_t nBatches, mrp_hl_preloaded* const* pres,
+                               mrp_hl_solution* const* solsArr, mrp_hl_batch_stats* stats) {
+  if (!s || !optIn || nBatches < 1 || !pres || !solsArr) return MRP_LL_E_INVALID;
+  for (int32_t b = 0; b < nBatches; ++b)
+    if (!pres[b] || pres[b]->owner != s || (pres[b]->nInst > 0 && !solsArr[b])) return MRP_LL_E_INVALID;
   mrp_hl_options opt = *optIn;
-  const int32_t nInst = pre->nInst;
+  mrp_hl_preloaded* pre = pres[0];
+  mrp_hl_solution* solutions = solsArr[0];
+  StreamView view;
+  int64_t total = 0;
+  for (int32_t b = 0; b < nBatches; ++b) {
+    view.first.push_back(static_cast<int32_t>(total));
+    view.inst.push_back(pres[b]->instances);
+    view.sols.push_back(solsArr[b]);
+    view.mapBase.push_back(&pres[b]->mapBase);
+    total += pres[b]->nInst;
+  }
+  if (total > INT32_MAX) return MRP_LL_E_INVALID;
+  view.first.push_back(static_cast<int32_t>(total));
+  const bool streamed = nBatches > 1;
+  if (streamed && (opt.mode == 1 || std::getenv("MRP_HL_STATIC_SPLIT") != nullptr)) {
+    s->err = "mrp_hl_solver_solve_stream: several batches need the session driver's shared pool (mode 0, no MRP_HL_STATIC_SPLIT)";
+    return MRP_LL_E_INVALID;
+  }
+  const int32_t nInst = static_cast<int32_t>(total);
   const mrp_hl_instance* instances = pre->instances;
-  const int32_t nThreads = static_cast<int32_t>(pre->idx.size());
+  int32_t nThreads = static_cast<int32_t>(pre->idx.size());
+  if (streamed) {  // engines that hold every batch's maps, and not more of them than there are instances
+    nThreads = static_cast<int32_t>(pre->mapBase.size());
+    for (int32_t b = 1; b < nBatches; ++b) nThreads = std::min(nThreads, static_cast<int32_t>(pres[b]->mapBase.size()));
+    nThreads = std::max(1, std::min(nThreads, std::max(nInst, 1)));
+  }
   const int32_t horizon = s->llOpt.max_horizon > 0 ? s->llOpt.max_horizon : 512;
   std::vector<std::vector<int32_t>>& idx = pre->idx;
   std::vector<std::vector<int32_t>>& mapIds = pre->mapIds;
@@ -1134,7 +1191,8 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   // [time][agents rounded up to 16] halfwords; 64 time steps of it are kept in LDS, the rest of a longer table lives in
   // the search's arena slot.
   int32_t maxAgents = 1;
-  for (int32_t k = 0; k < nInst; ++k) maxAgents = std::max(maxAgents, instances[k].n_agents);
+  for (int32_t b = 0; b < nBatches; ++b)
+    for (int32_t k = 0; k < pres[b]->nInst; ++k) maxAgents = std::max(maxAgents, pres[b]->instances[k].n_agents);
   const int32_t agentsPad = (maxAgents + 15) & ~15;
   int32_t occupancy = 4;
   if (s->llOpt.lds_nodes == 0 && opt.mode != 1) {  // the caller did not choose a geometry: pick one for this batch
@@ -1219,6 +1277,7 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
   }
   // one pool of instances for all workers (MRP_HL_STATIC_SPLIT=1 restores the fixed interleaved split)
   std::atomic<int32_t> nextInstance(0);
+  const std::vector<int32_t> noIdx;  // (a stream has no static split)
   int32_t sessionGate = 0;  // mrp_ll_session_begin_tiers_gated: every worker's heavy launch before anybody's front launch
   const bool sharedPool = sharedPoolMode;
   auto t0 = std::chrono::steady_clock::now();
@@ -1242,9 +1301,10 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
         if (opt.mode == 1)
           runGroup(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, gr[t]);
         else if (sharedPool)
-          runGroupSession(s->engines[e], opt, instances, solutions, idx[e], mapIds[e], horizon, sessionWgs, pathSlots,
+          runGroupSession(s->engines[e], opt, instances, solutions, streamed ? noIdx : idx[e], streamed ? noIdx : mapIds[e],
+                          horizon, sessionWgs, pathSlots,
                           gr[t], &nextInstance, nInst, pre->mapBase[e], nWork, heavyPer, &sessionGate, nRun, coIndex, coCount,
-                          coCount > 1 ? &coSync[e] : nullptr);
+                          coCount > 1 ? &coSync[e] : nullptr, streamed ? &view : nullptr, e);
         else
           runGroupSession(s->engines[t], opt, instances, solutions, idx[t], mapIds[t], horizon, sessionWgs, pathSlots,
                           gr[t], nullptr, 0, 0, nRun, heavyPer, &sessionGate, nRun);
@@ -1270,7 +1330,8 @@ int mrp_hl_solver_solve_preloaded(mrp_hl_solver* s, const mrp_hl_options* optIn,
     st.ll_call_seconds += g.llS;
     st.consume_seconds += g.consumeS;
   }
-  for (int32_t k = 0; k < nInst; ++k) st.solved += solutions[k].status == MRP_HL_SOLVED ? 1 : 0;
+  for (int32_t b = 0; b < nBatches; ++b)
+    for (int32_t k = 0; k < pres[b]->nInst; ++k) st.solved += solsArr[b][k].status == MRP_HL_SOLVED ? 1 : 0;
   if (stats) *stats = st;
   return MRP_LL_SUCCESS;
 }

@@ -58,6 +58,7 @@ class mrp_hl_sipp_solution(ctypes.Structure):
 
 
 EXPORTS = ["mrp_hl_solver_prioritized_sipp", "mrp_hl_solver_preload", "mrp_hl_solver_solve_preloaded",
+           "mrp_hl_solver_solve_stream",
            "mrp_hl_preloaded_free", "mrp_hl_solve_batch", "mrp_hl_solver_create", "mrp_hl_solver_destroy", "mrp_hl_solver_solve",
            "mrp_hl_solver_ll_stats", "mrp_hl_solver_last_error", "mrp_hl_generate_instance", "mrp_hl_generate_instances", "mrp_hl_astar_grid2d",
            "mrp_hl_ct_create", "mrp_hl_ct_destroy", "mrp_hl_ct_n_requests", "mrp_hl_ct_request", "mrp_hl_ct_deliver",
@@ -95,6 +96,10 @@ def load_library(path: Optional[str] = None):
         lib.mrp_hl_solver_preload.restype = ctypes.c_int
         lib.mrp_hl_solver_preload.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                               ctypes.POINTER(mrp_hl_instance), ctypes.POINTER(ctypes.c_void_p)]
+        lib.mrp_hl_solver_solve_stream.restype = ctypes.c_int
+        lib.mrp_hl_solver_solve_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(mrp_hl_options), ctypes.c_int32,
+                                                   ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                                   ctypes.POINTER(mrp_hl_batch_stats)]
         lib.mrp_hl_solver_solve_preloaded.restype = ctypes.c_int
         lib.mrp_hl_solver_solve_preloaded.argtypes = [ctypes.c_void_p, ctypes.POINTER(mrp_hl_options), ctypes.c_void_p,
                                                       ctypes.POINTER(mrp_hl_solution), ctypes.POINTER(mrp_hl_batch_stats)]
@@ -318,6 +323,28 @@ class BatchSolver:
                      speculative_searches=st.speculative_searches, wasted_ll_expansions=st.wasted_ll_expansions,
                      root_solved=st.root_solved)
         return (None if raw else self.results_of(prep)), stats
+
+    def solve_stream(self, preps, algo: int = ECBS, w: float = 1.3, max_ll_expansions: int = -1,
+                     max_hl_expansions: int = -1):
+        """Several prepared batches as ONE stream (mrp_hl.h mrp_hl_solver_solve_stream): no barrier between batches, so
+        the dependent chains that end one batch overlap with the next batch's root searches.  Every batch's results are
+        those of its own solve_prepared call; read them with result_arrays / results_of.  Returns the stream's statistics."""
+        n = len(preps)
+        if n == 0:
+            raise ValueError("solve_stream needs at least one prepared batch")
+        opt = mrp_hl_options(algo, w, max_ll_expansions, max_hl_expansions, 0, 0)
+        st = mrp_hl_batch_stats()
+        handles = (ctypes.c_void_p * n)(*[p["handle"] for p in preps])
+        sols = (ctypes.c_void_p * n)(*[ctypes.cast(p["csol"], ctypes.c_void_p) for p in preps])
+        rc = self._lib.mrp_hl_solver_solve_stream(self._h, ctypes.byref(opt), n, handles, sols, ctypes.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"mrp_hl_solver_solve_stream failed rc={rc}: "
+                               f"{self._lib.mrp_hl_solver_last_error(self._h).decode()}")
+        return dict(wall_seconds=st.wall_seconds, rounds=st.rounds, ll_searches=st.ll_searches,
+                    ll_expansions=st.ll_expansions, solved=st.solved, build_seconds=st.build_seconds,
+                    ll_call_seconds=st.ll_call_seconds, consume_seconds=st.consume_seconds,
+                    speculative_searches=st.speculative_searches, wasted_ll_expansions=st.wasted_ll_expansions,
+                    root_solved=st.root_solved, batches=n)
 
     def result_arrays(self, prep) -> Dict[str, np.ndarray]:
         """The results of a prepared batch as numpy arrays (status, cost, makespan, hl_expanded, ll_expanded, ll_searches,

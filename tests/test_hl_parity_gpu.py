@@ -359,6 +359,34 @@ def test_bench_scale_properties_and_determinism(solver):
     assert n_solved >= 4090
 
 
+@pytest.mark.gpu
+def test_stream_of_batches_equals_separate_solves_on_the_gpu(solver):
+    """mrp_hl_solver_solve_stream on the GPU: four synthetic agents10 batches as one stream (no barrier between batches)
+    against the same batches solved one call each — status, cost, both expansion counters, schedule digest and path lengths
+    of every instance, and the sums in the statistics."""
+    import numpy as np
+    from libmultirobotplanning_amd import hl
+    batches = [hl.generate_instances(77000 + 5000 * b, n, 32, 32, 204, 10) for b, n in enumerate((3000, 1, 2048, 777))]
+    a = [solver.prepare(b, want_paths=True, path_cap=128) for b in batches]
+    c = [solver.prepare(b, want_paths=True, path_cap=128) for b in batches]
+    try:
+        st = solver.solve_stream(a, algo=hl.ECBS, w=1.3, max_ll_expansions=50000)
+        exp = 0
+        for pa, pc in zip(a, c):
+            _, s1 = solver.solve_prepared(pc, algo=hl.ECBS, w=1.3, max_ll_expansions=50000, raw=True)
+            exp += s1["ll_expansions"]
+            ra, rc = solver.result_arrays(pa), solver.result_arrays(pc)
+            solved = rc["status"] == hl.SOLVED
+            assert np.array_equal(ra["status"], rc["status"])
+            for f in ("cost", "makespan", "hl_expanded", "ll_expanded", "schedule_digest"):
+                assert np.array_equal(ra[f][solved], rc[f][solved]), f
+            assert np.array_equal(ra["path_len"][solved], rc["path_len"][solved])
+        assert st["ll_expansions"] == exp and st["batches"] == 4
+    finally:
+        for p in a + c:
+            solver.release(p)
+
+
 def test_caller_stepped_conflict_tree_on_the_gpu(bench_instances, oracle_expected):
     """mrp_hl_ct_* + ct_sharded.solve_sharded with the product executor (this GPU through the C-ABI), world size 1: the
     same results as the batch drivers and the oracle for look-ahead widths 1 and 4 (the multi-rank exchange itself is
