@@ -12,6 +12,13 @@ over the whole job; `instances_per_s` rides along.  Instances are generated nati
 one mrp_hl_generate_instances call per batch) before the timed region and their maps are uploaded to HBM before it
 starts, as the reference constructs its Environment before its Timer (example/ecbs.cpp:576-582).
 
+The K timed steps go to the solver as ONE STREAM of K batches (mrp_hl_solver_solve_stream, config.steps_as_one_stream):
+every batch is solved completely and delivered inside the timed region, bracketed by the barrier + synchronize pair, but
+there is no barrier BETWEEN steps — the workers start on batch i + 1 while the last dependent chains of batch i (deep
+conflict trees, searches that run to the harness cap: ~95 ms during which a lone step leaves the device four-fifths
+idle) finish.  ms_per_step = region / K.  `one_call_per_step` = the same steps again with one solver call each
+(--sync-steps, after the timed region), and --no-stream times the region that way.
+
 The timed region DELIVERS SCHEDULES: every solved instance's paths are written to the caller's buffers
 (mrp_hl_solution.paths_xy, the equivalent of `solution = P.solution`, ecbs.hpp:238) inside it (config.delivers_schedules).
 
