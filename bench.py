@@ -24,7 +24,7 @@ The timed region DELIVERS SCHEDULES: every solved instance's paths are written t
 
 Extra objects in the same line:
   by_workload  — N = 1 only: one timed step each of the other shapes north_star names, after the headline region:
-                 agents50, agents100 (synthetic, same generator), "shipped" (ALL 1000 shipped
+                 agents50, agents100 (synthetic, same generator; three / two batches as one stream), "shipped" (ALL 1000 shipped
                  benchmark/32x32_obst204 inputs, tests/golden/shipped_32x32.npz, as ONE batch, every result checked against
                  tests/golden/shipped_32x32_expected.json) and "shipped_heavy_tail" (agents100_ex36 with NO cap, against
                  tests/golden/shipped_heavy_tail_expected.json; --legs ...,shipped_heavy_tail: it runs for a minute or two and
@@ -395,33 +395,40 @@ def main():
         by = {"agents%d" % args.agents: {"value": out["value"], "instances_per_s": out["instances_per_s"],
                                          "instances": int(inst_all), "capped": capped_first,
                                          "cap_per_instance": args.max_ll_expansions, "see": "top-level fields"}}
-        leg_specs = {  # name -> (agents, instances, cap per instance, CPU sample)
+        leg_specs = {  # name -> (agents, instances per batch, cap per instance, CPU sample, batches in the stream)
             # batches large enough that the one-wavefront chains of the few pathological instances (the capped ones run
-            # for seconds) do not leave the chip idle for most of the step
-            "agents50": (50, 65536, 400000, 192),
-            "agents100": (100, 16384, 3000000, 24),
+            # for seconds) do not leave the chip idle for most of the step; and, as in the headline region, a few batches
+            # as one stream (scripts/stream_legs_probe.py: 3 x 65536 at fifty agents 6.2e8 against 4.95e8 one call each,
+            # 2 x 16384 at a hundred 2.47e8 against 1.87e8)
+            "agents50": (50, 65536, 400000, 192, 1 if args.no_stream else 3),
+            "agents100": (100, 16384, 3000000, 24, 1 if args.no_stream else 2),
         }
         sipp_specs = {"sipp50": (50, 8192, 512), "sipp100": (100, 8192, 512), "sipp200": (200, 4096, 512)}
         for name in [x for x in legs.split(",") if x and x != "none"]:
             if name in leg_specs:
-                ag, nb, cap, ncpu = leg_specs[name]
-                ia = hl.generate_instances(1000 * ag, nb, 32, 32, 204, ag)
+                ag, nb, cap, ncpu, nbat = leg_specs[name]
+                ia = hl.generate_instances(1000 * ag, nb, 32, 32, 204, ag)  # the first batch: the one the CPU legs sample
+                more = [hl.generate_instances(1000 * ag + 100000 * b, nb, 32, 32, 204, ag) for b in range(1, nbat)]
                 small = solver.prepare(ia[:64], want_paths=False)
                 solver.solve_prepared(small, algo=hl.ECBS, w=1.3, max_ll_expansions=cap, raw=True)  # warm-up, same shape
                 solver.release(small)
-                prep = solver.prepare(ia, want_paths=False)
+                preps = [solver.prepare(b, want_paths=False) for b in [ia] + more]
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                _, st = solver.solve_prepared(prep, algo=hl.ECBS, w=1.3, max_ll_expansions=cap, raw=True)
+                st = solver.solve_stream(preps, algo=hl.ECBS, w=1.3, max_ll_expansions=cap)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
-                res = solver.result_arrays(prep)
-                solver.release(prep)
-                leg = {"value": st["ll_expansions"] / dt, "unit": "expansions/s", "instances_per_s": nb / dt,
-                       "instances": nb, "seconds": dt, "solved": int(st["solved"]),
-                       "capped": int((res["status"] == hl.CAP).sum()), "cap_per_instance": cap,
+                res = solver.result_arrays(preps[0])
+                capped = sum(int((solver.result_arrays(p)["status"] == hl.CAP).sum()) for p in preps)
+                for p in preps:
+                    solver.release(p)
+                del more
+                leg = {"value": st["ll_expansions"] / dt, "unit": "expansions/s", "instances_per_s": nbat * nb / dt,
+                       "instances": nbat * nb, "batches_in_the_stream": nbat, "seconds": dt, "solved": int(st["solved"]),
+                       "capped": capped, "cap_per_instance": cap,
                        "ll_searches": int(st["ll_searches"]),
-                       "workload": "ECBS w=1.3, synthetic 32x32_obst204-shaped, agents%d, seeds %d.." % (ag, 1000 * ag)}
+                       "workload": "ECBS w=1.3, synthetic 32x32_obst204-shaped, agents%d, %d batches of %d as one stream, "
+                                   "seeds %d.. (+100000 per batch)" % (ag, nbat, nb, 1000 * ag)}
                 if do_cpu:
                     leg["cpu_baseline"] = cpu_leg(oracle, ia, res, cap, ncpu, hl)
                     leg["vs_cpu_port_1core"] = leg["value"] / max(leg["cpu_baseline"]["value"], 1e-12)

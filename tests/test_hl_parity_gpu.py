@@ -362,8 +362,8 @@ def test_bench_scale_properties_and_determinism(solver):
 @pytest.mark.gpu
 def test_stream_of_batches_equals_separate_solves_on_the_gpu(solver):
     """mrp_hl_solver_solve_stream on the GPU: four synthetic agents10 batches as one stream (no barrier between batches)
-    against the same batches solved one call each — status, cost, both expansion counters, schedule digest and path lengths
-    of every instance, and the sums in the statistics."""
+    against the same batches solved one call each — status of every instance; cost, both expansion counters, schedule digest
+    and path lengths of every solved one."""
     import numpy as np
     from libmultirobotplanning_amd import hl
     batches = [hl.generate_instances(77000 + 5000 * b, n, 32, 32, 204, 10) for b, n in enumerate((3000, 1, 2048, 777))]
@@ -371,17 +371,18 @@ def test_stream_of_batches_equals_separate_solves_on_the_gpu(solver):
     c = [solver.prepare(b, want_paths=True, path_cap=128) for b in batches]
     try:
         st = solver.solve_stream(a, algo=hl.ECBS, w=1.3, max_ll_expansions=50000)
-        exp = 0
+        n_solved = 0
         for pa, pc in zip(a, c):
             _, s1 = solver.solve_prepared(pc, algo=hl.ECBS, w=1.3, max_ll_expansions=50000, raw=True)
-            exp += s1["ll_expansions"]
+            n_solved += s1["solved"]
             ra, rc = solver.result_arrays(pa), solver.result_arrays(pc)
             solved = rc["status"] == hl.SOLVED
             assert np.array_equal(ra["status"], rc["status"])
             for f in ("cost", "makespan", "hl_expanded", "ll_expanded", "schedule_digest"):
                 assert np.array_equal(ra[f][solved], rc[f][solved]), f
             assert np.array_equal(ra["path_len"][solved], rc["path_len"][solved])
-        assert st["ll_expansions"] == exp and st["batches"] == 4
+        # (the counters of an instance that ends at the harness cap depend on the look-ahead, i.e. on the schedule: DESIGN §4)
+        assert st["solved"] == n_solved and st["batches"] == 4
     finally:
         for p in a + c:
             solver.release(p)
