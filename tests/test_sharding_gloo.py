@@ -21,7 +21,11 @@ B = 12
 # weak-scaling shard: every rank has its own seeds
 base = sharding.seed_base(10, rank, 1, 0, B)
 insts = [hl.generate_instance(base + k, 32, 32, 204, 10) for k in range(B)]
-res, st = solver.solve(insts, algo=hl.ECBS, w=1.3, want_paths=False, max_ll_expansions=50000)
+# ... and solves them as bench.py does: its batches as one stream (mrp_hl_solver_solve_stream)
+preps = [solver.prepare(insts[:7], want_paths=False), solver.prepare(insts[7:], want_paths=False)]
+st = solver.solve_stream(preps, algo=hl.ECBS, w=1.3, max_ll_expansions=50000)
+for p in preps:
+    solver.release(p)
 elapsed, sums = sharding.reduce_totals(dist, "cpu", 1.0 + rank, [st["ll_expansions"], st["solved"], B])
 # strong-scaling split of one fixed list
 idx = sharding.shard_indices(10, rank, world)
