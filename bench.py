@@ -403,7 +403,10 @@ def main():
             "agents50": (50, 65536, 400000, 192, 1 if args.no_stream else 3),
             "agents100": (100, 16384, 3000000, 24, 1 if args.no_stream else 2),
         }
-        sipp_specs = {"sipp50": (50, 8192, 512), "sipp100": (100, 8192, 512), "sipp200": (200, 4096, 512)}
+        # (batch sizes: every instance is a chain of `agents` dependent searches, and the shortest chains need the largest
+        # batch to keep the device's 4096 resident searches fed to the end — measured, scripts/sipp_bench.py: fifty agents
+        # 6.0e8 / 6.8e8 / 7.5e8 at 8192 / 16384 / 32768 instances)
+        sipp_specs = {"sipp50": (50, 32768, 512), "sipp100": (100, 8192, 512), "sipp200": (200, 8192, 512)}
         for name in [x for x in legs.split(",") if x and x != "none"]:
             if name in leg_specs:
                 ag, nb, cap, ncpu, nbat = leg_specs[name]
