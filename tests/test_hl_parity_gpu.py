@@ -360,6 +360,28 @@ def test_bench_scale_properties_and_determinism(solver):
 
 
 @pytest.mark.gpu
+def test_cbs_stream_on_the_gpu(solver, bench_instances, oracle_expected):
+    """mrp_hl_solver_solve_stream with CBS sessions (mrp_ll_cbs_persistent_kernel): the shipped 8x8 inputs the oracle solves,
+    as three batches (the middle one empty) of one stream, against the golden vectors — schedules included."""
+    from libmultirobotplanning_amd import hl
+    names = [n for n in sorted(bench_instances) if "8by8" in n and oracle_expected[n]["cbs"]["rc"] == 1]
+    groups = [names[:7], [], names[7:]]
+    preps = [solver.prepare([bench_instances[n] for n in g], want_paths=True, path_cap=256) for g in groups]
+    try:
+        st = solver.solve_stream(preps, algo=hl.CBS)
+        for g, prep in zip(groups, preps):
+            for n, r in zip(g, solver.results_of(prep)):
+                e = oracle_expected[n]["cbs"]
+                assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
+                    hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"]), n
+                assert _digest(r["paths"]) == e["digest"], n
+        assert st["solved"] == len(names)
+    finally:
+        for prep in preps:
+            solver.release(prep)
+
+
+@pytest.mark.gpu
 def test_stream_of_batches_equals_separate_solves_on_the_gpu(solver):
     """mrp_hl_solver_solve_stream on the GPU: four synthetic agents10 batches as one stream (no barrier between batches)
     against the same batches solved one call each — status of every instance; cost, both expansion counters, schedule digest

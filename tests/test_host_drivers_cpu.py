@@ -79,6 +79,22 @@ def test_stream_of_batches_equals_separate_solves(cpu_solver, bench_instances, o
                 assert _digest(r["paths"]) == e["digest"], n
                 total += r["ll_expanded"]
         assert st["ll_expansions"] == total and st["solved"] == len(names) and st["batches"] == 3
+        # CBS (its own session kernels, independent root searches, no path store), mixed map sizes, an EMPTY batch in the middle
+        cn = [n for n in sorted(bench_instances) if "8by8" in n and oracle_expected[n]["cbs"]["rc"] == 1]
+        cgroups = [cn[:5], [], cn[5:]]
+        cpreps = [cpu_solver.prepare([bench_instances[n] for n in g], want_paths=True, path_cap=256) for g in cgroups]
+        try:
+            cst = cpu_solver.solve_stream(cpreps, algo=hl.CBS)
+            for g, prep in zip(cgroups, cpreps):
+                for n, r in zip(g, cpu_solver.results_of(prep)):
+                    e = oracle_expected[n]["cbs"]
+                    assert (r["status"], r["cost"], r["makespan"], r["hl_expanded"], r["ll_expanded"]) == (
+                        hl.SOLVED, e["cost"], e["makespan"], e["hl"], e["ll"]), n
+                    assert _digest(r["paths"]) == e["digest"], n
+            assert cst["solved"] == len(cn)
+        finally:
+            for prep in cpreps:
+                cpu_solver.release(prep)
         # the rounds schedule keeps a barrier between batches by construction: several batches are refused, not mis-served
         with pytest.raises(RuntimeError):
             opt_mode = cpu_solver._lib.mrp_hl_solver_solve_stream  # noqa: F841  (the binding exists)
