@@ -302,18 +302,33 @@ class Instance {
       ch.id = nextId_++;  // ++id happens whether or not the child's search succeeded
       if (a.status == MRP_LL_OK) {
         const PathPtr oldPath = ch.solution[ag];  // the parent's path of this agent
-        const int32_t oldT = maxT(ch.solution);
+        // focalHeuristic(child) (ecbs.hpp:272): incremental while the scan horizon is unchanged (grid_mapf.hpp).  One walk
+        // over the node's paths serves both horizons and both counts (PackedView: plain arrays of packed cells).
+        PackedView& pv = PackedView::local();
+        const bool packed = algo_ == MRP_HL_ECBS && pv.gather(ch.solution) && a.path->len() > 0 &&
+                            static_cast<int32_t>(a.path->cell.size()) == a.path->len();
+        int32_t oldT = 0, newT = 0;
+        if (packed) {
+          int32_t others = 0;  // longest path of the other agents
+          for (int32_t j = 0; j < n_; ++j)
+            if (j != ag) others = std::max(others, pv.len[j]);
+          oldT = std::max(others, pv.len[ag]) - 1;
+          newT = std::max(others, a.path->len()) - 1;
+        } else if (algo_ == MRP_HL_ECBS) {
+          oldT = maxT(ch.solution);
+        }
         ch.solution.set(ag, a.path);
         ch.cost += a.cost;
         if (algo_ == MRP_HL_ECBS) {
           ch.LB += a.fmin;
-          // focalHeuristic(child) (ecbs.hpp:272): incremental while the scan horizon is unchanged (grid_mapf.hpp)
-          const int32_t newT = maxT(ch.solution);
-          if (newT == oldT)
+          if (!packed) newT = maxT(ch.solution);
+          if (newT != oldT)
+            ch.focalHeuristic = countConflicts(ch.solution, scratch_);
+          else if (packed)
+            ch.focalHeuristic += conflictsOfAgentPacked(pv, ag, *a.path, newT) - conflictsOfAgentPacked(pv, ag, *oldPath, oldT);
+          else
             ch.focalHeuristic += conflictsOfAgent(ch.solution, ag, *a.path, newT) -
                                  conflictsOfAgent(ch.solution, ag, *oldPath, oldT);
-          else
-            ch.focalHeuristic = countConflicts(ch.solution, scratch_);
         }
         int32_t id = storeNode(chp);
         open_.push(id);

@@ -191,27 +191,65 @@ inline bool firstConflictQuadratic(const PathVec& sol, Conflict& out, std::vecto
   return false;
 }
 
+// The paths of a solution as plain arrays for the linear scans below: a scan looks at every agent at every time step, and
+// going through the chunked vector, the shared pointer, the Path and its vector for each of those looks was most of the
+// scan at a hundred agents (four dependent loads per look).  Packed cells (x | y << 8 per state, Path::packCells) are the
+// scans' keys already, and a quarter of the bytes of the coordinate pairs.  false: some path has no packed cells.
+struct PackedView {
+  std::vector<const uint16_t*> c;
+  std::vector<int32_t> len;
+  static PackedView& local() {
+    static thread_local PackedView v;
+    return v;
+  }
+  bool gather(const PathVec& sol) {
+    const size_t n = sol.size();
+    c.resize(n);
+    len.resize(n);
+    size_t i = 0;
+    for (const auto& p : sol) {
+      const int32_t l = p->len();
+      if (l == 0 || static_cast<int32_t>(p->cell.size()) != l) return false;
+      c[i] = p->cell.data();
+      len[i] = l;
+      ++i;
+    }
+    return true;
+  }
+};
+
 // The same result in O(T * N): at each t the agents are entered into the cell table in index order.
 //  * vertex: the lexicographically first pair (i<j) on a common cell is (first occupant, second occupant) of some
 //    cell; the minimum over cells is kept while scanning j upwards.
 //  * swap: reached only when no two agents share a cell at t, so "the agent now standing on i's next cell" is unique;
 //    scanning i upwards, the first i whose partner moves onto i's cell is the first pair in (i<j) order (a partner
 //    j < i would have reported the pair when the scan was at j).
-inline bool firstConflict(const PathVec& sol, Conflict& out, std::vector<int32_t>& scratch) {
-  if (!fitsCellTable(sol)) return firstConflictQuadratic(sol, out, scratch);
+template <bool PACKED>
+inline bool firstConflictLinear(const PathVec& sol, const PackedView& pv, Conflict& out, std::vector<int32_t>& scratch) {
   const int32_t n = static_cast<int32_t>(sol.size());
-  const int32_t T = maxT(sol);
   CellTable& tab = CellTable::local();
   scratch.resize(static_cast<size_t>(n) * 2);
   int32_t* cur = scratch.data();        // y << 8 | x at t
   int32_t* nxt = scratch.data() + n;    // at t + 1
-  auto keyAt = [](const Path& p, int32_t t) {
-    const int32_t k = t < p.len() ? t : p.len() - 1;
-    return (p.xy[2 * k + 1] << 8) | p.xy[2 * k];
+  auto keyAt = [&](int32_t i, int32_t t) -> int32_t {
+    if constexpr (PACKED) {
+      const int32_t l = pv.len[i];
+      return pv.c[i][t < l ? t : l - 1];
+    } else {
+      const Path& p = *sol[i];
+      const int32_t k = t < p.len() ? t : p.len() - 1;
+      return (p.xy[2 * k + 1] << 8) | p.xy[2 * k];
+    }
   };
-  for (int32_t i = 0; i < n; ++i) cur[i] = keyAt(*sol[i], 0);
+  int32_t T = 0;
+  if constexpr (PACKED) {
+    for (int32_t i = 0; i < n; ++i) T = std::max(T, pv.len[i] - 1);
+  } else {
+    T = maxT(sol);
+  }
+  for (int32_t i = 0; i < n; ++i) cur[i] = keyAt(i, 0);
   for (int32_t t = 0; t < T; ++t) {
-    for (int32_t i = 0; i < n; ++i) nxt[i] = keyAt(*sol[i], t + 1);
+    for (int32_t i = 0; i < n; ++i) nxt[i] = keyAt(i, t + 1);
     tab.nextStep();
     int32_t bi = n, bj = n;
     for (int32_t j = 0; j < n; ++j) {
@@ -244,6 +282,12 @@ inline bool firstConflict(const PathVec& sol, Conflict& out, std::vector<int32_t
   }
   return false;
 }
+inline bool firstConflict(const PathVec& sol, Conflict& out, std::vector<int32_t>& scratch) {
+  PackedView& pv = PackedView::local();
+  if (pv.gather(sol)) return firstConflictLinear<true>(sol, pv, out, scratch);  // (packed cells exist only when every coordinate fits 8 bits)
+  if (!fitsCellTable(sol)) return firstConflictQuadratic(sol, out, scratch);
+  return firstConflictLinear<false>(sol, pv, out, scratch);
+}
 
 // focalHeuristic (ecbs.cpp:315-350): number of vertex + swap conflicts over all pairs and t < max_t
 inline int32_t countConflictsQuadratic(const PathVec& sol, std::vector<int32_t>& scratch) {
@@ -271,24 +315,35 @@ inline int32_t countConflictsQuadratic(const PathVec& sol, std::vector<int32_t>&
 // The same integer with the cell table: agents on one cell are chained (who = last entered, link[] = the one before),
 // an agent entering a cell that already holds c agents adds c vertex conflicts, and the swap partners of agent i are
 // the agents j > i now on i's next cell whose next cell is i's current one.
-inline int32_t countConflicts(const PathVec& sol, std::vector<int32_t>& scratch) {
-  if (!fitsCellTable(sol)) return countConflictsQuadratic(sol, scratch);
+template <bool PACKED>
+inline int32_t countConflictsLinear(const PathVec& sol, const PackedView& pv, std::vector<int32_t>& scratch) {
   const int32_t n = static_cast<int32_t>(sol.size());
-  const int32_t T = maxT(sol);
   CellTable& tab = CellTable::local();
   scratch.resize(static_cast<size_t>(n) * 4);
   int32_t* cur = scratch.data();
   int32_t* nxt = scratch.data() + n;
   int32_t* link = scratch.data() + 2 * n;   // previous agent on the same cell, -1 = none
   int32_t* depth = scratch.data() + 3 * n;  // agents entered before this one on the same cell
-  auto keyAt = [](const Path& p, int32_t t) {
-    const int32_t k = t < p.len() ? t : p.len() - 1;
-    return (p.xy[2 * k + 1] << 8) | p.xy[2 * k];
+  auto keyAt = [&](int32_t i, int32_t t) -> int32_t {
+    if constexpr (PACKED) {
+      const int32_t l = pv.len[i];
+      return pv.c[i][t < l ? t : l - 1];
+    } else {
+      const Path& p = *sol[i];
+      const int32_t k = t < p.len() ? t : p.len() - 1;
+      return (p.xy[2 * k + 1] << 8) | p.xy[2 * k];
+    }
   };
-  for (int32_t i = 0; i < n; ++i) cur[i] = keyAt(*sol[i], 0);
+  int32_t T = 0;
+  if constexpr (PACKED) {
+    for (int32_t i = 0; i < n; ++i) T = std::max(T, pv.len[i] - 1);
+  } else {
+    T = maxT(sol);
+  }
+  for (int32_t i = 0; i < n; ++i) cur[i] = keyAt(i, 0);
   int32_t total = 0;
   for (int32_t t = 0; t < T; ++t) {
-    for (int32_t i = 0; i < n; ++i) nxt[i] = keyAt(*sol[i], t + 1);
+    for (int32_t i = 0; i < n; ++i) nxt[i] = keyAt(i, t + 1);
     tab.nextStep();
     for (int32_t j = 0; j < n; ++j) {
       const int32_t key = cur[j];
@@ -311,6 +366,12 @@ inline int32_t countConflicts(const PathVec& sol, std::vector<int32_t>& scratch)
     std::swap(cur, nxt);
   }
   return total;
+}
+inline int32_t countConflicts(const PathVec& sol, std::vector<int32_t>& scratch) {
+  PackedView& pv = PackedView::local();
+  if (pv.gather(sol)) return countConflictsLinear<true>(sol, pv, scratch);
+  if (!fitsCellTable(sol)) return countConflictsQuadratic(sol, scratch);
+  return countConflictsLinear<false>(sol, pv, scratch);
 }
 
 // Conflicts (vertex + swap, t < T) between path `p` of agent `ag` and every other agent of `sol` — the terms of
@@ -359,6 +420,31 @@ inline int32_t conflictsOfAgent(const PathVec& sol, int32_t ag, const Path& p, i
       total += (px == qx && py == qy);
       total += (px == qnx && py == qny && pnx == qx && pny == qy);
     }
+  }
+  return total;
+}
+
+// conflictsOfAgent's packed form over a gathered view (the entry of agent `ag` itself is not looked at): what the commit of a
+// conflict-tree child calls twice — for the new and for the replaced path — after ONE walk over the node's paths.
+inline int32_t conflictsOfAgentPacked(const PackedView& pv, int32_t ag, const Path& p, int32_t T) {
+  if (T <= 0) return 0;
+  const int32_t n = static_cast<int32_t>(pv.c.size());
+  static thread_local std::vector<uint16_t> pc;
+  pc.resize(static_cast<size_t>(T) + 2);
+  const int32_t lp = p.len();
+  for (int32_t t = 0; t <= T + 1; ++t) pc[t] = p.cell[t < lp ? t : lp - 1];
+  const uint16_t* P0 = pc.data();
+  int32_t total = 0;
+  for (int32_t j = 0; j < n; ++j) {
+    if (j == ag) continue;
+    const uint16_t* Q = pv.c[j];
+    const int32_t lq = pv.len[j];
+    const int32_t m = std::min(T, lq - 1);  // t < m: q(t) and q(t+1) are both real states
+    int32_t c = 0;
+    for (int32_t t = 0; t < m; ++t) c += (P0[t] == Q[t]) + ((P0[t] == Q[t + 1]) & (P0[t + 1] == Q[t]));
+    const uint16_t g = Q[lq - 1];           // from then on q stays on its last cell
+    for (int32_t t = m; t < T; ++t) c += (P0[t] == g) + ((P0[t] == g) & (P0[t + 1] == g));
+    total += c;
   }
   return total;
 }
