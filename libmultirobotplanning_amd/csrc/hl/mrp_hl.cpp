@@ -1166,8 +1166,11 @@ int mrp_hl_solver_solve_stream(mrp_hl_solver* s, const mrp_hl_options* optIn, in
     view.sols.push_back(solsArr[b]);
     view.mapBase.push_back(&pres[b]->mapBase);
     total += pres[b]->nInst;
+    if (total > INT32_MAX) {  // (checked before the next prefix is narrowed)
+      s->err = "mrp_hl_solver_solve_stream: more than 2^31 - 1 instances in one stream";
+      return MRP_LL_E_INVALID;
+    }
   }
-  if (total > INT32_MAX) return MRP_LL_E_INVALID;
   view.first.push_back(static_cast<int32_t>(total));
   const bool streamed = nBatches > 1;
   if (streamed && (opt.mode == 1 || std::getenv("MRP_HL_STATIC_SPLIT") != nullptr)) {
