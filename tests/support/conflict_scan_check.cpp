@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
       }
       p->cost = len - 1;
       p->fits8 = true;
+      if (c & 1) p->packCells();  // odd cases: the scans' packed-cell form (PackedView)
       sol.set(a, p);
     }
     Conflict a{}, b{};
